@@ -1,0 +1,193 @@
+/*
+ * bev_mi355x.h — C ABI of the MI355X-native batch_multi_bev_gen hot path.
+ *
+ * This is the drop-in boundary ("lower face").  The reference
+ * (soytony/Point-Cloud-Preprocessing-Tools) has no FFI layer of its own: its
+ * hot path is four C++ free functions that read file-scope globals.  Every
+ * entry point below names the reference interface it replaces (file:line are
+ * relative to the reference tree).  Only POD types and plain pointers cross
+ * this boundary; no C++/torch types.
+ *
+ * Conventions
+ *   - return 0 (BEV_OK) on success, a negative bev_status_t otherwise;
+ *     nothing throws, nothing calls exit().
+ *   - the caller owns every buffer it passes; the context owns its device
+ *     workspace, stream and events.
+ *   - one context per GPU, used by one host thread at a time.
+ *   - there is NO CPU fallback behind this ABI: if no HIP device is usable,
+ *     bev_create() fails with BEV_ERR_NO_DEVICE.
+ */
+#ifndef BEV_MI355X_H
+#define BEV_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEV_ABI_VERSION 1
+
+/* Ground-height grid of getBelongingGrid (BatchMultiBevGen.h:73-99,
+ * BatchMultiBevGen.cpp:25-26): 75 x 50 cells of 2 m. */
+#define BEV_GROUND_GRID_ROWS 75
+#define BEV_GROUND_GRID_COLS 50
+#define BEV_GROUND_GRID_CELLS (BEV_GROUND_GRID_ROWS * BEV_GROUND_GRID_COLS)
+
+typedef enum bev_status {
+    BEV_OK = 0,
+    BEV_ERR_INVALID_ARG = -1,
+    BEV_ERR_NO_DEVICE = -2,     /* no usable HIP device: there is no CPU path */
+    BEV_ERR_HIP = -3,           /* a HIP runtime call failed (see bev_last_error) */
+    BEV_ERR_OOM = -4,
+    BEV_ERR_UNSUPPORTED = -5,   /* parameter combination outside the built kernels */
+    BEV_ERR_TOO_LARGE = -6      /* n_frames / n_points above what bev_create sized */
+} bev_status_t;
+
+/* In-memory layout of pcl::PointXYZIRCT (BatchMultiBevGen.h:43-54): 32 bytes,
+ * 16-byte aligned; x@0 y@4 z@8 pad@12 intensity@16 row@20 col@22 t@24 label@28. */
+typedef struct bev_point {
+    float x, y, z, _pad0;
+    float intensity;
+    uint16_t row, col;
+    uint32_t t;
+    int16_t label;
+    uint16_t _pad1;
+} bev_point_t;
+
+/* SensorParams (include/Utility.h:30-36) plus the constants the reference
+ * hard-codes in computeAndSaveMultiBev / computeAndSaveSingleBev
+ * (BatchMultiBevGen.cpp:266-269,336-338) and main (:738). */
+typedef struct bev_params {
+    int32_t n_scan;             /* SensorParams::N_SCAN */
+    int32_t horizon_scan;       /* SensorParams::Horizon_SCAN */
+    int32_t ground_upper_scan;  /* SensorParams::GROUND_UPPER_SCAN */
+    float height_res;           /* SensorParams::HEIGHT_RES */
+    float interval;             /* 1.0f  (main :738) */
+    int32_t max_range;          /* 112   (:266,:336) */
+    int32_t n_layers;           /* 24    (:268,:271) */
+    float lidar_to_ground;      /* 2.0f  (:269,:338) */
+} bev_params_t;
+
+typedef struct bev_ctx bev_ctx_t;
+
+/* parseSensorType + getSensorParams (src/Utility.cpp:72-124) and the BEV
+ * defaults above.  `sensor` is matched by substring like the reference
+ * ("HDL_32E", "HDL_64E", "OS1_64").  Unknown sensor -> BEV_ERR_INVALID_ARG
+ * (the reference leaves the struct uninitialised). */
+int bev_params_for_sensor(const char *sensor, bev_params_t *out);
+
+/* Slots of the ordered range image: n_scan * horizon_scan. */
+size_t bev_num_slots(const bev_params_t *p);
+/* Bytes of one multi-layer BEV (.bin payload, BatchMultiBevGen.cpp:307-314)
+ * and of one single-layer BEV (cv::Mat single_bev, :340). */
+size_t bev_multi_bytes(const bev_params_t *p);
+size_t bev_single_bytes(const bev_params_t *p);
+
+/* Replaces the global state the reference sets up in main()
+ * (sensor_params_, four_neighbor_iterator_, BatchMultiBevGen.cpp:29,37,712-719).
+ * device        : HIP device ordinal (>= 0).
+ * max_batch     : frames processed per internal sub-batch (workspace is sized
+ *                 for this many; any n_frames is accepted later and looped).
+ * max_points    : largest per-frame input point count that will be passed. */
+int bev_create(bev_ctx_t **ctx, int device, const bev_params_t *p,
+               int max_batch, size_t max_points);
+void bev_destroy(bev_ctx_t *ctx);
+
+const char *bev_strerror(int status);
+/* Text of the last HIP error seen by this context ("" if none). */
+const char *bev_last_error(const bev_ctx_t *ctx);
+
+/* ---- whole hot path, host buffers ------------------------------------
+ * One call = the body of the per-file loop of main()
+ * (BatchMultiBevGen.cpp:727-757) for n_frames clouds, minus file I/O:
+ *   getOrderedCloud (:94-117) -> markGroundPoints (:119-252)
+ *   -> computeAndSaveMultiBev raster (:266-292)
+ *   -> computeAndSaveSingleBev raster (:336-356).
+ * pts[f]         : n_pts[f] unordered input points of frame f.
+ * ordered_out[f] : S points; labelled ordered cloud (what savePCDFileBinary
+ *                  writes at :756).
+ * multi_out[f]   : n_layers*M*M bytes, layer-major then row(x)-major — the
+ *                  exact .bin payload.
+ * single_out[f]  : M*M bytes, row(x)-major (cv::Mat single_bev).
+ * ground_mat_out : optional (NULL or per-frame NULL allowed); S int8 values,
+ *                  the final cv::Mat ground_mat of markGroundPoints. */
+int bev_process_batch(bev_ctx_t *ctx, int n_frames,
+                      const bev_point_t *const *pts, const uint32_t *n_pts,
+                      bev_point_t *const *ordered_out,
+                      uint8_t *const *multi_out,
+                      uint8_t *const *single_out,
+                      int8_t *const *ground_mat_out);
+
+/* ---- whole hot path, device-resident ----------------------------------
+ * Same computation, every data pointer is DEVICE memory; nothing crosses
+ * PCIe except a few hundred bytes of launch metadata.
+ * d_pts        : all frames' input points, packed; frame f occupies
+ *                [h_offsets[f], h_offsets[f+1]) (element offsets, HOST array
+ *                of n_frames+1 entries).
+ * d_ordered    : n_frames * S points.
+ * d_multi      : n_frames * bev_multi_bytes.
+ * d_single     : n_frames * bev_single_bytes.
+ * d_ground_mat : NULL or n_frames * S int8.
+ * Asynchronous on the context's stream; call bev_synchronize() (or
+ * hipDeviceSynchronize) before reading results. */
+int bev_process_device_resident(bev_ctx_t *ctx, int n_frames,
+                                const bev_point_t *d_pts,
+                                const uint64_t *h_offsets,
+                                bev_point_t *d_ordered,
+                                uint8_t *d_multi,
+                                uint8_t *d_single,
+                                int8_t *d_ground_mat);
+int bev_synchronize(bev_ctx_t *ctx);
+
+/* ---- per-function entry points (host buffers, one cloud) ---------------
+ * These let the reference-named C++ free functions be re-implemented as thin
+ * callers, one ABI call each. */
+
+/* getOrderedCloud (BatchMultiBevGen.cpp:94-117). out: S points. */
+int bev_order_cloud(bev_ctx_t *ctx, const bev_point_t *pts, uint32_t n_pts,
+                    bev_point_t *ordered_out);
+/* markGroundPoints (BatchMultiBevGen.cpp:119-252). `ordered` holds S points;
+ * labels are rewritten in place. ground_mat_out: NULL or S int8. */
+int bev_mark_ground(bev_ctx_t *ctx, bev_point_t *ordered, int8_t *ground_mat_out);
+/* Raster part of computeAndSaveMultiBev (:266-292) for any cloud of n points
+ * (points with label == 0 are skipped). out: bev_multi_bytes. */
+int bev_multi_bev(bev_ctx_t *ctx, const bev_point_t *cloud, uint32_t n,
+                  uint8_t *multi_out);
+/* Raster part of computeAndSaveSingleBev (:336-356). out: bev_single_bytes. */
+int bev_single_bev(bev_ctx_t *ctx, const bev_point_t *cloud, uint32_t n,
+                   uint8_t *single_out);
+
+/* ---- measurement ------------------------------------------------------- */
+#define BEV_MAX_KERNELS 16
+typedef struct bev_kernel_stat {
+    const char *name;      /* kernel symbol as rocprofv3 prints it */
+    uint64_t launches;     /* launches timed since the last reset */
+    double total_ms;       /* sum of HIP-event durations on the ctx stream */
+    uint64_t frames;       /* frames those launches covered */
+} bev_kernel_stat_t;
+/* When enabled, every kernel launch of bev_process_* is bracketed by HIP
+ * events recorded on the context's own stream. */
+int bev_profile_enable(bev_ctx_t *ctx, int on);
+int bev_profile_reset(bev_ctx_t *ctx);
+/* Synchronises, then fills up to `cap` entries; returns the number of kernels
+ * (or a negative status). */
+int bev_profile_get(bev_ctx_t *ctx, bev_kernel_stat_t *out, int cap);
+
+/* ---- test hooks (used by tests/ only; not part of the reference surface) - */
+/* Per-cell average ground heights of the LAST frame range processed:
+ * copies n_frames * 3750 floats (ground_grid_avg_heights after
+ * BatchMultiBevGen.cpp:210). */
+int bev_debug_get_cell_avg(bev_ctx_t *ctx, int first_frame, int n_frames, float *out);
+/* Evaluates the phase-A angle predicate (BatchMultiBevGen.cpp:169-179) on the
+ * device for n (dx,dy,dz) triples given as HOST arrays; out[i] = 1 if GROUND. */
+int bev_debug_angle_predicate(bev_ctx_t *ctx, const float *dx, const float *dy,
+                              const float *dz, uint8_t *out, size_t n);
+
+int bev_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEV_MI355X_H */

@@ -1,0 +1,104 @@
+/*
+ * bev_oracle.h — CPU restatement of the batch_multi_bev_gen hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * build, load or call it, and only as the checker / the timed CPU baseline.
+ * The product library (libbev_mi355x.so) never links or falls back to it.
+ *
+ * PARITY UNPINNED.  The reference ships no tests, golden vectors or fixtures
+ * for this path and cannot be built in this image
+ * (PCL / OpenCV / Eigen / fmt / Boost are absent and may not be stubbed), so
+ * this restatement is anchored on the reference SOURCE TEXT only — each
+ * function cites the lines it follows — plus hand-derived known-answer cases
+ * in tests/.  It has not been checked against outputs of the real binary.
+ *
+ * Third-party behaviour restated here (not under /root/reference):
+ *   - glibc libm atan2f / sqrtf / round / floor — called directly, so the
+ *     oracle inherits whatever libm the host has (glibc 2.35 in this image);
+ *   - OpenCV: cv::Mat::zeros / 0.01*ones / MatExpr divide on CV_32F are
+ *     restated as 0.0f, (float)(1.0f*0.01) and IEEE float division;
+ *   - x86-64 SSE2 float->int conversion (cvttss2si / cvttsd2si): out-of-range
+ *     and NaN inputs give INT_MIN ("integer indefinite"); the reference casts
+ *     without a range check, so that is what its binary does.
+ *
+ * All file:line citations are relative to the reference tree.
+ */
+#ifndef BEV_ORACLE_H
+#define BEV_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* pcl::PointXYZIRCT in memory, BatchMultiBevGen.h:43-54 (sizeof == 32). */
+typedef struct oracle_point {
+    float x, y, z, pad0;
+    float intensity;
+    uint16_t row, col;
+    uint32_t t;
+    int16_t label;
+    uint16_t pad1;
+} oracle_point_t;
+
+/* SensorParams, include/Utility.h:30-36. */
+typedef struct oracle_sensor {
+    int horizon_scan;
+    int n_scan;
+    int ground_upper_scan;
+    float height_res;
+} oracle_sensor_t;
+
+#define ORACLE_GRID_ROWS 75 /* BatchMultiBevGen.cpp:25 */
+#define ORACLE_GRID_COLS 50 /* BatchMultiBevGen.cpp:26 */
+
+/* getSensorParams, src/Utility.cpp:92-124. kind: 0 HDL_32E, 1 HDL_64E, 2 OS1_64.
+ * Returns 0, or -1 for an unknown kind. */
+int oracle_sensor_params(int kind, oracle_sensor_t *out);
+
+/* getBelongingGrid, BatchMultiBevGen.h:73-99. */
+void oracle_belonging_grid(float x, float y, int *sector_row, int *sector_col);
+
+/* getOrderedCloud, BatchMultiBevGen.cpp:94-117. out: S points, fully written. */
+void oracle_order_cloud(const oracle_sensor_t *sp, const oracle_point_t *in,
+                        size_t n_in, oracle_point_t *out);
+
+/* The angle test of markGroundPoints phase A, BatchMultiBevGen.cpp:169-179,
+ * for one (upper - lower) difference vector. Returns 1 if "ground". */
+int oracle_angle_is_ground(float diff_x, float diff_y, float diff_z);
+
+/* markGroundPoints, BatchMultiBevGen.cpp:119-252.  cloud: S ordered points,
+ * labels rewritten in place.  ground_mat: S int8 (required).  avg_out: NULL or
+ * 75*50 floats = ground_grid_avg_heights after the divide at :210. */
+void oracle_mark_ground(const oracle_sensor_t *sp, oracle_point_t *cloud,
+                        int8_t *ground_mat, float *avg_out);
+
+/* Raster part of computeAndSaveMultiBev, BatchMultiBevGen.cpp:266-292.
+ * out: 24 * M * M bytes laid out as the .bin file (:307-314), M = 224/interval. */
+void oracle_multi_bev(const oracle_sensor_t *sp, const oracle_point_t *cloud,
+                      size_t n, float interval, uint8_t *out);
+
+/* Raster part of computeAndSaveSingleBev, BatchMultiBevGen.cpp:336-356.
+ * out: M * M bytes, row index = x. */
+void oracle_single_bev(const oracle_point_t *cloud, size_t n, float interval,
+                       uint8_t *out);
+
+/* Whole per-frame body of main(), BatchMultiBevGen.cpp:735-747 (no file I/O).
+ * ground_mat may be NULL. */
+void oracle_process_frame(const oracle_sensor_t *sp, const oracle_point_t *in,
+                          size_t n_in, oracle_point_t *ordered, int8_t *ground_mat,
+                          uint8_t *multi, uint8_t *single);
+
+/* Float max-height BEV of batch_cloud_manip / cloud_manip (saveAsMat,
+ * BatchCloudManip.cpp:201-225, CloudManip.cpp:79-99).  skip_label0 = 1 for the
+ * batch variant (:218).  out: M*M floats, M = 200/interval + 1. */
+void oracle_float_bev(const oracle_point_t *cloud, size_t n, float interval,
+                      int skip_label0, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

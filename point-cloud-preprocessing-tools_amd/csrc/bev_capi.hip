@@ -1,0 +1,681 @@
+/*
+ * bev_capi.hip — context, workspace and the extern "C" boundary declared in
+ * include/bev_mi355x.h.  Host-side only; the kernels are in bev_kernels.hip.
+ *
+ * There is deliberately no CPU implementation behind these entry points: if
+ * HIP cannot give us a device, bev_create() fails.
+ */
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bev_internal.h"
+
+using namespace bevk;
+
+namespace {
+
+constexpr int kDescRing = 4;
+constexpr int kEventPairs = 2048;
+
+struct ProfSlot {
+    hipEvent_t a, b;
+    int kid;
+    int frames;
+};
+
+} // namespace
+
+struct bev_ctx {
+    int device = -1;
+    bev_params_t params{};
+    Geometry geo{};
+    int max_batch = 0;
+    size_t max_points = 0;
+    size_t multi_bytes = 0, single_bytes = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;
+
+    /* workspace for one sub-batch */
+    uint32_t *winner = nullptr;
+    uint32_t *codes = nullptr;
+    size_t codes_elems = 0;
+    Candidate *cand = nullptr;
+    uint32_t *ncand = nullptr;
+    float *zsorted = nullptr;
+    float *avg = nullptr;
+    int8_t *gm = nullptr; /* lazily allocated */
+
+    /* frame descriptors: ring of pinned host + device arrays */
+    FrameDesc *h_desc[kDescRing] = {nullptr, nullptr, nullptr, nullptr};
+    FrameDesc *d_desc[kDescRing] = {nullptr, nullptr, nullptr, nullptr};
+    size_t desc_cap[kDescRing] = {0, 0, 0, 0};
+    hipEvent_t desc_copied[kDescRing]{};
+    hipEvent_t desc_done[kDescRing]{};
+    bool desc_used[kDescRing] = {false, false, false, false};
+    int desc_next = 0;
+
+    /* staging for the host-buffer entry points (lazily allocated) */
+    bev_point_t *st_in = nullptr;
+    size_t st_in_elems = 0;
+    bev_point_t *st_ordered = nullptr;
+    uint8_t *st_multi = nullptr, *st_single = nullptr;
+    int8_t *st_gm = nullptr;
+    bool staging_ready = false;
+
+    /* profiling */
+    bool prof_on = false;
+    std::vector<ProfSlot> prof_pool;
+    size_t prof_used = 0;
+    double prof_ms[K_COUNT]{};
+    uint64_t prof_launches[K_COUNT]{};
+    uint64_t prof_frames[K_COUNT]{};
+
+    int last_sub_frames = 0;
+    std::string last_error;
+};
+
+namespace {
+
+int hip_fail(bev_ctx *c, hipError_t e, const char *what, int line)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s failed at bev_capi.hip:%d: %s", what, line, hipGetErrorString(e));
+    if (c) c->last_error = buf;
+    return e == hipErrorOutOfMemory ? BEV_ERR_OOM : BEV_ERR_HIP;
+}
+
+#define HIPCK(ctx, expr)                                                   \
+    do {                                                                   \
+        hipError_t e_ = (expr);                                            \
+        if (e_ != hipSuccess) return hip_fail((ctx), e_, #expr, __LINE__); \
+    } while (0)
+
+int mat_size_of(const bev_params_t *p)
+{
+    /* static int MAT_SIZE = MAX_RANGE*2 / interval;  BatchMultiBevGen.cpp:267 */
+    return bevx::cvtt_f32((float)(p->max_range * 2) / p->interval);
+}
+
+int validate_params(const bev_params_t *p)
+{
+    if (!p) return BEV_ERR_INVALID_ARG;
+    if (p->n_scan < 3 || p->n_scan > 65535 || p->horizon_scan < 5 || p->horizon_scan > 65535) return BEV_ERR_INVALID_ARG;
+    /* lo = N - G >= 2 keeps every index phase A touches inside the cloud
+     * (the reference would read out of bounds otherwise) */
+    if (p->ground_upper_scan < 1 || p->ground_upper_scan > p->n_scan - 2) return BEV_ERR_INVALID_ARG;
+    if (!(p->interval > 0.0f) || p->max_range <= 0) return BEV_ERR_INVALID_ARG;
+    if ((size_t)p->n_scan * (size_t)p->horizon_scan > ((size_t)1 << 26)) return BEV_ERR_UNSUPPORTED;
+    const int M = mat_size_of(p);
+    if (M < 16 || M > 512 || (M % 16) != 0) return BEV_ERR_UNSUPPORTED;
+    if (p->n_layers < 1 || p->n_layers > 30) return BEV_ERR_UNSUPPORTED;
+    return BEV_OK;
+}
+
+void fill_geometry(const bev_params_t *p, Geometry *g)
+{
+    g->N = p->n_scan;
+    g->H = p->horizon_scan;
+    g->G = p->ground_upper_scan;
+    g->S = p->n_scan * p->horizon_scan;
+    g->tiles = (g->S + kTile - 1) / kTile;
+    g->rp.max_range_f = (float)p->max_range;
+    g->rp.interval = p->interval;
+    g->rp.height_res = p->height_res;
+    g->rp.lidar_to_ground = p->lidar_to_ground;
+    g->rp.mat_size = mat_size_of(p);
+    g->rp.n_layers = p->n_layers;
+}
+
+/* ---- profiling -------------------------------------------------------- */
+int prof_flush(bev_ctx *c)
+{
+    for (size_t i = 0; i < c->prof_used; ++i) {
+        ProfSlot &s = c->prof_pool[i];
+        HIPCK(c, hipEventSynchronize(s.b));
+        float ms = 0.f;
+        HIPCK(c, hipEventElapsedTime(&ms, s.a, s.b));
+        c->prof_ms[s.kid] += ms;
+        c->prof_launches[s.kid] += 1;
+        c->prof_frames[s.kid] += (uint64_t)s.frames;
+    }
+    c->prof_used = 0;
+    return BEV_OK;
+}
+
+struct ProfScope {
+    bev_ctx *c;
+    ProfSlot *s = nullptr;
+    ProfScope(bev_ctx *ctx, int kid, int frames) : c(ctx)
+    {
+        if (!c->prof_on) return;
+        if (c->prof_used == c->prof_pool.size()) {
+            if (prof_flush(c) != BEV_OK) return;
+        }
+        s = &c->prof_pool[c->prof_used++];
+        s->kid = kid;
+        s->frames = frames;
+        (void)hipEventRecord(s->a, c->stream);
+    }
+    ~ProfScope()
+    {
+        if (s) (void)hipEventRecord(s->b, c->stream);
+    }
+};
+
+/* ---- frame descriptors -------------------------------------------------- */
+int acquire_desc(bev_ctx *c, size_t n, int *slot_out)
+{
+    const int k = c->desc_next;
+    c->desc_next = (k + 1) % kDescRing;
+    if (c->desc_used[k]) HIPCK(c, hipEventSynchronize(c->desc_done[k]));
+    if (c->desc_cap[k] < n) {
+        if (c->h_desc[k]) HIPCK(c, hipHostFree(c->h_desc[k]));
+        if (c->d_desc[k]) HIPCK(c, hipFree(c->d_desc[k]));
+        c->h_desc[k] = nullptr;
+        c->d_desc[k] = nullptr;
+        const size_t cap = std::max<size_t>(n, 64);
+        HIPCK(c, hipHostMalloc((void **)&c->h_desc[k], cap * sizeof(FrameDesc), hipHostMallocDefault));
+        HIPCK(c, hipMalloc((void **)&c->d_desc[k], cap * sizeof(FrameDesc)));
+        c->desc_cap[k] = cap;
+    }
+    *slot_out = k;
+    return BEV_OK;
+}
+
+int ensure_gm(bev_ctx *c)
+{
+    if (c->gm) return BEV_OK;
+    HIPCK(c, hipMalloc((void **)&c->gm, (size_t)c->max_batch * c->geo.S));
+    return BEV_OK;
+}
+
+/* The whole pipeline on device pointers.  `identity`: d_pts already holds
+ * ordered clouds (n_frames * S points) and the order stage is skipped.       */
+int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint64_t *h_offsets, bool identity,
+                 bev_point_t *d_ordered, uint8_t *d_multi, uint8_t *d_single, int8_t *d_gm)
+{
+    if (n_frames == 0) return BEV_OK;
+    const Geometry &g = c->geo;
+    const size_t S = (size_t)g.S;
+    HIPCK(c, hipSetDevice(c->device));
+    if (d_gm) {
+        int rc = ensure_gm(c);
+        if (rc != BEV_OK) return rc;
+    }
+
+    int ds = 0;
+    if (!identity) {
+        int rc = acquire_desc(c, (size_t)n_frames, &ds);
+        if (rc != BEV_OK) return rc;
+        for (int f = 0; f < n_frames; ++f) {
+            const uint64_t a = h_offsets[f], b = h_offsets[f + 1];
+            if (b < a || b - a > c->max_points) {
+                c->desc_used[ds] = false;
+                return BEV_ERR_TOO_LARGE;
+            }
+            c->h_desc[ds][f].in_offset = a;
+            c->h_desc[ds][f].n_pts = (uint32_t)(b - a);
+            c->h_desc[ds][f]._pad = 0;
+        }
+        HIPCK(c, hipMemcpyAsync(c->d_desc[ds], c->h_desc[ds], (size_t)n_frames * sizeof(FrameDesc),
+                                hipMemcpyHostToDevice, c->copy_stream));
+        HIPCK(c, hipEventRecord(c->desc_copied[ds], c->copy_stream));
+        HIPCK(c, hipStreamWaitEvent(c->stream, c->desc_copied[ds], 0));
+    }
+
+    for (int f0 = 0; f0 < n_frames; f0 += c->max_batch) {
+        const int nb = std::min(c->max_batch, n_frames - f0);
+        BatchPtrs b{};
+        b.pts = identity ? d_pts + (size_t)f0 * S : d_pts;
+        b.frames = identity ? nullptr : c->d_desc[ds] + f0;
+        b.winner = c->winner;
+        b.ordered = d_ordered + (size_t)f0 * S;
+        b.codes = c->codes;
+        b.cand = c->cand;
+        b.ncand = c->ncand;
+        b.zsorted = c->zsorted;
+        b.avg = c->avg;
+        b.gm = d_gm ? c->gm : nullptr;
+        b.multi = d_multi ? d_multi + (size_t)f0 * c->multi_bytes : nullptr;
+        b.single = d_single ? d_single + (size_t)f0 * c->single_bytes : nullptr;
+
+        if (!identity) {
+            uint32_t max_pts = 0;
+            for (int f = 0; f < nb; ++f) max_pts = std::max(max_pts, c->h_desc[ds][f0 + f].n_pts);
+            HIPCK(c, hipMemsetAsync(c->winner, 0, (size_t)nb * S * sizeof(uint32_t), c->stream));
+            {
+                ProfScope ps(c, K_ORDER_SCAN, nb);
+                launch_order_scan(g, b, nb, max_pts, c->stream);
+            }
+        }
+        {
+            ProfScope ps(c, K_GATHER_GROUND, nb);
+            launch_gather_ground(g, b, nb, identity, c->stream);
+        }
+        {
+            ProfScope ps(c, K_CELL_SUMS, nb);
+            launch_cell_sums(g, b, nb, c->stream);
+        }
+        {
+            ProfScope ps(c, K_GROUND_RESOLVE, nb);
+            launch_ground_resolve(g, b, nb, c->stream);
+        }
+        if (d_gm) {
+            ProfScope ps(c, K_GROUND_MAT, nb);
+            launch_ground_mat(g, b, d_gm + (size_t)f0 * S, nb, c->stream);
+        }
+        if (d_multi || d_single) {
+            ProfScope ps(c, K_BEV_RASTER, nb);
+            launch_bev_raster(g, c->codes, S, (uint32_t)S, b.multi, b.single, d_multi != nullptr,
+                              d_single != nullptr, nb, c->stream);
+        }
+        c->last_sub_frames = nb;
+        HIPCK(c, hipGetLastError());
+    }
+    if (!identity) {
+        HIPCK(c, hipEventRecord(c->desc_done[ds], c->stream));
+        c->desc_used[ds] = true;
+    }
+    return BEV_OK;
+}
+
+int ensure_staging(bev_ctx *c)
+{
+    if (c->staging_ready) return BEV_OK;
+    const size_t S = (size_t)c->geo.S;
+    const size_t per_frame = std::max(c->max_points, S);
+    c->st_in_elems = per_frame * (size_t)c->max_batch;
+    HIPCK(c, hipMalloc((void **)&c->st_in, c->st_in_elems * sizeof(bev_point_t)));
+    HIPCK(c, hipMalloc((void **)&c->st_ordered, (size_t)c->max_batch * S * sizeof(bev_point_t)));
+    HIPCK(c, hipMalloc((void **)&c->st_multi, (size_t)c->max_batch * c->multi_bytes));
+    HIPCK(c, hipMalloc((void **)&c->st_single, (size_t)c->max_batch * c->single_bytes));
+    HIPCK(c, hipMalloc((void **)&c->st_gm, (size_t)c->max_batch * S));
+    c->staging_ready = true;
+    return BEV_OK;
+}
+
+} // namespace
+
+/* ======================================================================== */
+extern "C" {
+
+int bev_abi_version(void) { return BEV_ABI_VERSION; }
+
+const char *bev_strerror(int status)
+{
+    switch (status) {
+    case BEV_OK: return "ok";
+    case BEV_ERR_INVALID_ARG: return "invalid argument";
+    case BEV_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
+    case BEV_ERR_HIP: return "HIP runtime error (see bev_last_error)";
+    case BEV_ERR_OOM: return "out of device memory";
+    case BEV_ERR_UNSUPPORTED: return "parameter combination not supported by the built kernels";
+    case BEV_ERR_TOO_LARGE: return "batch or point count larger than the context was created for";
+    default: return "unknown status";
+    }
+}
+
+const char *bev_last_error(const bev_ctx_t *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int bev_params_for_sensor(const char *sensor, bev_params_t *out)
+{
+    if (!sensor || !out) return BEV_ERR_INVALID_ARG;
+    /* parseSensorType: substring match, src/Utility.cpp:74-83; table :96-118 */
+    if (strstr(sensor, "HDL_32E")) {
+        out->n_scan = 32; out->horizon_scan = 1056; out->ground_upper_scan = 20; out->height_res = 0.5f;
+    } else if (strstr(sensor, "HDL_64E")) {
+        out->n_scan = 64; out->horizon_scan = 2083; out->ground_upper_scan = 50; out->height_res = 0.25f;
+    } else if (strstr(sensor, "OS1_64")) {
+        out->n_scan = 64; out->horizon_scan = 1024; out->ground_upper_scan = 31; out->height_res = 1.0f;
+    } else {
+        return BEV_ERR_INVALID_ARG;
+    }
+    out->interval = 1.0f;        /* BatchMultiBevGen.cpp:738 */
+    out->max_range = 112;        /* :266 */
+    out->n_layers = 24;          /* :268 */
+    out->lidar_to_ground = 2.0f; /* :269 */
+    return BEV_OK;
+}
+
+size_t bev_num_slots(const bev_params_t *p) { return p ? (size_t)p->n_scan * (size_t)p->horizon_scan : 0; }
+size_t bev_multi_bytes(const bev_params_t *p)
+{
+    if (!p || validate_params(p) != BEV_OK) return 0;
+    const size_t M = (size_t)mat_size_of(p);
+    return (size_t)p->n_layers * M * M;
+}
+size_t bev_single_bytes(const bev_params_t *p)
+{
+    if (!p || validate_params(p) != BEV_OK) return 0;
+    const size_t M = (size_t)mat_size_of(p);
+    return M * M;
+}
+
+int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch, size_t max_points)
+{
+    if (!out || !p || max_batch < 1 || max_batch > 65535 || max_points >= 0xffffffffull) return BEV_ERR_INVALID_ARG;
+    *out = nullptr;
+    int rc = validate_params(p);
+    if (rc != BEV_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BEV_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return BEV_ERR_NO_DEVICE;
+
+    bev_ctx *c = new (std::nothrow) bev_ctx();
+    if (!c) return BEV_ERR_OOM;
+    c->device = device;
+    c->params = *p;
+    fill_geometry(p, &c->geo);
+    c->max_batch = max_batch;
+    c->max_points = max_points;
+    c->multi_bytes = bev_multi_bytes(p);
+    c->single_bytes = bev_single_bytes(p);
+
+    auto fail = [&](int code) {
+        bev_destroy(c);
+        return code;
+    };
+#define CK(expr)                                                                     \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            int code_ = hip_fail(c, e_, #expr, __LINE__);                            \
+            fprintf(stderr, "bev_create: %s\n", c->last_error.c_str());              \
+            return fail(code_);                                                      \
+        }                                                                            \
+    } while (0)
+
+    CK(hipSetDevice(device));
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int k = 0; k < kDescRing; ++k) {
+        CK(hipEventCreateWithFlags(&c->desc_copied[k], hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&c->desc_done[k], hipEventDisableTiming));
+    }
+    const size_t S = (size_t)c->geo.S, nb = (size_t)max_batch;
+    c->codes_elems = std::max(nb * S, std::max(max_points, S));
+    CK(hipMalloc((void **)&c->winner, nb * S * sizeof(uint32_t)));
+    CK(hipMalloc((void **)&c->codes, c->codes_elems * sizeof(uint32_t)));
+    CK(hipMalloc((void **)&c->cand, nb * (size_t)c->geo.tiles * kTile * sizeof(Candidate)));
+    CK(hipMalloc((void **)&c->ncand, nb * (size_t)c->geo.tiles * sizeof(uint32_t)));
+    CK(hipMalloc((void **)&c->zsorted, nb * S * sizeof(float)));
+    CK(hipMalloc((void **)&c->avg, nb * (size_t)bevx::kGridCells * sizeof(float)));
+    /* >64 KiB dynamic LDS needs an explicit opt-in per kernel */
+    CK(configure_kernels(c->geo));
+    c->prof_pool.resize(kEventPairs);
+    for (auto &s : c->prof_pool) {
+        CK(hipEventCreate(&s.a));
+        CK(hipEventCreate(&s.b));
+    }
+#undef CK
+    *out = c;
+    return BEV_OK;
+}
+
+void bev_destroy(bev_ctx_t *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    void *dev[] = {c->winner, c->codes, c->cand, c->ncand, c->zsorted, c->avg, c->gm,
+                   c->st_in, c->st_ordered, c->st_multi, c->st_single, c->st_gm};
+    for (void *p : dev)
+        if (p) (void)hipFree(p);
+    for (int k = 0; k < kDescRing; ++k) {
+        if (c->h_desc[k]) (void)hipHostFree(c->h_desc[k]);
+        if (c->d_desc[k]) (void)hipFree(c->d_desc[k]);
+        if (c->desc_copied[k]) (void)hipEventDestroy(c->desc_copied[k]);
+        if (c->desc_done[k]) (void)hipEventDestroy(c->desc_done[k]);
+    }
+    for (auto &s : c->prof_pool) {
+        if (s.a) (void)hipEventDestroy(s.a);
+        if (s.b) (void)hipEventDestroy(s.b);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    delete c;
+}
+
+int bev_synchronize(bev_ctx_t *c)
+{
+    if (!c) return BEV_ERR_INVALID_ARG;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BEV_OK;
+}
+
+int bev_process_device_resident(bev_ctx_t *c, int n_frames, const bev_point_t *d_pts, const uint64_t *h_offsets,
+                                bev_point_t *d_ordered, uint8_t *d_multi, uint8_t *d_single, int8_t *d_ground_mat)
+{
+    if (!c || n_frames < 0 || !h_offsets || !d_ordered) return BEV_ERR_INVALID_ARG;
+    if (n_frames > 0 && !d_pts && h_offsets[n_frames] != h_offsets[0]) return BEV_ERR_INVALID_ARG;
+    return run_pipeline(c, n_frames, d_pts, h_offsets, false, d_ordered, d_multi, d_single, d_ground_mat);
+}
+
+int bev_process_batch(bev_ctx_t *c, int n_frames, const bev_point_t *const *pts, const uint32_t *n_pts,
+                      bev_point_t *const *ordered_out, uint8_t *const *multi_out, uint8_t *const *single_out,
+                      int8_t *const *ground_mat_out)
+{
+    if (!c || n_frames < 0 || (n_frames > 0 && (!pts || !n_pts || !ordered_out))) return BEV_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c);
+    if (rc != BEV_OK) return rc;
+    const size_t S = (size_t)c->geo.S;
+    std::vector<uint64_t> off;
+    for (int f0 = 0; f0 < n_frames; f0 += c->max_batch) {
+        const int nb = std::min(c->max_batch, n_frames - f0);
+        off.assign((size_t)nb + 1, 0);
+        bool any_gm = false;
+        for (int f = 0; f < nb; ++f) {
+            const uint32_t n = n_pts[f0 + f];
+            if (n > c->max_points) return BEV_ERR_TOO_LARGE;
+            if (n && !pts[f0 + f]) return BEV_ERR_INVALID_ARG;
+            off[f + 1] = off[f] + n;
+            if (n)
+                HIPCK(c, hipMemcpyAsync(c->st_in + off[f], pts[f0 + f], (size_t)n * sizeof(bev_point_t),
+                                        hipMemcpyHostToDevice, c->stream));
+            if (ground_mat_out && ground_mat_out[f0 + f]) any_gm = true;
+        }
+        rc = run_pipeline(c, nb, c->st_in, off.data(), false, c->st_ordered, multi_out ? c->st_multi : nullptr,
+                          single_out ? c->st_single : nullptr, any_gm ? c->st_gm : nullptr);
+        if (rc != BEV_OK) return rc;
+        for (int f = 0; f < nb; ++f) {
+            if (ordered_out[f0 + f])
+                HIPCK(c, hipMemcpyAsync(ordered_out[f0 + f], c->st_ordered + (size_t)f * S, S * sizeof(bev_point_t),
+                                        hipMemcpyDeviceToHost, c->stream));
+            if (multi_out && multi_out[f0 + f])
+                HIPCK(c, hipMemcpyAsync(multi_out[f0 + f], c->st_multi + (size_t)f * c->multi_bytes, c->multi_bytes,
+                                        hipMemcpyDeviceToHost, c->stream));
+            if (single_out && single_out[f0 + f])
+                HIPCK(c, hipMemcpyAsync(single_out[f0 + f], c->st_single + (size_t)f * c->single_bytes,
+                                        c->single_bytes, hipMemcpyDeviceToHost, c->stream));
+            if (ground_mat_out && ground_mat_out[f0 + f])
+                HIPCK(c, hipMemcpyAsync(ground_mat_out[f0 + f], c->st_gm + (size_t)f * S, S, hipMemcpyDeviceToHost,
+                                        c->stream));
+        }
+        /* staging is reused by the next sub-batch */
+        HIPCK(c, hipStreamSynchronize(c->stream));
+    }
+    return BEV_OK;
+}
+
+int bev_order_cloud(bev_ctx_t *c, const bev_point_t *pts, uint32_t n_pts, bev_point_t *ordered_out)
+{
+    if (!c || !ordered_out || (n_pts && !pts)) return BEV_ERR_INVALID_ARG;
+    if (n_pts > c->max_points) return BEV_ERR_TOO_LARGE;
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c);
+    if (rc != BEV_OK) return rc;
+    const Geometry &g = c->geo;
+    const size_t S = (size_t)g.S;
+    int ds = 0;
+    rc = acquire_desc(c, 1, &ds);
+    if (rc != BEV_OK) return rc;
+    c->h_desc[ds][0] = FrameDesc{0, n_pts, 0};
+    HIPCK(c, hipMemcpyAsync(c->d_desc[ds], c->h_desc[ds], sizeof(FrameDesc), hipMemcpyHostToDevice, c->stream));
+    if (n_pts)
+        HIPCK(c, hipMemcpyAsync(c->st_in, pts, (size_t)n_pts * sizeof(bev_point_t), hipMemcpyHostToDevice, c->stream));
+    BatchPtrs b{};
+    b.pts = c->st_in;
+    b.frames = c->d_desc[ds];
+    b.winner = c->winner;
+    b.ordered = c->st_ordered;
+    HIPCK(c, hipMemsetAsync(c->winner, 0, S * sizeof(uint32_t), c->stream));
+    {
+        ProfScope ps(c, K_ORDER_SCAN, 1);
+        launch_order_scan(g, b, 1, n_pts, c->stream);
+    }
+    {
+        ProfScope ps(c, K_GATHER_ONLY, 1);
+        launch_gather_only(g, b, 1, c->stream);
+    }
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(ordered_out, c->st_ordered, S * sizeof(bev_point_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipEventRecord(c->desc_done[ds], c->stream));
+    c->desc_used[ds] = true;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BEV_OK;
+}
+
+int bev_mark_ground(bev_ctx_t *c, bev_point_t *ordered, int8_t *ground_mat_out)
+{
+    if (!c || !ordered) return BEV_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c);
+    if (rc != BEV_OK) return rc;
+    const size_t S = (size_t)c->geo.S;
+    HIPCK(c, hipMemcpyAsync(c->st_in, ordered, S * sizeof(bev_point_t), hipMemcpyHostToDevice, c->stream));
+    rc = run_pipeline(c, 1, c->st_in, nullptr, true, c->st_ordered, nullptr, nullptr,
+                      ground_mat_out ? c->st_gm : nullptr);
+    if (rc != BEV_OK) return rc;
+    HIPCK(c, hipMemcpyAsync(ordered, c->st_ordered, S * sizeof(bev_point_t), hipMemcpyDeviceToHost, c->stream));
+    if (ground_mat_out) HIPCK(c, hipMemcpyAsync(ground_mat_out, c->st_gm, S, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BEV_OK;
+}
+
+static int raster_cloud(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, uint8_t *multi_out, uint8_t *single_out)
+{
+    if (!c || (n && !cloud)) return BEV_ERR_INVALID_ARG;
+    if ((size_t)n > std::max(c->max_points, (size_t)c->geo.S)) return BEV_ERR_TOO_LARGE;
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c);
+    if (rc != BEV_OK) return rc;
+    if (n) HIPCK(c, hipMemcpyAsync(c->st_in, cloud, (size_t)n * sizeof(bev_point_t), hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, K_CLOUD_CODES, 1);
+        launch_cloud_codes(c->geo, c->st_in, n, c->codes, c->stream);
+    }
+    {
+        ProfScope ps(c, K_BEV_RASTER, 1);
+        launch_bev_raster(c->geo, c->codes, 0, n, c->st_multi, c->st_single, multi_out != nullptr,
+                          single_out != nullptr, 1, c->stream);
+    }
+    HIPCK(c, hipGetLastError());
+    if (multi_out) HIPCK(c, hipMemcpyAsync(multi_out, c->st_multi, c->multi_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (single_out)
+        HIPCK(c, hipMemcpyAsync(single_out, c->st_single, c->single_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BEV_OK;
+}
+
+int bev_multi_bev(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, uint8_t *multi_out)
+{
+    if (!multi_out) return BEV_ERR_INVALID_ARG;
+    return raster_cloud(c, cloud, n, multi_out, nullptr);
+}
+int bev_single_bev(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, uint8_t *single_out)
+{
+    if (!single_out) return BEV_ERR_INVALID_ARG;
+    return raster_cloud(c, cloud, n, nullptr, single_out);
+}
+
+int bev_profile_enable(bev_ctx_t *c, int on)
+{
+    if (!c) return BEV_ERR_INVALID_ARG;
+    if (!on && c->prof_on) {
+        int rc = prof_flush(c);
+        if (rc != BEV_OK) return rc;
+    }
+    c->prof_on = on != 0;
+    return BEV_OK;
+}
+int bev_profile_reset(bev_ctx_t *c)
+{
+    if (!c) return BEV_ERR_INVALID_ARG;
+    int rc = prof_flush(c);
+    if (rc != BEV_OK) return rc;
+    for (int k = 0; k < K_COUNT; ++k) {
+        c->prof_ms[k] = 0;
+        c->prof_launches[k] = 0;
+        c->prof_frames[k] = 0;
+    }
+    return BEV_OK;
+}
+int bev_profile_get(bev_ctx_t *c, bev_kernel_stat_t *out, int cap)
+{
+    if (!c || (!out && cap > 0)) return BEV_ERR_INVALID_ARG;
+    int rc = prof_flush(c);
+    if (rc != BEV_OK) return rc;
+    int n = 0;
+    for (int k = 0; k < K_COUNT; ++k) {
+        if (c->prof_launches[k] == 0) continue;
+        if (n < cap) {
+            out[n].name = kernel_name(k);
+            out[n].launches = c->prof_launches[k];
+            out[n].total_ms = c->prof_ms[k];
+            out[n].frames = c->prof_frames[k];
+        }
+        ++n;
+    }
+    return n;
+}
+
+int bev_debug_get_cell_avg(bev_ctx_t *c, int first_frame, int n_frames, float *out)
+{
+    if (!c || !out || first_frame < 0 || n_frames < 0 || first_frame + n_frames > c->last_sub_frames)
+        return BEV_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpy(out, c->avg + (size_t)first_frame * bevx::kGridCells,
+                       (size_t)n_frames * bevx::kGridCells * sizeof(float), hipMemcpyDeviceToHost));
+    return BEV_OK;
+}
+
+int bev_debug_angle_predicate(bev_ctx_t *c, const float *dx, const float *dy, const float *dz, uint8_t *out, size_t n)
+{
+    if (!c || !dx || !dy || !dz || !out) return BEV_ERR_INVALID_ARG;
+    if (n == 0) return BEV_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    float *d = nullptr;
+    uint8_t *o = nullptr;
+    HIPCK(c, hipMalloc((void **)&d, 3 * n * sizeof(float)));
+    hipError_t e = hipMalloc((void **)&o, n);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return hip_fail(c, e, "hipMalloc", __LINE__);
+    }
+    int rc = BEV_OK;
+    auto ck = [&](hipError_t err, int line) {
+        if (err != hipSuccess && rc == BEV_OK) rc = hip_fail(c, err, "bev_debug_angle_predicate", line);
+    };
+    ck(hipMemcpy(d, dx, n * sizeof(float), hipMemcpyHostToDevice), __LINE__);
+    ck(hipMemcpy(d + n, dy, n * sizeof(float), hipMemcpyHostToDevice), __LINE__);
+    ck(hipMemcpy(d + 2 * n, dz, n * sizeof(float), hipMemcpyHostToDevice), __LINE__);
+    if (rc == BEV_OK) {
+        launch_angle_debug(d, d + n, d + 2 * n, o, n, c->stream);
+        ck(hipGetLastError(), __LINE__);
+        ck(hipStreamSynchronize(c->stream), __LINE__);
+        ck(hipMemcpy(out, o, n, hipMemcpyDeviceToHost), __LINE__);
+    }
+    (void)hipFree(d);
+    (void)hipFree(o);
+    return rc;
+}
+
+} /* extern "C" */

@@ -1,0 +1,216 @@
+/*
+ * bev_exact.h — the per-point / per-slot arithmetic of the hot path, written
+ * once for the HIP kernels (and compiled for the host ONLY by tests/, which
+ * check these closed forms against the sequential oracle without a GPU).
+ *
+ * Everything here must give bit-identical results on gfx950 and x86-64:
+ *   - only IEEE-754 correctly rounded operations are used (+ - * / sqrt,
+ *     conversions, floor/round); no libm transcendental is evaluated;
+ *   - floating-point contraction is OFF (pragma below AND -ffp-contract=off),
+ *     because the reference is built for baseline x86-64 without FMA
+ *     (CMakeLists.txt:5-10);
+ *   - float->int conversions reproduce x86-64 cvttss2si / cvttsd2si, which is
+ *     what the reference's unchecked casts compile to (NaN / out of range ->
+ *     INT_MIN).
+ * file:line citations are relative to the reference tree.
+ */
+#ifndef BEV_EXACT_H
+#define BEV_EXACT_H
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define BEVX_HD __host__ __device__ __forceinline__
+#else
+#define BEVX_HD static inline
+#endif
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+namespace bevx {
+
+constexpr int kGridRows = 75;  /* BatchMultiBevGen.cpp:25 */
+constexpr int kGridCols = 50;  /* BatchMultiBevGen.cpp:26 */
+constexpr int kGridCells = kGridRows * kGridCols;
+
+constexpr int kIntMin = (-2147483647 - 1);
+
+/* x86-64 cvttsd2si / cvttss2si */
+BEVX_HD int cvtt_f64(double v)
+{
+    if (!(v > -2147483649.0 && v < 2147483648.0)) return kIntMin;
+    return (int)v;
+}
+BEVX_HD int cvtt_f32(float v)
+{
+    if (!(v >= -2147483648.0f && v < 2147483648.0f)) return kIntMin;
+    return (int)v;
+}
+
+/* ---------------------------------------------------------------------------
+ * Phase-A angle test, BatchMultiBevGen.cpp:169-179:
+ *     angle = atan2f(dz, sqrtf(dx*dx + dy*dy)) * 180.0 / M_PI   (stored to float)
+ *     ground  iff  fabsf(angle - 0.0f) <= 10.0f
+ * Restated without the transcendental.  With glibc 2.35's atan2f
+ *   (a) fl32(fl64(a) * 180.0 / M_PI) <= 10.0f  <=>  a <= 0x1.657184p-3f
+ *       (checked for every non-negative float a),
+ *   (b) atanf is monotone non-decreasing over all non-negative floats and
+ *       atanf(q) <= 0x1.657184p-3f  <=>  q <= kTanThreshold (exhaustive),
+ *   (c) for s >= +0, atan2f(+-dz, s) = +-atanf(fl32(|dz| / s)) in every case that
+ *       reaches the comparison (2e9 random + special-value cases, 0 mismatches;
+ *       tests/test_angle_predicate.py re-derives (a)-(c) against the libm of
+ *       the machine it runs on).
+ * So: ground iff (dz == 0 and s == 0) or fl32(|dz| / s) <= kTanThreshold, with
+ * NaN comparing false exactly like the reference's "<=".
+ * ------------------------------------------------------------------------- */
+constexpr uint32_t kTanThresholdBits = 0x3e348f0fu; /* 0.176326975f */
+
+BEVX_HD float bits_to_float(uint32_t u)
+{
+    union { uint32_t u; float f; } c;
+    c.u = u;
+    return c.f;
+}
+
+BEVX_HD bool angle_is_ground(float dx, float dy, float dz)
+{
+    float xx = dx * dx;
+    float yy = dy * dy;
+    float s = sqrtf(xx + yy);
+    float a = fabsf(dz);
+    if (a == 0.0f && s == 0.0f) return true; /* atan2f(+-0, +0) = +-0 */
+    float q = a / s;
+    return q <= bits_to_float(kTanThresholdBits);
+}
+
+/* getBelongingGrid, BatchMultiBevGen.h:73-99 -> cell = row * 50 + col */
+BEVX_HD int ground_cell(float x, float y)
+{
+    float nx = (float)((double)x + 75.0); /* :78 */
+    float ny = (float)((double)y + 50.0); /* :79 */
+    int r = cvtt_f64(floor((double)nx * 0.5)); /* :81, /2.0 is exact */
+    int c = cvtt_f64(floor((double)ny * 0.5)); /* :82 */
+    if (r >= kGridRows) r = kGridRows - 1; /* :84-89 */
+    if (r < 0) r = 0;
+    if (c >= kGridCols) c = kGridCols - 1; /* :91-96 */
+    if (c < 0) c = 0;
+    return r * kGridCols + c;
+}
+
+/* Phase C test for one slot, BatchMultiBevGen.cpp:227-241: any in-range
+ * 4-neighbour cell (own cell excluded) with (double)(float)(z - avg) > 0.30. */
+template <class AvgPtr>
+BEVX_HD bool above_neighbour_ground(float z, int cell, AvgPtr avg)
+{
+    const int sr = cell / kGridCols, sc = cell % kGridCols;
+    bool hit = false;
+    if (sr - 1 >= 0)        hit = hit || ((double)(z - avg[cell - kGridCols]) > 0.30);
+    if (sc + 1 < kGridCols) hit = hit || ((double)(z - avg[cell + 1]) > 0.30);
+    if (sc - 1 >= 0)        hit = hit || ((double)(z - avg[cell - 1]) > 0.30);
+    if (sr + 1 < kGridRows) hit = hit || ((double)(z - avg[cell + kGridCols]) > 0.30);
+    return hit;
+}
+
+/* ---------------------------------------------------------------------------
+ * BEV bins.  BatchMultiBevGen.cpp:279-281 and :343-346.
+ * A point's contribution to both rasters is packed into one 32-bit code:
+ *   bits  0.. 8  x bin   (row index of the cv::Mat)       [0, M)
+ *   bits  9..17  y bin   (col index)                      [0, M)
+ *   bits 18..25  single-BEV height, already clamped       [0, 255]
+ *   bits 26..30  layer, 31 = "not in any layer"           [0, n_layers)
+ * kSkip marks a point that contributes to neither raster.
+ * ------------------------------------------------------------------------- */
+constexpr uint32_t kSkip = 0xffffffffu;
+constexpr uint32_t kNoLayer = 31u;
+
+struct RasterParams {
+    float max_range_f;   /* (float)MAX_RANGE, :266 */
+    float interval;      /* :264 */
+    float height_res;    /* SensorParams::HEIGHT_RES */
+    float lidar_to_ground; /* :269 */
+    int mat_size;        /* :267 */
+    int n_layers;        /* :268 */
+};
+
+BEVX_HD int bev_bin(float p, float max_range_f, float interval)
+{
+    float shifted = (p + max_range_f) / interval;          /* float */
+    return cvtt_f64(round((double)shifted + 0.5));        /* double, half away from zero */
+}
+
+BEVX_HD uint32_t bev_code(float px, float py, float pz, int label, const RasterParams &rp)
+{
+    if (label == 0) return kSkip;                                      /* :285, :349 */
+    int x = bev_bin(px, rp.max_range_f, rp.interval);                  /* :279, :343 */
+    int y = bev_bin(py, rp.max_range_f, rp.interval);                  /* :280, :344 */
+    if (x < 0 || x >= rp.mat_size || y < 0 || y >= rp.mat_size) return kSkip;
+    int layer = cvtt_f32(roundf(pz / rp.height_res + rp.lidar_to_ground)); /* :281 */
+    int h = cvtt_f64((double)(pz + rp.lidar_to_ground) * 4.0);         /* :345 */
+    h = h < 0 ? 0 : (h > 255 ? 255 : h);                               /* :346 */
+    uint32_t l = (layer >= 0 && layer < rp.n_layers) ? (uint32_t)layer : kNoLayer;
+    return (uint32_t)x | ((uint32_t)y << 9) | ((uint32_t)h << 18) | (l << 26);
+}
+BEVX_HD int code_x(uint32_t c) { return (int)(c & 511u); }
+BEVX_HD int code_y(uint32_t c) { return (int)((c >> 9) & 511u); }
+BEVX_HD int code_h(uint32_t c) { return (int)((c >> 18) & 255u); }
+BEVX_HD uint32_t code_layer(uint32_t c) { return (c >> 26) & 31u; }
+
+/* ---------------------------------------------------------------------------
+ * Phase A per slot.  `fetch(flat_index)` returns (x, y, z, intensity) of the
+ * ordered cloud at a flat slot index.
+ *
+ * slot_status(): BatchMultiBevGen.cpp:142-182 for one (row, col):
+ *   upper candidates tried in the reference's order, each step only if the
+ *   CURRENT upper has intensity == -1:
+ *     (row-1, col) -> (row-1, (col+2) % H) -> flat (row-1)*H + col - 2
+ *     -> (row-2, col) if row >= 2.
+ *   "(col - 2) % H" keeps the sign in C++, so for col < 2 the third candidate
+ *   is the flat index (row-1)*H + col - 2 (tail of row-2), not a wrap.
+ * ------------------------------------------------------------------------- */
+enum : int { kInvalid = -1, kSteep = 0, kGround = 1 };
+
+struct XYZI { float x, y, z, i; };
+
+template <class Fetch>
+BEVX_HD int slot_status(int row, int col, int H, const XYZI &lower, Fetch fetch)
+{
+    const long long base = (long long)(row - 1) * H;
+    XYZI up = fetch(base + col);                               /* :143 */
+    if (up.i == -1.0f) up = fetch(base + (col + 2) % H);        /* :146-149 */
+    if (up.i == -1.0f) up = fetch(base + (col - 2));            /* :151-154 */
+    if (up.i == -1.0f && row >= 2) up = fetch((long long)(row - 2) * H + col); /* :157-160 */
+    if (lower.i == -1.0f || up.i == -1.0f) return kInvalid;     /* :162-167 */
+    float dx = up.x - lower.x, dy = up.y - lower.y, dz = up.z - lower.z; /* :169-171 */
+    return angle_is_ground(dx, dy, dz) ? kGround : kSteep;      /* :173-182 */
+}
+
+/* Value of ground_mat(row, col) when phase A ends (before phase C), in closed
+ * form.  The reference walks rows N-1 .. lo (lo = N - G) per column; a GROUND
+ * row r writes gm[r] = gm[r-1] = 1, an INVALID row writes gm[r] = -1 (after
+ * row r+1 may have written 1 there), a STEEP row writes nothing:
+ *   lo <= r <= N-1 : -1 if s[r] INVALID;  1 if s[r] GROUND;
+ *                    else 1 if (r+1 <= N-1 and s[r+1] GROUND) else 0
+ *   r == lo-1      : 1 if s[lo] GROUND else 0
+ *   r <  lo-1      : 0                                                      */
+template <class Fetch>
+BEVX_HD int phase_a_ground(int row, int col, int N, int H, int G, const XYZI &self, Fetch fetch)
+{
+    const int lo = N - G;
+    if (row < lo - 1) return 0;
+    if (row >= lo) {
+        int s = slot_status(row, col, H, self, fetch);
+        if (s == kInvalid) return -1;
+        if (s == kGround) return 1;
+    }
+    if (row + 1 <= N - 1) {
+        XYZI below = fetch((long long)(row + 1) * H + col);
+        return slot_status(row + 1, col, H, below, fetch) == kGround ? 1 : 0;
+    }
+    return 0;
+}
+
+} /* namespace bevx */
+#endif

@@ -1,0 +1,97 @@
+/*
+ * bev_internal.h — shared between the HIP kernels (bev_kernels.hip) and the
+ * C-ABI / context code (bev_capi.hip).  Not installed; the public boundary is
+ * include/bev_mi355x.h.
+ */
+#ifndef BEV_INTERNAL_H
+#define BEV_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bev_mi355x.h"
+#include "bev_exact.h"
+
+namespace bevk {
+
+constexpr int kTile = 256;        /* slots per workgroup of the gather kernel */
+constexpr int kSumWaves = 8;      /* waves of the per-frame cell-sum workgroup */
+constexpr int kSumThreads = kSumWaves * 64;
+constexpr int kRasterThreads = 1024;
+constexpr int kRasterSplit = 4;   /* x-bands per frame in the raster kernel */
+
+/* per-frame launch metadata, copied H2D once per sub-batch */
+struct FrameDesc {
+    uint64_t in_offset; /* element offset of the frame's points in d_pts */
+    uint32_t n_pts;
+    uint32_t _pad;
+};
+
+/* A slot that phase A marked ground_mat == 1: the only slots whose label
+ * depends on the per-cell averages (BatchMultiBevGen.cpp:244-246). 16 bytes. */
+struct Candidate {
+    uint32_t slot;   /* flat slot index inside the frame */
+    float z;
+    uint32_t code;   /* BEV code the point gets if phase C un-grounds it */
+    uint16_t cell;   /* getBelongingGrid cell, row * 50 + col */
+    int16_t label;   /* label the point came in with */
+};
+static_assert(sizeof(Candidate) == 16, "Candidate must be 16 bytes");
+static_assert(sizeof(bev_point_t) == 32, "bev_point_t must be 32 bytes");
+
+struct Geometry {
+    int N, H, G;       /* N_SCAN, Horizon_SCAN, GROUND_UPPER_SCAN */
+    int S;             /* N * H */
+    int tiles;         /* ceil(S / kTile) */
+    bevx::RasterParams rp;
+};
+
+/* device-side views of one sub-batch */
+struct BatchPtrs {
+    const bev_point_t *pts;      /* packed input points (or ordered cloud in identity mode) */
+    const FrameDesc *frames;
+    uint32_t *winner;            /* [nf][S]  index+1 of the last input point per slot */
+    bev_point_t *ordered;        /* [nf][S] */
+    uint32_t *codes;             /* [nf][S] */
+    Candidate *cand;             /* [nf][tiles][kTile] */
+    uint32_t *ncand;             /* [nf][tiles] */
+    float *zsorted;              /* [nf][S] */
+    float *avg;                  /* [nf][3750] */
+    int8_t *gm;                  /* [nf][S] or nullptr: phase-A ground_mat */
+    uint8_t *multi;              /* [nf][L*M*M] */
+    uint8_t *single;             /* [nf][M*M] */
+};
+
+enum KernelId {
+    K_ORDER_SCAN = 0,
+    K_GATHER_GROUND,
+    K_CELL_SUMS,
+    K_GROUND_RESOLVE,
+    K_BEV_RASTER,
+    K_GATHER_ONLY,
+    K_GROUND_MAT,
+    K_CLOUD_CODES,
+    K_ANGLE_DEBUG,
+    K_COUNT
+};
+const char *kernel_name(int id);
+
+/* launchers (bev_kernels.hip) — all asynchronous on `st` */
+void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, hipStream_t st);
+void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st);
+void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
+void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
+void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
+void launch_bev_raster(const Geometry &g, const uint32_t *codes, size_t code_stride, uint32_t n_codes,
+                       uint8_t *multi, uint8_t *single, bool want_multi, bool want_single,
+                       int nf, hipStream_t st);
+void launch_ground_mat(const Geometry &g, const BatchPtrs &b, int8_t *out, int nf, hipStream_t st);
+void launch_cloud_codes(const Geometry &g, const bev_point_t *cloud, uint32_t n, uint32_t *codes, hipStream_t st);
+void launch_angle_debug(const float *dx, const float *dy, const float *dz, uint8_t *out, size_t n, hipStream_t st);
+/* opt in to > 64 KiB of dynamic LDS for the two kernels that need it */
+hipError_t configure_kernels(const Geometry &g);
+size_t cell_sums_lds_bytes();
+size_t raster_lds_bytes(const Geometry &g);
+
+} /* namespace bevk */
+#endif

@@ -1,0 +1,52 @@
+"""ctypes loader for tests/hostcheck/libhostcheck.so (host build of csrc/bev_exact.h)."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from bev_amd import POINT_DTYPE, BevParams
+
+SO = Path(__file__).resolve().parent / "hostcheck" / "libhostcheck.so"
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        l = C.CDLL(str(SO))
+        vp = C.c_void_p
+        l.hc_angle.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        l.hc_angle.restype = None
+        l.hc_tan_threshold_bits.restype = C.c_uint32
+        l.hc_ground_cell.argtypes = [C.c_float, C.c_float]
+        l.hc_bev_code.argtypes = [C.POINTER(BevParams), C.c_float, C.c_float, C.c_float, C.c_int]
+        l.hc_bev_code.restype = C.c_uint32
+        l.hc_process_frame.argtypes = [C.POINTER(BevParams), vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
+        l.hc_process_frame.restype = None
+        _lib = l
+    return _lib
+
+
+def angle(dx, dy, dz):
+    dx = np.ascontiguousarray(dx, np.float32)
+    dy = np.ascontiguousarray(dy, np.float32)
+    dz = np.ascontiguousarray(dz, np.float32)
+    out = np.empty(len(dx), np.uint8)
+    lib().hc_angle(dx.ctypes.data, dy.ctypes.data, dz.ctypes.data, len(dx), out.ctypes.data)
+    return out
+
+
+def process_frame(p: BevParams, pts):
+    pts = np.ascontiguousarray(pts, dtype=POINT_DTYPE)
+    S, M, L = p.slots, p.mat_size, p.n_layers
+    ordered = np.empty(S, POINT_DTYPE)
+    gm_a = np.empty((p.n_scan, p.horizon_scan), np.int8)
+    gm = np.empty((p.n_scan, p.horizon_scan), np.int8)
+    avg = np.empty(75 * 50, np.float32)
+    multi = np.empty((L, M, M), np.uint8)
+    single = np.empty((M, M), np.uint8)
+    lib().hc_process_frame(C.byref(p), pts.ctypes.data, len(pts), ordered.ctypes.data, gm_a.ctypes.data,
+                           gm.ctypes.data, avg.ctypes.data, multi.ctypes.data, single.ctypes.data)
+    return ordered, gm, avg, multi, single
