@@ -82,6 +82,16 @@ def load_lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64; two
+    # HIP runtimes in one process cannot both open the GPU.  Importing torch FIRST
+    # makes the dynamic linker resolve our NEEDED libamdhip64.so.7 to the copy torch
+    # already loaded (same SONAME), so the process has exactly one runtime.
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not LIB_PATH.exists():
         raise BevError(
             f"{LIB_PATH} is missing: build it with __graft_entry__.build() or "

@@ -1,0 +1,177 @@
+"""GPU: the HIP path, called through the C ABI, against the CPU oracle.
+Bit-exact everywhere: every output is integer / byte / index data, and the one
+float channel (per-cell average heights) is compared bit for bit too."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import bev_amd
+import oracle_lib as orc
+from bev_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+SENSORS = ["HDL_32E", "HDL_64E", "OS1_64"]
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    made = {}
+
+    def get(sensor, max_batch=4, max_points=200000):
+        key = (sensor, max_batch, max_points)
+        if key not in made:
+            p = bev_amd.params_for_sensor(sensor)
+            made[key] = (p, bev_amd.BevContext(p, device=0, max_batch=max_batch, max_points=max_points))
+        return made[key]
+
+    yield get
+    for _, c in made.values():
+        c.close()
+
+
+def _oracle(p, pts):
+    sp = orc.sensor_from_params(p)
+    ordered, gm, multi, single = orc.process_frame(sp, pts)
+    _, _, avg = orc.mark_ground(sp, orc.order_cloud(sp, pts))
+    return ordered, gm, multi, single, avg
+
+
+def _check_batch(p, ctx, frames):
+    ordered, multi, single, gm = ctx.process_batch(frames, want_ground_mat=True)
+    navg = min(len(frames), ctx.max_batch)
+    # averages of the LAST sub-batch only
+    first = ((len(frames) - 1) // ctx.max_batch) * ctx.max_batch if frames else 0
+    avg = ctx.cell_avg(0, len(frames) - first) if frames else None
+    for i, pts in enumerate(frames):
+        o_ord, o_gm, o_multi, o_single, o_avg = _oracle(p, pts)
+        if i >= first:
+            assert avg[i - first].tobytes() == o_avg.tobytes(), f"frame {i}: per-cell averages differ"
+        assert np.array_equal(gm[i], o_gm), f"frame {i}: ground_mat differs at {np.argwhere(gm[i] != o_gm)[:4]}"
+        assert ordered[i].tobytes() == o_ord.tobytes(), f"frame {i}: ordered cloud / labels differ"
+        assert np.array_equal(multi[i], o_multi), f"frame {i}: multi BEV differs"
+        assert np.array_equal(single[i], o_single), f"frame {i}: single BEV differs"
+
+
+@pytest.mark.parametrize("sensor", SENSORS)
+def test_sweep_frames(ctxs, sensor):
+    p, ctx = ctxs(sensor)
+    _check_batch(p, ctx, [synth.sweep(p, f) for f in range(3)])
+
+
+@pytest.mark.parametrize("sensor", SENSORS)
+def test_firing_order_frames(ctxs, sensor):
+    p, ctx = ctxs(sensor)
+    _check_batch(p, ctx, [synth.firing_order(p, f) for f in range(2)])
+
+
+@pytest.mark.parametrize("sensor", SENSORS)
+@pytest.mark.parametrize("nonfinite", [False, True])
+def test_adversarial_frames(ctxs, sensor, nonfinite):
+    p, ctx = ctxs(sensor)
+    _check_batch(p, ctx, [synth.adversarial(p, 50000 + 7777 * s, s, nonfinite) for s in range(3)])
+
+
+def test_ragged_batch_with_empty_and_tiny_frames(ctxs):
+    p, ctx = ctxs("HDL_32E")
+    full = synth.sweep(p, 0)
+    frames = [np.empty(0, bev_amd.POINT_DTYPE), full[:1], full, full[:1000], np.empty(0, bev_amd.POINT_DTYPE),
+              synth.sweep(p, 1, keep=0.3, n_dup=20000)]
+    _check_batch(p, ctx, frames)  # 6 frames through a max_batch=4 context: two sub-batches
+
+
+def test_degenerate_clouds(ctxs):
+    p, ctx = ctxs("HDL_32E")
+    base = synth.sweep(p, 5)
+    allsame = base[:5000].copy()
+    allsame["row"] = 31
+    allsame["col"] = 0
+    noret = base.copy()
+    noret["intensity"] = -1.0
+    lab0 = base.copy()
+    lab0["label"] = 0
+    oob = base[:3000].copy()
+    oob["row"] = 40
+    _check_batch(p, ctx, [allsame, noret, lab0, oob])
+
+
+def test_oxford_concat(ctxs):
+    p = bev_amd.params_for_sensor("HDL_32E")
+    pts = synth.concat(p, 0, n_sweeps=20)  # ~660k points into 33,792 slots
+    p, ctx = ctxs("HDL_32E", 2, len(pts))
+    _check_batch(p, ctx, [pts])
+
+
+# ---- per-function entry points (what the reference-named C++ functions call) ----
+@pytest.mark.parametrize("sensor", SENSORS)
+def test_per_function_entry_points(ctxs, sensor):
+    p, ctx = ctxs(sensor)
+    sp = orc.sensor_from_params(p)
+    pts = synth.sweep(p, 11)
+    ordered = ctx.order_cloud(pts)                      # getOrderedCloud
+    o_ordered = orc.order_cloud(sp, pts)
+    assert ordered.tobytes() == o_ordered.tobytes()
+    marked, gm = ctx.mark_ground(ordered)               # markGroundPoints
+    o_marked, o_gm, _ = orc.mark_ground(sp, o_ordered)
+    assert np.array_equal(gm, o_gm)
+    assert marked.tobytes() == o_marked.tobytes()
+    assert np.array_equal(ctx.multi_bev(marked), orc.multi_bev(sp, o_marked))    # computeAndSaveMultiBev raster
+    assert np.array_equal(ctx.single_bev(marked), orc.single_bev(o_marked))      # computeAndSaveSingleBev raster
+    # rasters of an UNORDERED cloud (any point list is legal input)
+    adv = synth.adversarial(p, 30000, 9, True)
+    assert np.array_equal(ctx.multi_bev(adv), orc.multi_bev(sp, adv))
+    assert np.array_equal(ctx.single_bev(adv), orc.single_bev(adv))
+    # markGroundPoints is idempotent on its own output
+    again, gm2 = ctx.mark_ground(marked)
+    assert again.tobytes() == marked.tobytes() and np.array_equal(gm2, gm)
+
+
+def test_angle_predicate_device_vs_libm(ctxs):
+    """The transcendental-free angle test on the device == the reference's atan2f
+    expression evaluated by the host libm, including +-1 ulp around the threshold."""
+    p, ctx = ctxs("HDL_32E")
+    rng = np.random.default_rng(1234)
+    n = 2_000_000
+    s = np.ldexp(1.0 + rng.random(n), rng.integers(-20, 20, n)).astype(np.float32)
+    t = (np.float64(0.17632698070846498) * s.astype(np.float64)).astype(np.float32)
+    dz = (t.view(np.uint32) + rng.integers(-8, 9, n).astype(np.int64)).astype(np.uint32).view(np.float32)
+    dz = np.where(rng.random(n) < 0.5, -dz, dz).astype(np.float32)
+    ang = rng.random(n) * 2 * np.pi
+    dx = (s.astype(np.float64) * np.cos(ang)).astype(np.float32)
+    dy = (s.astype(np.float64) * np.sin(ang)).astype(np.float32)
+    special = np.array([0.0, -0.0, 1.0, np.inf, -np.inf, np.nan, 1e-45, 3e38, 1e-38, -1.0], np.float32)
+    g = np.array(np.meshgrid(special, special, special)).reshape(3, -1)
+    dx = np.concatenate([dx, g[0]]); dy = np.concatenate([dy, g[1]]); dz = np.concatenate([dz, g[2]])
+    dev = ctx.angle_predicate(dx, dy, dz)
+    lib = orc.lib()
+    ref = np.fromiter((lib.oracle_angle_is_ground(float(a), float(b), float(c)) for a, b, c in
+                       zip(dx[:200000], dy[:200000], dz[:200000])), np.uint8, 200000)
+    assert np.array_equal(dev[:200000], ref)
+    import hostcheck_lib as hc
+    assert np.array_equal(dev, hc.angle(dx, dy, dz)), "device and host evaluation of bev_exact.h differ"
+    refs = np.fromiter((lib.oracle_angle_is_ground(float(a), float(b), float(c)) for a, b, c in
+                        zip(g[0], g[1], g[2])), np.uint8, g.shape[1])
+    assert np.array_equal(dev[n:], refs)
+
+
+def test_device_resident_matches_host_entry(ctxs):
+    torch = pytest.importorskip("torch")
+    p, ctx = ctxs("HDL_64E", 4)
+    frames = [synth.sweep(p, 100 + f) for f in range(6)]
+    ordered, multi, single, _ = ctx.process_batch(frames)
+    offs = np.zeros(len(frames) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(f) for f in frames])
+    packed = np.concatenate(frames)
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(packed.view(np.uint8).reshape(-1)).to(dev)
+    S, M, L = p.slots, p.mat_size, p.n_layers
+    d_ord = torch.empty(len(frames) * S * 32, dtype=torch.uint8, device=dev)
+    d_multi = torch.empty(len(frames) * L * M * M, dtype=torch.uint8, device=dev)
+    d_single = torch.empty(len(frames) * M * M, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.process_device(len(frames), d_in.data_ptr(), offs, d_ord.data_ptr(), d_multi.data_ptr(), d_single.data_ptr())
+    ctx.synchronize()
+    assert d_ord.cpu().numpy().tobytes() == ordered.tobytes()
+    assert d_multi.cpu().numpy().tobytes() == multi.tobytes()
+    assert d_single.cpu().numpy().tobytes() == single.tobytes()
