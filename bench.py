@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py — BEV frames/s of the batch_multi_bev_gen hot path on MI355X.
+
+Workload (BASELINE.json configs[1]; configs[3] is the same per GPU): 1000
+synthetic KITTI-like HDL_64E clouds (~135.6k input points each into 133,312
+slots) per GPU, resident in HBM; one "step" = one pass of the whole hot path
+(order -> ground segmentation -> multi + single BEV) over those 1000 frames,
+outputs left in HBM.  N > 1: one process per GPU (torch.distributed, backend
+nccl = RCCL), frames sharded contiguously, the only collective on the path is
+the broadcast of the frame-range table; weak scaling (1000 frames per GPU).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO / "point-cloud-preprocessing-tools_amd"))
+sys.path.insert(0, str(REPO / "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy kernel reaches
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU (BASELINE config: 1000)")
+    ap.add_argument("--sensor", default="HDL_64E")
+    ap.add_argument("--sub-batch", type=int, default=int(os.environ.get("BEV_SUB_BATCH", "256")))
+    ap.add_argument("--cpu-sample", type=int, default=400, help="frames timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch  # before the HIP library: one HIP runtime per process (bev_amd.load_lib)
+    import torch.distributed as dist
+
+    import __graft_entry__ as ge
+    import bev_amd
+    from bev_amd import shard, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to fall back to)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    lib_missing = not bev_amd.LIB_PATH.exists()
+    if lib_missing:
+        raise SystemExit(f"{bev_amd.LIB_PATH} missing")
+
+    p = bev_amd.params_for_sensor(args.sensor)
+    S, M, L = p.slots, p.mat_size, p.n_layers
+    F = args.frames
+
+    # ---- frame-range table: rank 0 decides, RCCL broadcast (the path's only collective)
+    table = shard.broadcast_ranges(F * world, rank, world, device=dev)
+    first, count = int(table[rank, 0]), int(table[rank, 1])
+    assert count == F
+
+    # ---- synthetic frames, generated on the host cores, then made resident in HBM
+    n_dup = 5000
+    cap = S + n_dup
+    t_gen = time.time()
+    host = np.empty((count, cap), dtype=bev_amd.POINT_DTYPE)
+    counts = np.zeros(count, dtype=np.int64)
+
+    def gen(i):
+        counts[i] = len(synth.sweep(p, first + i, keep=0.98, n_dup=n_dup, out=host[i]))
+
+    with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex:
+        list(ex.map(gen, range(count)))
+    offsets = np.zeros(count + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(counts)
+    total_pts = int(offsets[-1])
+    d_in = torch.empty(total_pts * 32, dtype=torch.uint8, device=dev)
+    for i in range(count):
+        a, b = int(offsets[i]) * 32, int(offsets[i + 1]) * 32
+        d_in[a:b].copy_(torch.from_numpy(host[i, : counts[i]].view(np.uint8).reshape(-1)))
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+    d_ordered = torch.empty(count * S * 32, dtype=torch.uint8, device=dev)
+    d_multi = torch.empty(count * L * M * M, dtype=torch.uint8, device=dev)
+    d_single = torch.empty(count * M * M, dtype=torch.uint8, device=dev)
+
+    ctx = bev_amd.BevContext(p, device=local_rank, max_batch=args.sub_batch, max_points=int(counts.max()))
+
+    def step():
+        ctx.process_device(count, d_in.data_ptr(), offsets, d_ordered.data_ptr(), d_multi.data_ptr(),
+                           d_single.data_ptr())
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_profile:
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    elapsed = shard.max_over_ranks(elapsed, world, device=dev)
+    total_frames = shard.sum_over_ranks(float(count * args.steps), world, device=dev)
+
+    # ---- per-kernel HIP-event durations of the timed region (rank 0's stream)
+    stats = [] if args.no_profile else ctx.profile_get()
+    mean_pts = total_pts / count
+    b_frame = bev_amd.algorithmic_bytes_per_frame(p, mean_pts)  # 32P + 32S + L*M*M + M*M
+    # which part of B_frame each kernel is the one to move (DESIGN.md "Kernels")
+    own_bytes = {
+        "k_gather_ground": 32.0 * mean_pts + 32.0 * S,
+        "k_bev_raster": float(L * M * M + M * M),
+    }
+    roofline = None
+    kernels = []
+    if stats:
+        tot_ms = sum(s["total_ms"] for s in stats)
+        for s in stats:
+            per_launch_frames = s["frames"] / s["launches"]
+            kernels.append({
+                "name": s["name"], "launches": s["launches"],
+                "avg_launch_ms": s["total_ms"] / s["launches"],
+                "share": s["total_ms"] / tot_ms,
+                "algorithmic_bytes_per_launch": own_bytes.get(s["name"], 0.0) * per_launch_frames,
+            })
+        dom = max(stats, key=lambda s: s["total_ms"])
+        per_launch_frames = dom["frames"] / dom["launches"]
+        avg_ms = dom["total_ms"] / dom["launches"]
+        dom_bytes = own_bytes.get(dom["name"], 0.0) * per_launch_frames
+        achieved = dom_bytes / (avg_ms * 1e-3) / 1e9
+        pipe_achieved = b_frame * sum(s["frames"] for s in stats if s["name"] == "k_gather_ground") / (tot_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "kernel": dom["name"], "frames_per_launch": per_launch_frames,
+            "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": avg_ms,
+            # whole hot path: B_frame * frames / (sum of ALL kernel durations)
+            "pipeline": {"bytes_per_frame": b_frame, "achieved": pipe_achieved, "frac": pipe_achieved / HBM_PEAK_GBPS,
+                         "kernel_ms_per_frame": tot_ms / max(1, sum(s["frames"] for s in stats if s["name"] == "k_gather_ground"))},
+        }
+
+    # ---- CPU baseline: the oracle (a port of the reference algorithm), 1 thread, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import oracle_lib as orc
+
+        sp = orc.sensor_from_params(p)
+        n_cpu = min(args.cpu_sample, count)
+        o_ord = np.empty(S, bev_amd.POINT_DTYPE)
+        o_multi = np.empty((L, M, M), np.uint8)
+        o_single = np.empty((M, M), np.uint8)
+        import ctypes as C
+        lib = orc.lib()
+        tc = time.perf_counter()
+        for i in range(n_cpu):
+            fr = host[i, : counts[i]]
+            lib.oracle_process_frame(C.byref(sp), fr.ctypes.data, len(fr), o_ord.ctypes.data, None,
+                                     o_multi.ctypes.data, o_single.ctypes.data)
+        tc = time.perf_counter() - tc
+        # the last oracle frame doubles as a live parity check of the benchmarked run
+        i = n_cpu - 1
+        got = d_ordered[i * S * 32:(i + 1) * S * 32].cpu().numpy().tobytes()
+        parity = (got == o_ord.tobytes()
+                  and d_multi[i * L * M * M:(i + 1) * L * M * M].cpu().numpy().tobytes() == o_multi.tobytes()
+                  and d_single[i * M * M:(i + 1) * M * M].cpu().numpy().tobytes() == o_single.tobytes())
+        cpu = {"value": n_cpu / tc, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"first {n_cpu} of the {count} frames, oracle_process_frame (order+ground+both rasters, outputs to memory), gcc -O3 no -march",
+               "ms_per_frame": tc / n_cpu * 1e3, "host_cpus": os.cpu_count(),
+               "gpu_output_matches_oracle_on_sampled_frame": bool(parity)}
+
+    if rank == 0:
+        out = {
+            "metric": "BEV frames/sec (131k-pt HDL-64E cloud)",
+            "value": total_frames / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{F} synthetic KITTI {args.sensor} clouds per GPU (mean {mean_pts:.0f} input pts, "
+                                   f"{S} slots), single+multi BEV, device-resident",
+                       "frames_per_gpu": F, "sub_batch": args.sub_batch, "sensor": args.sensor,
+                       "algorithmic_bytes_per_frame": b_frame, "parallelism": f"frames x{world}"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": kernels,
+            "gen_seconds": t_gen,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
