@@ -28,6 +28,23 @@ struct ProfSlot {
     int frames;
 };
 
+/* Sub-batches are dealt round-robin to a few "lanes": each lane has its own
+ * stream and its own sub-batch workspace, so the latency-bound per-frame
+ * cell-sum kernel of one sub-batch overlaps the bandwidth-bound kernels of the
+ * next.  Lane 0 doubles as the workspace of the single-cloud entry points. */
+constexpr int kMaxLanes = 4;
+struct Lane {
+    hipStream_t st = nullptr;
+    hipEvent_t done = nullptr;
+    uint32_t *winner = nullptr;
+    uint32_t *codes = nullptr;
+    Candidate *cand = nullptr;
+    uint32_t *ncand = nullptr;
+    float *zsorted = nullptr;
+    float *avg = nullptr;
+    int8_t *gm = nullptr; /* lazily allocated */
+};
+
 } // namespace
 
 struct bev_ctx {
@@ -40,15 +57,14 @@ struct bev_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;
 
-    /* workspace for one sub-batch */
+    /* per-lane sub-batch workspace; the aliases below are lane 0's */
+    Lane lanes[kMaxLanes];
+    int n_lanes = 1;
+    hipEvent_t fork_ev = nullptr;
     uint32_t *winner = nullptr;
     uint32_t *codes = nullptr;
     size_t codes_elems = 0;
-    Candidate *cand = nullptr;
-    uint32_t *ncand = nullptr;
-    float *zsorted = nullptr;
-    float *avg = nullptr;
-    int8_t *gm = nullptr; /* lazily allocated */
+    float *last_avg = nullptr;
 
     /* frame descriptors: ring of pinned host + device arrays */
     FrameDesc *h_desc[kDescRing] = {nullptr, nullptr, nullptr, nullptr};
@@ -109,7 +125,7 @@ int validate_params(const bev_params_t *p)
      * (the reference would read out of bounds otherwise) */
     if (p->ground_upper_scan < 1 || p->ground_upper_scan > p->n_scan - 2) return BEV_ERR_INVALID_ARG;
     if (!(p->interval > 0.0f) || p->max_range <= 0) return BEV_ERR_INVALID_ARG;
-    if ((size_t)p->n_scan * (size_t)p->horizon_scan > ((size_t)1 << 26)) return BEV_ERR_UNSUPPORTED;
+    if ((size_t)p->n_scan * (size_t)p->horizon_scan > (size_t)kMaxTiles * kTile) return BEV_ERR_UNSUPPORTED;
     const int M = mat_size_of(p);
     if (M < 16 || M > 512 || (M % 16) != 0) return BEV_ERR_UNSUPPORTED;
     if (p->n_layers < 1 || p->n_layers > 30) return BEV_ERR_UNSUPPORTED;
@@ -150,7 +166,8 @@ int prof_flush(bev_ctx *c)
 struct ProfScope {
     bev_ctx *c;
     ProfSlot *s = nullptr;
-    ProfScope(bev_ctx *ctx, int kid, int frames) : c(ctx)
+    hipStream_t st;
+    ProfScope(bev_ctx *ctx, int kid, int frames, hipStream_t stream = nullptr) : c(ctx), st(stream ? stream : ctx->stream)
     {
         if (!c->prof_on) return;
         if (c->prof_used == c->prof_pool.size()) {
@@ -159,11 +176,11 @@ struct ProfScope {
         s = &c->prof_pool[c->prof_used++];
         s->kid = kid;
         s->frames = frames;
-        (void)hipEventRecord(s->a, c->stream);
+        (void)hipEventRecord(s->a, st);
     }
     ~ProfScope()
     {
-        if (s) (void)hipEventRecord(s->b, c->stream);
+        if (s) (void)hipEventRecord(s->b, st);
     }
 };
 
@@ -189,8 +206,8 @@ int acquire_desc(bev_ctx *c, size_t n, int *slot_out)
 
 int ensure_gm(bev_ctx *c)
 {
-    if (c->gm) return BEV_OK;
-    HIPCK(c, hipMalloc((void **)&c->gm, (size_t)c->max_batch * c->geo.S));
+    for (int l = 0; l < c->n_lanes; ++l)
+        if (!c->lanes[l].gm) HIPCK(c, hipMalloc((void **)&c->lanes[l].gm, (size_t)c->max_batch * c->geo.S));
     return BEV_OK;
 }
 
@@ -228,54 +245,69 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         HIPCK(c, hipStreamWaitEvent(c->stream, c->desc_copied[ds], 0));
     }
 
-    for (int f0 = 0; f0 < n_frames; f0 += c->max_batch) {
+    /* fork: every lane starts after whatever the caller already queued on the main stream */
+    const int n_sub = (n_frames + c->max_batch - 1) / c->max_batch;
+    const int lanes_used = std::min(c->n_lanes, n_sub);
+    HIPCK(c, hipEventRecord(c->fork_ev, c->stream));
+    for (int l = 0; l < lanes_used; ++l) HIPCK(c, hipStreamWaitEvent(c->lanes[l].st, c->fork_ev, 0));
+
+    int sub = 0;
+    for (int f0 = 0; f0 < n_frames; f0 += c->max_batch, ++sub) {
         const int nb = std::min(c->max_batch, n_frames - f0);
+        Lane &ln = c->lanes[sub % lanes_used];
+        hipStream_t st = ln.st;
         BatchPtrs b{};
         b.pts = identity ? d_pts + (size_t)f0 * S : d_pts;
         b.frames = identity ? nullptr : c->d_desc[ds] + f0;
-        b.winner = c->winner;
+        b.winner = ln.winner;
         b.ordered = d_ordered + (size_t)f0 * S;
-        b.codes = c->codes;
-        b.cand = c->cand;
-        b.ncand = c->ncand;
-        b.zsorted = c->zsorted;
-        b.avg = c->avg;
-        b.gm = d_gm ? c->gm : nullptr;
+        b.codes = ln.codes;
+        b.cand = ln.cand;
+        b.ncand = ln.ncand;
+        b.zsorted = ln.zsorted;
+        b.avg = ln.avg;
+        b.gm = d_gm ? ln.gm : nullptr;
         b.multi = d_multi ? d_multi + (size_t)f0 * c->multi_bytes : nullptr;
         b.single = d_single ? d_single + (size_t)f0 * c->single_bytes : nullptr;
 
         if (!identity) {
             uint32_t max_pts = 0;
             for (int f = 0; f < nb; ++f) max_pts = std::max(max_pts, c->h_desc[ds][f0 + f].n_pts);
-            HIPCK(c, hipMemsetAsync(c->winner, 0, (size_t)nb * S * sizeof(uint32_t), c->stream));
+            HIPCK(c, hipMemsetAsync(ln.winner, 0, (size_t)nb * S * sizeof(uint32_t), st));
             {
-                ProfScope ps(c, K_ORDER_SCAN, nb);
-                launch_order_scan(g, b, nb, max_pts, c->stream);
+                ProfScope ps(c, K_ORDER_SCAN, nb, st);
+                launch_order_scan(g, b, nb, max_pts, st);
             }
         }
         {
-            ProfScope ps(c, K_GATHER_GROUND, nb);
-            launch_gather_ground(g, b, nb, identity, c->stream);
+            ProfScope ps(c, K_GATHER_GROUND, nb, st);
+            launch_gather_ground(g, b, nb, identity, st);
         }
         {
-            ProfScope ps(c, K_CELL_SUMS, nb);
-            launch_cell_sums(g, b, nb, c->stream);
+            ProfScope ps(c, K_CELL_SUMS, nb, st);
+            launch_cell_sums(g, b, nb, st);
         }
         {
-            ProfScope ps(c, K_GROUND_RESOLVE, nb);
-            launch_ground_resolve(g, b, nb, c->stream);
+            ProfScope ps(c, K_GROUND_RESOLVE, nb, st);
+            launch_ground_resolve(g, b, nb, st);
         }
         if (d_gm) {
-            ProfScope ps(c, K_GROUND_MAT, nb);
-            launch_ground_mat(g, b, d_gm + (size_t)f0 * S, nb, c->stream);
+            ProfScope ps(c, K_GROUND_MAT, nb, st);
+            launch_ground_mat(g, b, d_gm + (size_t)f0 * S, nb, st);
         }
         if (d_multi || d_single) {
-            ProfScope ps(c, K_BEV_RASTER, nb);
-            launch_bev_raster(g, c->codes, S, (uint32_t)S, b.multi, b.single, d_multi != nullptr,
-                              d_single != nullptr, nb, c->stream);
+            ProfScope ps(c, K_BEV_RASTER, nb, st);
+            launch_bev_raster(g, ln.codes, S, (uint32_t)S, b.multi, b.single, d_multi != nullptr,
+                              d_single != nullptr, nb, st);
         }
         c->last_sub_frames = nb;
+        c->last_avg = ln.avg;
         HIPCK(c, hipGetLastError());
+    }
+    /* join: the main stream continues after every lane */
+    for (int l = 0; l < lanes_used; ++l) {
+        HIPCK(c, hipEventRecord(c->lanes[l].done, c->lanes[l].st));
+        HIPCK(c, hipStreamWaitEvent(c->stream, c->lanes[l].done, 0));
     }
     if (!identity) {
         HIPCK(c, hipEventRecord(c->desc_done[ds], c->stream));
@@ -399,12 +431,32 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
     }
     const size_t S = (size_t)c->geo.S, nb = (size_t)max_batch;
     c->codes_elems = std::max(nb * S, std::max(max_points, S));
-    CK(hipMalloc((void **)&c->winner, nb * S * sizeof(uint32_t)));
-    CK(hipMalloc((void **)&c->codes, c->codes_elems * sizeof(uint32_t)));
-    CK(hipMalloc((void **)&c->cand, nb * (size_t)c->geo.tiles * kTile * sizeof(Candidate)));
-    CK(hipMalloc((void **)&c->ncand, nb * (size_t)c->geo.tiles * sizeof(uint32_t)));
-    CK(hipMalloc((void **)&c->zsorted, nb * S * sizeof(float)));
-    CK(hipMalloc((void **)&c->avg, nb * (size_t)bevx::kGridCells * sizeof(float)));
+    {
+        const char *e = getenv("BEV_LANES");
+        int nl = e ? atoi(e) : 2;
+        c->n_lanes = std::max(1, std::min(kMaxLanes, nl));
+    }
+    CK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+    /* Streams of equal priority may be multiplexed onto ONE hardware queue (observed:
+     * two such lanes never overlapped); streams of different priority get different
+     * queues, so each lane takes its own priority level where the device has enough. */
+    int prio_least = 0, prio_greatest = 0;
+    CK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    for (int l = 0; l < c->n_lanes; ++l) {
+        Lane &ln = c->lanes[l];
+        int prio = prio_greatest + l;
+        if (prio > prio_least) prio = prio_least;
+        CK(hipStreamCreateWithPriority(&ln.st, hipStreamNonBlocking, prio));
+        CK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+        CK(hipMalloc((void **)&ln.winner, nb * S * sizeof(uint32_t)));
+        CK(hipMalloc((void **)&ln.codes, c->codes_elems * sizeof(uint32_t)));
+        CK(hipMalloc((void **)&ln.cand, nb * (size_t)c->geo.tiles * kTile * sizeof(Candidate)));
+        CK(hipMalloc((void **)&ln.ncand, nb * (size_t)c->geo.tiles * sizeof(uint32_t)));
+        CK(hipMalloc((void **)&ln.zsorted, nb * S * sizeof(float)));
+        CK(hipMalloc((void **)&ln.avg, nb * (size_t)bevx::kGridCells * sizeof(float)));
+    }
+    c->winner = c->lanes[0].winner;
+    c->codes = c->lanes[0].codes;
     /* >64 KiB dynamic LDS needs an explicit opt-in per kernel */
     CK(configure_kernels(c->geo));
     c->prof_pool.resize(kEventPairs);
@@ -423,8 +475,17 @@ void bev_destroy(bev_ctx_t *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    void *dev[] = {c->winner, c->codes, c->cand, c->ncand, c->zsorted, c->avg, c->gm,
-                   c->st_in, c->st_ordered, c->st_multi, c->st_single, c->st_gm};
+    for (int l = 0; l < kMaxLanes; ++l) {
+        Lane &ln = c->lanes[l];
+        if (ln.st) (void)hipStreamSynchronize(ln.st);
+        void *ws[] = {ln.winner, ln.codes, ln.cand, ln.ncand, ln.zsorted, ln.avg, ln.gm};
+        for (void *p : ws)
+            if (p) (void)hipFree(p);
+        if (ln.done) (void)hipEventDestroy(ln.done);
+        if (ln.st) (void)hipStreamDestroy(ln.st);
+    }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    void *dev[] = {c->st_in, c->st_ordered, c->st_multi, c->st_single, c->st_gm};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     for (int k = 0; k < kDescRing; ++k) {
@@ -642,7 +703,8 @@ int bev_debug_get_cell_avg(bev_ctx_t *c, int first_frame, int n_frames, float *o
         return BEV_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->device));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    HIPCK(c, hipMemcpy(out, c->avg + (size_t)first_frame * bevx::kGridCells,
+    if (!c->last_avg) return BEV_ERR_INVALID_ARG;
+    HIPCK(c, hipMemcpy(out, c->last_avg + (size_t)first_frame * bevx::kGridCells,
                        (size_t)n_frames * bevx::kGridCells * sizeof(float), hipMemcpyDeviceToHost));
     return BEV_OK;
 }

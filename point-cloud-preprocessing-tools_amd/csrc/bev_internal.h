@@ -14,7 +14,10 @@
 
 namespace bevk {
 
-constexpr int kTile = 256;        /* slots per workgroup of the gather kernel */
+constexpr int kGatherThreads = 256;
+constexpr int kSlotsPerThread = 4;
+constexpr int kTile = kGatherThreads * kSlotsPerThread; /* slots per workgroup of the gather kernel */
+constexpr int kMaxTiles = 1024;   /* => at most 2^20 slots per frame (bev_create checks) */
 constexpr int kSumWaves = 8;      /* waves of the per-frame cell-sum workgroup */
 constexpr int kSumThreads = kSumWaves * 64;
 constexpr int kRasterThreads = 1024;

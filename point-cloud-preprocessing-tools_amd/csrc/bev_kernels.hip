@@ -87,118 +87,159 @@ struct SlotFetch {
     }
 };
 
-/* One thread per slot.  Writes the ordered cloud (label already 0 for
- * candidates, restored later if phase C un-grounds them), the slot's BEV code,
- * the tile's candidate list (slot order) and optionally the phase-A ground_mat. */
+/* kGatherThreads threads x kSlotsPerThread slots = one tile of kTile consecutive
+ * slots.  Writes the ordered cloud (label already 0 for candidates, restored
+ * later if phase C un-grounds them), each slot's BEV code, the tile's candidate
+ * list IN SLOT ORDER and optionally the phase-A ground_mat.  The kSlotsPerThread
+ * independent load chains per thread (winner -> point -> stencil neighbours) are
+ * what keeps enough requests in flight to stream from HBM. */
 template <bool kIdentity>
-__global__ __launch_bounds__(kTile) void k_gather_ground(BatchPtrs b, Geometry g, int nf)
+__global__ __launch_bounds__(kGatherThreads) void k_gather_ground(BatchPtrs b, Geometry g, int nf)
 {
     int f, tile;
     if (!map_block_xcd(blockIdx.x, nf, g.tiles, f, tile)) return;
     const int tid = threadIdx.x;
-    const int slot = tile * kTile + tid;
-    const bool live = slot < g.S;
     const size_t fbase = (size_t)f * g.S;
 
     const bev_point_t *fpts = kIdentity ? (b.pts + fbase) : (b.pts + b.frames[f].in_offset);
     SlotFetch<kIdentity> fetch{b.winner + fbase, fpts};
 
-    Half lo = {{0, 0, 0, 0}}, hi = {{0, 0, 0, 0}};
-    int gflag = 0;
-    if (live) {
-        long long src = slot;
-        bool have = true;
-        if (!kIdentity) {
-            const uint32_t w = b.winner[fbase + slot];
-            have = (w != 0u);
-            src = (long long)w - 1;
-        }
-        if (have) {
-            lo = *reinterpret_cast<const Half *>(fpts + src);
-            hi = *(reinterpret_cast<const Half *>(fpts + src) + 1);
-        }
-        const int row = slot / g.H, col = slot - row * g.H;
-        XYZI self{__uint_as_float(lo.w[0]), __uint_as_float(lo.w[1]), __uint_as_float(lo.w[2]),
-                  __uint_as_float(hi.w[0])};
-        gflag = phase_a_ground(row, col, g.N, g.H, g.G, self, fetch);
-    }
-    const float px = __uint_as_float(lo.w[0]), py = __uint_as_float(lo.w[1]), pz = __uint_as_float(lo.w[2]);
-    const int label = (int)(int16_t)(hi.w[3] & 0xffffu);
-    const uint32_t code = bev_code(px, py, pz, label, g.rp);
-    const bool is_cand = live && (gflag == 1);
+    Half lo[kSlotsPerThread], hi[kSlotsPerThread];
+    int gflag[kSlotsPerThread];
+    uint32_t code[kSlotsPerThread];
+    bool live[kSlotsPerThread];
 
-    /* compact the tile's candidates in slot order: wave ballot + wave offsets */
-    __shared__ uint32_t wave_cnt[kTile / 64];
-    const int lane = tid & 63, wv = tid >> 6;
-    const unsigned long long m = __ballot(is_cand);
-    if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t before = 0, total = 0;
+    /* issue the self loads of all sub-slots first */
 #pragma unroll
-    for (int k = 0; k < kTile / 64; ++k) {
-        const uint32_t c = wave_cnt[k];
-        if (k < wv) before += c;
-        total += c;
+    for (int k = 0; k < kSlotsPerThread; ++k) {
+        const int slot = tile * kTile + k * kGatherThreads + tid;
+        live[k] = slot < g.S;
+        lo[k] = Half{{0, 0, 0, 0}};
+        hi[k] = Half{{0, 0, 0, 0}};
+        if (live[k]) {
+            long long src = slot;
+            bool have = true;
+            if (!kIdentity) {
+                const uint32_t w = b.winner[fbase + slot];
+                have = (w != 0u);
+                src = (long long)w - 1;
+            }
+            if (have) {
+                lo[k] = *reinterpret_cast<const Half *>(fpts + src);
+                hi[k] = *(reinterpret_cast<const Half *>(fpts + src) + 1);
+            }
+        }
     }
-    if (is_cand) {
-        const uint32_t rank = before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        Candidate c;
-        c.slot = (uint32_t)slot;
-        c.z = pz;
-        c.code = code;
-        c.cell = (uint16_t)ground_cell(px, py);
-        c.label = (int16_t)label;
-        b.cand[((size_t)f * g.tiles + tile) * kTile + rank] = c;
+#pragma unroll
+    for (int k = 0; k < kSlotsPerThread; ++k) {
+        const int slot = tile * kTile + k * kGatherThreads + tid;
+        gflag[k] = 0;
+        if (live[k]) {
+            const int row = slot / g.H, col = slot - row * g.H;
+            XYZI self{__uint_as_float(lo[k].w[0]), __uint_as_float(lo[k].w[1]), __uint_as_float(lo[k].w[2]),
+                      __uint_as_float(hi[k].w[0])};
+            gflag[k] = phase_a_ground(row, col, g.N, g.H, g.G, self, fetch);
+        }
+        code[k] = bev_code(__uint_as_float(lo[k].w[0]), __uint_as_float(lo[k].w[1]), __uint_as_float(lo[k].w[2]),
+                           (int)(int16_t)(hi[k].w[3] & 0xffffu), g.rp);
     }
-    if (tid == 0) b.ncand[(size_t)f * g.tiles + tile] = total;
 
-    if (live) {
-        if (is_cand) hi.w[3] &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
-        Half *dst = reinterpret_cast<Half *>(b.ordered + fbase + slot);
-        dst[0] = lo;
-        dst[1] = hi;
-        b.codes[fbase + slot] = is_cand ? kSkip : code;
-        if (b.gm) b.gm[fbase + slot] = (int8_t)gflag;
+    /* compact the tile's candidates in slot order = (k, tid) order */
+    constexpr int kWaves = kGatherThreads / 64;
+    __shared__ uint32_t wave_cnt[kSlotsPerThread][kWaves];
+    const int lane = tid & 63, wv = tid >> 6;
+    unsigned long long m[kSlotsPerThread];
+#pragma unroll
+    for (int k = 0; k < kSlotsPerThread; ++k) {
+        m[k] = __ballot(live[k] && gflag[k] == 1);
+        if (lane == 0) wave_cnt[k][wv] = (uint32_t)__popcll(m[k]);
     }
+    __syncthreads();
+    uint32_t running = 0;
+    Candidate *tcand = b.cand + ((size_t)f * g.tiles + tile) * kTile;
+#pragma unroll
+    for (int k = 0; k < kSlotsPerThread; ++k) {
+        uint32_t before = running;
+#pragma unroll
+        for (int w = 0; w < kWaves; ++w) {
+            const uint32_t c = wave_cnt[k][w];
+            if (w < wv) before += c;
+            running += c;
+        }
+        const bool is_cand = live[k] && gflag[k] == 1;
+        const int slot = tile * kTile + k * kGatherThreads + tid;
+        if (is_cand) {
+            const uint32_t rank = before + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull));
+            Candidate c;
+            c.slot = (uint32_t)slot;
+            c.z = __uint_as_float(lo[k].w[2]);
+            c.code = code[k];
+            c.cell = (uint16_t)ground_cell(__uint_as_float(lo[k].w[0]), __uint_as_float(lo[k].w[1]));
+            c.label = (int16_t)(hi[k].w[3] & 0xffffu);
+            tcand[rank] = c;
+            hi[k].w[3] &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
+        }
+        if (live[k]) {
+            Half *dst = reinterpret_cast<Half *>(b.ordered + fbase + slot);
+            dst[0] = lo[k];
+            dst[1] = hi[k];
+            b.codes[fbase + slot] = is_cand ? kSkip : code[k];
+            if (b.gm) b.gm[fbase + slot] = (int8_t)gflag[k];
+        }
+    }
+    if (tid == 0) b.ncand[(size_t)f * g.tiles + tile] = running;
 }
 
 /* getOrderedCloud alone (bev_order_cloud): no ground work. */
-__global__ __launch_bounds__(kTile) void k_gather_only(BatchPtrs b, Geometry g, int nf)
+__global__ __launch_bounds__(kGatherThreads) void k_gather_only(BatchPtrs b, Geometry g, int nf)
 {
     int f, tile;
     if (!map_block_xcd(blockIdx.x, nf, g.tiles, f, tile)) return;
-    const int slot = tile * kTile + threadIdx.x;
-    if (slot >= g.S) return;
     const size_t fbase = (size_t)f * g.S;
     const bev_point_t *fpts = b.pts + b.frames[f].in_offset;
-    Half lo = {{0, 0, 0, 0}}, hi = {{0, 0, 0, 0}};
-    const uint32_t w = b.winner[fbase + slot];
-    if (w) {
-        lo = *reinterpret_cast<const Half *>(fpts + (w - 1));
-        hi = *(reinterpret_cast<const Half *>(fpts + (w - 1)) + 1);
+#pragma unroll
+    for (int k = 0; k < kSlotsPerThread; ++k) {
+        const int slot = tile * kTile + k * kGatherThreads + threadIdx.x;
+        if (slot >= g.S) continue;
+        Half lo = {{0, 0, 0, 0}}, hi = {{0, 0, 0, 0}};
+        const uint32_t w = b.winner[fbase + slot];
+        if (w) {
+            lo = *reinterpret_cast<const Half *>(fpts + (w - 1));
+            hi = *(reinterpret_cast<const Half *>(fpts + (w - 1)) + 1);
+        }
+        Half *dst = reinterpret_cast<Half *>(b.ordered + fbase + slot);
+        dst[0] = lo;
+        dst[1] = hi;
     }
-    Half *dst = reinterpret_cast<Half *>(b.ordered + fbase + slot);
-    dst[0] = lo;
-    dst[1] = hi;
 }
 
 /* ------------------------------------------------------------------------- */
 /* markGroundPoints phase B + divide, BatchMultiBevGen.cpp:187-210.
  * One workgroup (8 waves) per frame.
- *   LDS: hist[8][3750] u32 | cell_start[3750] | cell_total[3750] | scan scratch
- *   pass 1  wave w owns a contiguous range of tiles (slot order); counts its
- *           candidates per cell (LDS atomics).
+ *   LDS: hist[8][3750] u32 (later reused as the z staging chunk) | cell_start |
+ *        cell_total | per-wave tile counts | scan scratch
+ *   pass 1  wave w owns a contiguous range of tiles (slot order) and counts its
+ *           candidates per cell (LDS atomics; order-free, so loads are issued
+ *           several slices at a time).
  *   scan    hist[w][c] -> offset of wave w inside cell c's run;
  *           cell_start = exclusive scan of the totals.
- *   pass 2  each wave re-walks its range IN ORDER; inside a 64-slice lanes of
- *           the same cell are ranked with ballots, so the placement into
- *           zsorted is a stable sort by cell == row-major order per cell.
- *   pass 3  one lane per cell adds its run sequentially in float32
- *           (sum += z; cnt = cnt + 1 from 0.01f), then avg = sum / cnt.      */
+ *   pass 2  each wave re-walks its range IN ORDER (next slice prefetched);
+ *           inside a 64-slice, lanes of the same cell are ranked with ballots,
+ *           so the placement into zsorted is a stable sort by cell, i.e. each
+ *           cell's run is in row-major slot order.
+ *   pass 3  zsorted is staged through LDS in coalesced chunks; one lane per
+ *           cell adds its run sequentially in float32 (sum += z; cnt = cnt + 1
+ *           from 0.01f) — the reference's accumulation order — then
+ *           avg = sum / cnt.                                                  */
 constexpr int kCells = kGridCells;
 constexpr int kScanPerThread = (kCells + kSumThreads - 1) / kSumThreads; /* 8 */
+constexpr int kChunk = kSumWaves * kCells;  /* floats staged per pass-3 chunk (the dead hist region) */
+constexpr int kMaxTilesPerWave = kMaxTiles / kSumWaves + 1;
 
-size_t cell_sums_lds_bytes() { return sizeof(uint32_t) * ((size_t)kSumWaves * kCells + 2 * kCells + kSumWaves + 8); }
+size_t cell_sums_lds_bytes()
+{
+    return sizeof(uint32_t) * ((size_t)kSumWaves * kCells + 2 * kCells + (size_t)kSumWaves * kMaxTilesPerWave + 16);
+}
 
 __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry g)
 {
@@ -206,7 +247,8 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     uint32_t *hist = lds;                         /* [kSumWaves][kCells] */
     uint32_t *cell_start = hist + kSumWaves * kCells;
     uint32_t *cell_total = cell_start + kCells;
-    uint32_t *wave_sum = cell_total + kCells;     /* [kSumWaves] */
+    uint32_t *tile_cnt = cell_total + kCells;     /* [kSumWaves][kMaxTilesPerWave] */
+    uint32_t *wave_sum = tile_cnt + kSumWaves * kMaxTilesPerWave; /* [kSumWaves] */
 
     const int f = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -215,16 +257,27 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     const uint32_t *ncand = b.ncand + (size_t)f * T;
     float *zs = b.zsorted + (size_t)f * g.S;
 
+    const int t0 = (int)((long long)T * wv / kSumWaves), t1 = (int)((long long)T * (wv + 1) / kSumWaves);
+    uint32_t *mycnt = tile_cnt + wv * kMaxTilesPerWave;
+    for (int t = t0 + lane; t < t1; t += 64) mycnt[t - t0] = ncand[t];
     for (int k = tid; k < kSumWaves * kCells; k += kSumThreads) hist[k] = 0u;
     __syncthreads();
 
-    const int t0 = (int)((long long)T * wv / kSumWaves), t1 = (int)((long long)T * (wv + 1) / kSumWaves);
     uint32_t *myhist = hist + wv * kCells;
 
-    /* pass 1 */
+    /* pass 1: order-free histogram of this wave's range */
     for (int t = t0; t < t1; ++t) {
-        const int n = (int)ncand[t];
-        for (int i = lane; i < n; i += 64) atomicAdd(&myhist[cand[(size_t)t * kTile + i].cell], 1u);
+        const int n = (int)mycnt[t - t0];
+        const Candidate *tc = cand + (size_t)t * kTile;
+        int i = lane;
+        for (; i + 192 < n; i += 256) {
+            const uint32_t c0 = tc[i].cell, c1 = tc[i + 64].cell, c2 = tc[i + 128].cell, c3 = tc[i + 192].cell;
+            atomicAdd(&myhist[c0], 1u);
+            atomicAdd(&myhist[c1], 1u);
+            atomicAdd(&myhist[c2], 1u);
+            atomicAdd(&myhist[c3], 1u);
+        }
+        for (; i < n; i += 64) atomicAdd(&myhist[tc[i].cell], 1u);
     }
     __syncthreads();
 
@@ -272,59 +325,98 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     }
     __syncthreads();
 
-    /* pass 2: stable placement */
-    for (int t = t0; t < t1; ++t) {
-        const int n = (int)ncand[t];
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int i = i0 + lane;
-            const bool valid = i < n;
-            int cell = -1;
-            float z = 0.f;
-            if (valid) {
-                const Candidate c = cand[(size_t)t * kTile + i];
-                cell = c.cell;
-                z = c.z;
+    /* pass 2: stable placement, one 64-slice at a time, next slice prefetched */
+    {
+        int t = t0, i0 = 0;
+        int n = (t < t1) ? (int)mycnt[0] : 0;
+        while (t < t1 && n == 0) { ++t; n = (t < t1) ? (int)mycnt[t - t0] : 0; }
+        bool valid = false;
+        Candidate cur{};
+        if (t < t1) {
+            valid = (i0 + lane) < n;
+            if (valid) cur = cand[(size_t)t * kTile + i0 + lane];
+        }
+        while (t < t1) {
+            /* locate and prefetch the next slice */
+            int nt = t, ni0 = i0 + 64, nn = n;
+            if (ni0 >= nn) {
+                ni0 = 0;
+                do { ++nt; nn = (nt < t1) ? (int)mycnt[nt - t0] : 0; } while (nt < t1 && nn == 0);
             }
-            unsigned long long todo = __ballot(valid);
+            bool nvalid = false;
+            Candidate nxt{};
+            if (nt < t1) {
+                nvalid = (ni0 + lane) < nn;
+                if (nvalid) nxt = cand[(size_t)nt * kTile + ni0 + lane];
+            }
+            /* rank the current slice: lanes holding the same cell find each other with
+             * one ballot per key bit (12 bits cover 3750 cells) — constant work however
+             * many distinct cells the 64 candidates have */
+            const uint32_t cell = valid ? (uint32_t)cur.cell : 0xfffu; /* 4095 is not a cell */
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 12; ++bit) {
+                const bool one = (cell >> bit) & 1u;
+                const unsigned long long bal = __ballot(one);
+                peers &= one ? bal : ~bal;
+            }
             uint32_t pos = 0;
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const int lc = __shfl(cell, leader);
-                const unsigned long long same = __ballot(valid && cell == lc);
-                if (valid && cell == lc) {
-                    const uint32_t off = myhist[lc];
-                    pos = cell_start[lc] + off + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                }
-                if (lane == leader) myhist[lc] += (uint32_t)__popcll(same);
-                todo &= ~same;
+            if (valid) {
+                const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+                pos = cell_start[cell] + myhist[cell] + below;
             }
-            if (valid) zs[pos] = z;
+            /* the lowest lane of each peer group advances the wave's cursor for that cell;
+             * every read above is issued before this write (same wave, program order) */
+            if (valid && (peers & ((1ull << lane) - 1ull)) == 0ull) myhist[cell] += (uint32_t)__popcll(peers);
+            if (valid) zs[pos] = cur.z;
+            t = nt; i0 = ni0; n = nn; valid = nvalid; cur = nxt;
         }
     }
     __threadfence_block();
     __syncthreads();
 
-    /* pass 3: in-order float accumulation, one lane per cell */
+    /* pass 3: in-order float accumulation; thread owns cells tid + 512*j */
+    float sum[kScanPerThread], cnt[kScanPerThread];
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; ++j) {
+        sum[j] = 0.0f;   /* :133-134 */
+        cnt[j] = 0.01f;  /* :135-136 */
+    }
+    const int n_total = (int)(cell_start[kCells - 1] + cell_total[kCells - 1]);
+    float *zchunk = reinterpret_cast<float *>(hist);
+    for (int chunk0 = 0; chunk0 < n_total; chunk0 += kChunk) {
+        const int cn = min(kChunk, n_total - chunk0);
+        for (int i = tid; i < cn; i += kSumThreads) zchunk[i] = zs[chunk0 + i];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kScanPerThread; ++j) {
+            const int c = tid + j * kSumThreads;
+            if (c < kCells) {
+                const int st = (int)cell_start[c];
+                const int a = max(st, chunk0) - chunk0;
+                const int e = min(st + (int)cell_total[c], chunk0 + cn) - chunk0;
+                float sj = sum[j], cj = cnt[j];
+                int i = a;
+                for (; i + 4 <= e; i += 4) {
+                    const float v0 = zchunk[i], v1 = zchunk[i + 1], v2 = zchunk[i + 2], v3 = zchunk[i + 3];
+                    sj += v0; sj += v1; sj += v2; sj += v3;       /* :198-199 */
+                    cj += 1.0f; cj += 1.0f; cj += 1.0f; cj += 1.0f; /* :205-206 */
+                }
+                for (; i < e; ++i) {
+                    sj += zchunk[i];
+                    cj = cj + 1.0f;
+                }
+                sum[j] = sj;
+                cnt[j] = cj;
+            }
+        }
+        __syncthreads();
+    }
     float *avg = b.avg + (size_t)f * kCells;
-    for (int c = tid; c < kCells; c += kSumThreads) {
-        const int n = (int)cell_total[c];
-        const float *p = zs + cell_start[c];
-        float sum = 0.0f;                 /* :133-134 */
-        float cnt = 0.01f;                /* :135-136 */
-        int i = 0;
-        for (; i + 8 <= n; i += 8) {
-            float v0 = p[i], v1 = p[i + 1], v2 = p[i + 2], v3 = p[i + 3];
-            float v4 = p[i + 4], v5 = p[i + 5], v6 = p[i + 6], v7 = p[i + 7];
-            sum += v0; sum += v1; sum += v2; sum += v3;
-            sum += v4; sum += v5; sum += v6; sum += v7;
-            cnt += 1.0f; cnt += 1.0f; cnt += 1.0f; cnt += 1.0f;
-            cnt += 1.0f; cnt += 1.0f; cnt += 1.0f; cnt += 1.0f;
-        }
-        for (; i < n; ++i) {
-            sum += p[i];                  /* :198-199 */
-            cnt = cnt + 1.0f;             /* :205-206 */
-        }
-        avg[c] = sum / cnt;               /* :210 */
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; ++j) {
+        const int c = tid + j * kSumThreads;
+        if (c < kCells) avg[c] = sum[j] / cnt[j]; /* :210 */
     }
 }
 
@@ -332,34 +424,38 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
 /* markGroundPoints phase C for the candidates, BatchMultiBevGen.cpp:216-250.
  * A candidate that is higher than a neighbour cell's average + 0.30 stops
  * being ground: its label is restored and it gets its BEV code back.        */
-__global__ __launch_bounds__(kTile) void k_ground_resolve(BatchPtrs b, Geometry g, int nf)
+__global__ __launch_bounds__(kGatherThreads) void k_ground_resolve(BatchPtrs b, Geometry g, int nf)
 {
     int f, tile;
     if (!map_block_xcd(blockIdx.x, nf, g.tiles, f, tile)) return;
     const uint32_t n = b.ncand[(size_t)f * g.tiles + tile];
-    if (threadIdx.x >= n) return;
-    const Candidate c = b.cand[((size_t)f * g.tiles + tile) * kTile + threadIdx.x];
     const float *avg = b.avg + (size_t)f * kCells;
-    if (above_neighbour_ground(c.z, (int)c.cell, avg)) {
-        const size_t idx = (size_t)f * g.S + c.slot;
-        reinterpret_cast<int16_t *>(b.ordered + idx)[14] = c.label; /* byte offset 28 */
-        b.codes[idx] = c.code;
+    for (uint32_t i = threadIdx.x; i < n; i += kGatherThreads) {
+        const Candidate c = b.cand[((size_t)f * g.tiles + tile) * kTile + i];
+        if (above_neighbour_ground(c.z, (int)c.cell, avg)) {
+            const size_t idx = (size_t)f * g.S + c.slot;
+            reinterpret_cast<int16_t *>(b.ordered + idx)[14] = c.label; /* byte offset 28 */
+            b.codes[idx] = c.code;
+        }
     }
 }
 
 /* Final cv::Mat ground_mat (optional output): phase C writes 0 wherever the
  * neighbour test fires, for EVERY slot (:236-240). */
-__global__ __launch_bounds__(kTile) void k_ground_mat(BatchPtrs b, Geometry g, int8_t *out, int nf)
+__global__ __launch_bounds__(kGatherThreads) void k_ground_mat(BatchPtrs b, Geometry g, int8_t *out, int nf)
 {
     int f, tile;
     if (!map_block_xcd(blockIdx.x, nf, g.tiles, f, tile)) return;
-    const int slot = tile * kTile + threadIdx.x;
-    if (slot >= g.S) return;
-    const size_t idx = (size_t)f * g.S + slot;
-    const float4 a = *reinterpret_cast<const float4 *>(b.ordered + idx);
-    const int cell = ground_cell(a.x, a.y);
-    const bool hit = above_neighbour_ground(a.z, cell, b.avg + (size_t)f * kCells);
-    out[idx] = hit ? (int8_t)0 : b.gm[idx];
+#pragma unroll
+    for (int k = 0; k < kSlotsPerThread; ++k) {
+        const int slot = tile * kTile + k * kGatherThreads + threadIdx.x;
+        if (slot >= g.S) continue;
+        const size_t idx = (size_t)f * g.S + slot;
+        const float4 a = *reinterpret_cast<const float4 *>(b.ordered + idx);
+        const int cell = ground_cell(a.x, a.y);
+        const bool hit = above_neighbour_ground(a.z, cell, b.avg + (size_t)f * kCells);
+        out[idx] = hit ? (int8_t)0 : b.gm[idx];
+    }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -478,14 +574,14 @@ void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, bool id
     if (nf == 0) return;
     const int grid = xcd_grid(nf, g.tiles);
     if (identity)
-        hipLaunchKernelGGL(k_gather_ground<true>, dim3(grid), dim3(kTile), 0, st, b, g, nf);
+        hipLaunchKernelGGL(k_gather_ground<true>, dim3(grid), dim3(kGatherThreads), 0, st, b, g, nf);
     else
-        hipLaunchKernelGGL(k_gather_ground<false>, dim3(grid), dim3(kTile), 0, st, b, g, nf);
+        hipLaunchKernelGGL(k_gather_ground<false>, dim3(grid), dim3(kGatherThreads), 0, st, b, g, nf);
 }
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_gather_only, dim3(xcd_grid(nf, g.tiles)), dim3(kTile), 0, st, b, g, nf);
+    hipLaunchKernelGGL(k_gather_only, dim3(xcd_grid(nf, g.tiles)), dim3(kGatherThreads), 0, st, b, g, nf);
 }
 void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {
@@ -495,7 +591,7 @@ void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_ground_resolve, dim3(xcd_grid(nf, g.tiles)), dim3(kTile), 0, st, b, g, nf);
+    hipLaunchKernelGGL(k_ground_resolve, dim3(xcd_grid(nf, g.tiles)), dim3(kGatherThreads), 0, st, b, g, nf);
 }
 void launch_bev_raster(const Geometry &g, const uint32_t *codes, size_t code_stride, uint32_t n_codes,
                        uint8_t *multi, uint8_t *single, bool want_multi, bool want_single, int nf,
@@ -509,7 +605,7 @@ void launch_bev_raster(const Geometry &g, const uint32_t *codes, size_t code_str
 void launch_ground_mat(const Geometry &g, const BatchPtrs &b, int8_t *out, int nf, hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_ground_mat, dim3(xcd_grid(nf, g.tiles)), dim3(kTile), 0, st, b, g, out, nf);
+    hipLaunchKernelGGL(k_ground_mat, dim3(xcd_grid(nf, g.tiles)), dim3(kGatherThreads), 0, st, b, g, out, nf);
 }
 void launch_cloud_codes(const Geometry &g, const bev_point_t *cloud, uint32_t n, uint32_t *codes, hipStream_t st)
 {
