@@ -8,6 +8,7 @@
  * test-suite compares this composition with the sequential oracle, so a wrong
  * closed form is caught without a GPU.
  */
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -43,6 +44,85 @@ void hc_angle(const float *dx, const float *dy, const float *dz, size_t n, uint8
 }
 
 uint32_t hc_tan_threshold_bits(void) { return kTanThresholdBits; }
+
+/* The reference's expression (BatchMultiBevGen.cpp:173-179, float overloads) on an
+ * angle a = atan2f(...) that is already known. */
+static inline bool ref_accepts_angle(float a)
+{
+    float angle = (float)((double)a * 180.0 / M_PI);
+    return std::fabs(angle - 0.0f) <= 10.0f;
+}
+
+/* Re-derives, against the libm of THIS machine, the facts bev_exact.h relies on:
+ *   out[0] = largest float bits a with ref_accepts_angle(a) (and the set is a prefix)
+ *   out[1] = largest float bits q with ref_accepts_angle(atanf(q))
+ *   out[2] = number of non-negative floats q (incl. +inf) where
+ *            ref_accepts_angle(atanf(q)) != (q <= out[1])        (must be 0)
+ *   out[3] = number of places where atanf decreases over the non-negative floats (must be 0)
+ *   out[4] = number of non-negative floats a where ref_accepts_angle(a) != (a <= out[0]) (must be 0) */
+void hc_derive_angle_threshold(uint64_t *out)
+{
+    uint32_t ta = 0;
+    for (uint32_t u = 0; u <= 0x7f800000u; ++u) {
+        if (ref_accepts_angle(bits_to_float(u))) ta = u; else break;
+    }
+    uint64_t bad_a = 0, bad_q = 0, nonmono = 0;
+    uint32_t qs = 0;
+#pragma omp parallel for reduction(+ : bad_a) schedule(static)
+    for (int64_t u = 0; u <= 0x7f800000LL; ++u)
+        if (ref_accepts_angle(bits_to_float((uint32_t)u)) != ((uint32_t)u <= ta)) ++bad_a;
+    /* Q*: scan downwards from 1.0f (atan(1) = 45 deg is rejected) */
+    for (uint32_t u = 0x3f800000u;; --u) {
+        if (ref_accepts_angle(atanf(bits_to_float(u)))) { qs = u; break; }
+        if (u == 0) break;
+    }
+#pragma omp parallel for reduction(+ : bad_q, nonmono) schedule(static)
+    for (int64_t u = 0; u <= 0x7f800000LL; ++u) {
+        const float a = atanf(bits_to_float((uint32_t)u));
+        if (ref_accepts_angle(a) != ((uint32_t)u <= qs)) ++bad_q;
+        if (u > 0 && a < atanf(bits_to_float((uint32_t)(u - 1)))) ++nonmono;
+    }
+    out[0] = ta; out[1] = qs; out[2] = bad_q; out[3] = nonmono; out[4] = bad_a;
+}
+
+/* Random + structured (dz, s) pairs around the threshold: the reference expression
+ * with libm atan2f against angle_is_ground's ratio test.  Returns mismatches. */
+uint64_t hc_angle_vs_libm(uint64_t n, uint64_t seed)
+{
+    uint64_t bad = 0;
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        uint64_t z = seed + 0x9e3779b97f4a7c15ULL * (uint64_t)(i + 1);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; z ^= z >> 31;
+        uint64_t z2 = z * 0xd1b54a32d192ed03ULL + 0x2545f4914f6cdd1dULL;
+        z2 = (z2 ^ (z2 >> 29)) * 0xbf58476d1ce4e5b9ULL; z2 ^= z2 >> 32;
+        float dx, dy, dz;
+        const int mode = (int)(z & 7);
+        if (mode < 5) { /* near the threshold: dz = s * tan(10 deg) +- a few ulps */
+            const int e = (int)((z >> 8) % 60) - 30;
+            dx = std::ldexp(1.0f + (float)((z >> 16) & 0x7fffff) / 8388608.0f, e);
+            dy = (mode & 1) ? 0.0f : dx * (float)((z >> 40) & 0xff) / 64.0f;
+            const float s = std::sqrt(dx * dx + dy * dy);
+            float t = (float)(0.17632698070846498 * (double)s);
+            uint32_t ut; std::memcpy(&ut, &t, 4);
+            ut += (uint32_t)((int)((z2 >> 3) % 33) - 16);
+            std::memcpy(&dz, &ut, 4);
+            if (z2 & 1) dz = -dz;
+        } else if (mode < 7) { /* arbitrary bit patterns incl. denormals, inf, NaN */
+            uint32_t a = (uint32_t)z2, b = (uint32_t)(z2 >> 32), c = (uint32_t)(z >> 32);
+            std::memcpy(&dx, &a, 4); std::memcpy(&dy, &b, 4); std::memcpy(&dz, &c, 4);
+        } else { /* plain small reals */
+            dx = ((int)(z2 & 0xffff) - 32768) / 512.0f;
+            dy = ((int)((z2 >> 16) & 0xffff) - 32768) / 512.0f;
+            dz = ((int)((z2 >> 32) & 0xffff) - 32768) / 4096.0f;
+        }
+        const float horiz = std::sqrt(dx * dx + dy * dy);
+        const float angle = (float)((double)std::atan2(dz, horiz) * 180.0 / M_PI); /* float overload = atan2f */
+        const bool ref = std::fabs(angle - 0.0f) <= 10.0f;
+        if (ref != angle_is_ground(dx, dy, dz)) ++bad;
+    }
+    return bad;
+}
 
 int hc_ground_cell(float x, float y) { return ground_cell(x, y); }
 
