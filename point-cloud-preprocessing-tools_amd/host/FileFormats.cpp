@@ -1,0 +1,285 @@
+#include "FileFormats.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace bevio {
+
+namespace {
+
+struct Field {
+    std::string name;
+    int size = 4;
+    char type = 'F';
+    int count = 1;
+    int offset = 0; /* byte offset inside one packed record */
+};
+
+double read_scalar(const unsigned char *p, int size, char type)
+{
+    switch (type) {
+    case 'F':
+        if (size == 4) { float v; std::memcpy(&v, p, 4); return v; }
+        if (size == 8) { double v; std::memcpy(&v, p, 8); return v; }
+        break;
+    case 'U':
+        if (size == 1) return *p;
+        if (size == 2) { std::uint16_t v; std::memcpy(&v, p, 2); return v; }
+        if (size == 4) { std::uint32_t v; std::memcpy(&v, p, 4); return v; }
+        if (size == 8) { std::uint64_t v; std::memcpy(&v, p, 8); return (double)v; }
+        break;
+    case 'I':
+        if (size == 1) return (std::int8_t)*p;
+        if (size == 2) { std::int16_t v; std::memcpy(&v, p, 2); return v; }
+        if (size == 4) { std::int32_t v; std::memcpy(&v, p, 4); return v; }
+        if (size == 8) { std::int64_t v; std::memcpy(&v, p, 8); return (double)v; }
+        break;
+    }
+    return 0.0;
+}
+
+void assign_field(pcl::PointXYZIRCT &pt, const std::string &name, double v)
+{
+    if (name == "x") pt.x = (float)v;
+    else if (name == "y") pt.y = (float)v;
+    else if (name == "z") pt.z = (float)v;
+    else if (name == "intensity") pt.intensity = (float)v;
+    else if (name == "row") pt.row = (std::uint16_t)v;
+    else if (name == "col") pt.col = (std::uint16_t)v;
+    else if (name == "t") pt.t = (std::uint32_t)v;
+    else if (name == "label") pt.label = (std::int16_t)v;
+}
+
+/* liblzf decompression (format used by PCL's DATA binary_compressed) */
+bool lzf_decompress(const unsigned char *in, std::size_t in_len, unsigned char *out, std::size_t out_len)
+{
+    const unsigned char *ip = in, *in_end = in + in_len;
+    unsigned char *op = out, *out_end = out + out_len;
+    while (ip < in_end) {
+        unsigned ctrl = *ip++;
+        if (ctrl < 32) { /* literal run */
+            ++ctrl;
+            if (op + ctrl > out_end || ip + ctrl > in_end) return false;
+            std::memcpy(op, ip, ctrl);
+            op += ctrl; ip += ctrl;
+        } else { /* back reference */
+            unsigned len = ctrl >> 5;
+            if (len == 7) { if (ip >= in_end) return false; len += *ip++; }
+            if (ip >= in_end) return false;
+            const unsigned char *ref = op - ((ctrl & 0x1f) << 8) - 1 - *ip++;
+            len += 2;
+            if (ref < out || op + len > out_end) return false;
+            while (len--) *op++ = *ref++;
+        }
+    }
+    return op == out_end;
+}
+
+} // namespace
+
+int loadPCDFile(const std::string &path, pcl::PointCloud<pcl::PointXYZIRCT> &cloud)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return -1;
+    std::vector<Field> fields;
+    std::size_t points = 0, width = 0, height = 1;
+    bool have_points = false;
+    std::string data_kind, line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ss(line);
+        std::string key;
+        ss >> key;
+        if (key == "FIELDS" || key == "COLUMNS") {
+            std::string n;
+            while (ss >> n) { Field fd; fd.name = n; fields.push_back(fd); }
+        } else if (key == "SIZE") {
+            for (auto &fd : fields) ss >> fd.size;
+        } else if (key == "TYPE") {
+            for (auto &fd : fields) ss >> fd.type;
+        } else if (key == "COUNT") {
+            for (auto &fd : fields) ss >> fd.count;
+        } else if (key == "WIDTH") {
+            ss >> width;
+        } else if (key == "HEIGHT") {
+            ss >> height;
+        } else if (key == "POINTS") {
+            ss >> points; have_points = true;
+        } else if (key == "DATA") {
+            ss >> data_kind;
+            break;
+        }
+    }
+    if (fields.empty() || data_kind.empty()) return -1;
+    if (!have_points) points = width * height; /* PCL accepts WIDTH 0 HEIGHT 0 with POINTS n */
+    int rec = 0;
+    for (auto &fd : fields) { fd.offset = rec; rec += fd.size * fd.count; }
+    cloud.points.assign(points, pcl::PointXYZIRCT{});
+    cloud.width = (std::uint32_t)(width ? width : points);
+    cloud.height = (std::uint32_t)(height ? height : 1);
+
+    if (data_kind == "ascii") {
+        for (std::size_t i = 0; i < points; ++i) {
+            if (!std::getline(f, line)) return -1;
+            std::istringstream ss(line);
+            for (auto &fd : fields)
+                for (int k = 0; k < fd.count; ++k) {
+                    double v = 0;
+                    ss >> v;
+                    if (k == 0) assign_field(cloud.points[i], fd.name, v);
+                }
+        }
+        return 0;
+    }
+    if (data_kind == "binary") {
+        std::vector<unsigned char> buf((std::size_t)rec * points);
+        f.read(reinterpret_cast<char *>(buf.data()), (std::streamsize)buf.size());
+        if ((std::size_t)f.gcount() != buf.size()) return -1;
+        for (std::size_t i = 0; i < points; ++i)
+            for (auto &fd : fields)
+                assign_field(cloud.points[i], fd.name, read_scalar(buf.data() + i * rec + fd.offset, fd.size, fd.type));
+        return 0;
+    }
+    if (data_kind == "binary_compressed") {
+        std::uint32_t comp = 0, uncomp = 0;
+        f.read(reinterpret_cast<char *>(&comp), 4);
+        f.read(reinterpret_cast<char *>(&uncomp), 4);
+        if (!f || uncomp != (std::uint64_t)rec * points) return -1;
+        std::vector<unsigned char> cbuf(comp), buf(uncomp);
+        f.read(reinterpret_cast<char *>(cbuf.data()), comp);
+        if ((std::size_t)f.gcount() != comp) return -1;
+        if (!lzf_decompress(cbuf.data(), comp, buf.data(), uncomp)) return -1;
+        /* compressed PCDs are stored field-by-field (SoA) */
+        std::size_t base = 0;
+        for (auto &fd : fields) {
+            const std::size_t stride = (std::size_t)fd.size * fd.count;
+            for (std::size_t i = 0; i < points; ++i)
+                assign_field(cloud.points[i], fd.name, read_scalar(buf.data() + base + i * stride, fd.size, fd.type));
+            base += stride * points;
+        }
+        return 0;
+    }
+    return -1;
+}
+
+int savePCDFileBinary(const std::string &path, const pcl::PointCloud<pcl::PointXYZIRCT> &cloud)
+{
+    const std::size_t n = cloud.points.size();
+    std::ostringstream h;
+    h << "# .PCD v0.7 - Point Cloud Data file format\n"
+      << "VERSION 0.7\n"
+      << "FIELDS x y z intensity row col t label\n"
+      << "SIZE 4 4 4 4 2 2 4 2\n"
+      << "TYPE F F F F U U U I\n"
+      << "COUNT 1 1 1 1 1 1 1 1\n"
+      << "WIDTH " << n << "\n"
+      << "HEIGHT 1\n"
+      << "VIEWPOINT 0 0 0 1 0 0 0\n"
+      << "POINTS " << n << "\n"
+      << "DATA binary\n";
+    const std::string head = h.str();
+    std::vector<unsigned char> buf(head.size() + n * 26);
+    std::memcpy(buf.data(), head.data(), head.size());
+    unsigned char *p = buf.data() + head.size();
+    for (const auto &pt : cloud.points) { /* packed 26-byte records */
+        std::memcpy(p, &pt.x, 4); std::memcpy(p + 4, &pt.y, 4); std::memcpy(p + 8, &pt.z, 4);
+        std::memcpy(p + 12, &pt.intensity, 4); std::memcpy(p + 16, &pt.row, 2); std::memcpy(p + 18, &pt.col, 2);
+        std::memcpy(p + 20, &pt.t, 4); std::memcpy(p + 24, &pt.label, 2);
+        p += 26;
+    }
+    return writeFile(path, buf.data(), buf.size()) ? 0 : -1;
+}
+
+bool writeFile(const std::string &path, const void *data, std::size_t n)
+{
+    std::FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = std::fwrite(data, 1, n, f) == n;
+    return std::fclose(f) == 0 && ok;
+}
+
+/* ---- PNG: 8-bit grayscale, zlib stream of stored (uncompressed) deflate blocks ---- */
+namespace {
+std::uint32_t crc_table[256];
+bool crc_ready = false;
+std::uint32_t crc32(const unsigned char *p, std::size_t n, std::uint32_t crc = 0)
+{
+    if (!crc_ready) {
+        for (std::uint32_t i = 0; i < 256; ++i) {
+            std::uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+            crc_table[i] = c;
+        }
+        crc_ready = true;
+    }
+    crc = ~crc;
+    for (std::size_t i = 0; i < n; ++i) crc = crc_table[(crc ^ p[i]) & 0xff] ^ (crc >> 8);
+    return ~crc;
+}
+void put32(std::vector<unsigned char> &v, std::uint32_t x)
+{
+    v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x);
+}
+void chunk(std::vector<unsigned char> &out, const char *tag, const std::vector<unsigned char> &body)
+{
+    put32(out, (std::uint32_t)body.size());
+    std::vector<unsigned char> t(tag, tag + 4);
+    t.insert(t.end(), body.begin(), body.end());
+    out.insert(out.end(), t.begin(), t.end());
+    put32(out, crc32(t.data(), t.size()));
+}
+} // namespace
+
+bool writePngGray8(const std::string &path, const std::uint8_t *pixels, int rows, int cols)
+{
+    std::vector<unsigned char> raw;
+    raw.reserve((std::size_t)rows * (cols + 1));
+    for (int r = 0; r < rows; ++r) {
+        raw.push_back(0); /* filter: none */
+        raw.insert(raw.end(), pixels + (std::size_t)r * cols, pixels + (std::size_t)(r + 1) * cols);
+    }
+    std::vector<unsigned char> z = {0x78, 0x01};
+    std::uint32_t a = 1, b = 0;
+    for (unsigned char c : raw) { a = (a + c) % 65521u; b = (b + a) % 65521u; }
+    for (std::size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+        const std::size_t n = std::min<std::size_t>(65535, raw.size() - off);
+        z.push_back(off + n >= raw.size() ? 1 : 0);
+        z.push_back(n & 0xff); z.push_back(n >> 8);
+        z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
+        z.insert(z.end(), raw.begin() + (std::ptrdiff_t)off, raw.begin() + (std::ptrdiff_t)(off + n));
+        if (raw.empty()) break;
+    }
+    put32(z, (b << 16) | a);
+    std::vector<unsigned char> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::vector<unsigned char> ihdr;
+    put32(ihdr, (std::uint32_t)cols); put32(ihdr, (std::uint32_t)rows);
+    ihdr.push_back(8); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk(out, "IHDR", ihdr);
+    chunk(out, "IDAT", z);
+    chunk(out, "IEND", {});
+    return writeFile(path, out.data(), out.size());
+}
+
+/* cv::format(mat, cv::Formatter::FMT_CSV) for CV_8U, from memory of OpenCV's out.cpp:
+ * every value "%3d", values joined by ", ", every row terminated by "\n". */
+std::string formatCsvU8(const std::uint8_t *pixels, int rows, int cols)
+{
+    std::string s;
+    s.reserve((std::size_t)rows * (cols * 5));
+    char buf[8];
+    for (int r = 0; r < rows; ++r) {
+        for (int c = 0; c < cols; ++c) {
+            std::snprintf(buf, sizeof buf, "%3d", (int)pixels[(std::size_t)r * cols + c]);
+            s += buf;
+            if (c + 1 < cols) s += ", ";
+        }
+        s += "\n";
+    }
+    return s;
+}
+
+} // namespace bevio

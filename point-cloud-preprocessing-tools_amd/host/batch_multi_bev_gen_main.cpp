@@ -1,0 +1,89 @@
+/*
+ * batch_multi_bev_gen <keyframes_root_dir> <sensor_type>
+ *
+ * Same command line, directory layout and stdout lines as the reference's tool
+ * (BatchMultiBevGen.cpp:664-771); the per-file loop (:727-757) runs on MI355X
+ * through the C ABI in batches.  Extra, optional environment:
+ *   BEV_DEVICES=N   use GPUs 0..N-1 of this node (one host thread + one context
+ *                   per GPU, contiguous shards of the sorted file list)
+ *   BEV_BATCH=B     frames per bev_process_batch call (default 32)
+ *   BEV_NO_PNG=1    skip the 25 PNG files per frame
+ */
+#include <chrono>
+#include <cstdlib>
+#include <iostream>
+#include <thread>
+
+#include "BatchMultiBevGen.h"
+#include "LabelStep.h"
+
+void bevhost_recreate_dir(const std::string &dir); /* BatchMultiBevGen.cpp (host): rm -rf + mkdir -p */
+
+int main(int argc, char **argv)
+{
+    if (argc < 3 || argv[1] == nullptr || argv[2] == nullptr) {
+        std::cout << "Usage: " << (argc > 0 ? argv[0] : "batch_multi_bev_gen") << " [keyframes_root_dir] [sensor_type]\n\n"
+                  << "[keyframes_root_dir] should be organized as follows: \n"
+                  << "[keyframes_root_dir]\n"
+                  << "  keyframe_point_cloud/  <- selected point clouds in pcd format, one per frame\n"
+                  << "  keyframe_pose.csv      <- 6-DoF pose for each frame\n\n"
+                  << "[sensor_type] could be HDL_32E, HDL_64E or OS1_64. \n\n"
+                  << "Writes non_ground_point_cloud/, output_multi_bev/{binary,image}/, output_single_bev/{csv,image}/\n"
+                  << "and keyframe_label.csv under [keyframes_root_dir].\n";
+        return 1;
+    }
+    std::string root(argv[1]);
+    if (root.empty() || root.back() != '/') root.append("/");
+    const std::string pcd_dir = root + "keyframe_point_cloud/";
+    const std::string pose_file = root + "keyframe_pose.csv";
+    const std::string label_file = root + "keyframe_label.csv";
+
+    std::vector<std::string> files;
+    getPcdFileNames(pcd_dir, files);
+    setNeighbors();
+    initDirectories(root);
+    bevhost_recreate_dir(root + "non_ground_point_cloud/"); /* :704-705 */
+
+    const SensorType st = parseSensorType(std::string(argv[2]));
+    sensor_params_ = getSensorParams(st);
+    if (sensor_params_.N_SCAN <= 0) return 1; /* the reference would go on with garbage parameters */
+    std::cout << "Using sensor_type " << argv[2] << ", with params: " << printSensorParams(sensor_params_) << "\n";
+
+    const int n_dev = std::max(1, std::atoi(std::getenv("BEV_DEVICES") ? std::getenv("BEV_DEVICES") : "1"));
+    const int batch = std::max(1, std::atoi(std::getenv("BEV_BATCH") ? std::getenv("BEV_BATCH") : "32"));
+    const bool png = std::getenv("BEV_NO_PNG") == nullptr;
+
+    /* Step 1: frames are independent -> contiguous shards of the sorted list, one GPU each */
+    std::vector<double> ms(n_dev, 0.0);
+    std::vector<int> bad(n_dev, 0);
+    std::vector<std::thread> workers;
+    const size_t F = files.size();
+    for (int d = 0; d < n_dev; ++d) {
+        const size_t first = F * d / n_dev, count = F * (d + 1) / n_dev - first;
+        workers.emplace_back([&, d, first, count]() {
+            BatchMultiBevGen gen(root, argv[2], d, batch);
+            if (!gen.ok()) { bad[d] = 1; return; }
+            ms[d] = gen.processFiles(files, first, count, png, n_dev == 1);
+        });
+    }
+    for (auto &w : workers) w.join();
+    for (int d = 0; d < n_dev; ++d)
+        if (bad[d]) return 1;
+    double total_ms = 0;
+    for (double v : ms) total_ms += v;
+    std::cout << "[TIME] Average preprocessing and BEV generation: " << (F ? total_ms / (double)F : 0.0) << "\n";
+
+    /* Step 2 (:762-765) */
+    bool ok = false;
+    std::vector<Pose6f> poses = readKeyframePose(pose_file, &ok);
+    if (!ok) return 1; /* the reference exit(1)s here */
+    if (poses.empty()) {
+        std::cerr << "no keyframe poses\n";
+        return 1;
+    }
+    std::vector<int32_t> major = selectMajorFrames(poses);
+    std::vector<LabelType> labels = getKeyFrameLabel(poses, major);
+    if (!saveLabels(labels, label_file)) return 1;
+    std::cout << "Done. " << std::endl;
+    return 0;
+}

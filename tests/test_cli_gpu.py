@@ -1,0 +1,121 @@
+"""GPU: the batch_multi_bev_gen CLI (host C++ over the C ABI) end to end:
+directory tree, file names and sizes, .bin / .csv / .png / .pcd payloads against
+the oracle, and keyframe_label.csv against a straightforward Python restatement."""
+import subprocess
+
+import numpy as np
+import pytest
+
+import bev_amd
+import oracle_lib as orc
+import pcd_util
+from bev_amd import synth
+
+pytestmark = pytest.mark.gpu
+CLI = bev_amd.PKG_DIR / "host" / "batch_multi_bev_gen"
+
+
+def _pose_line(i, x, y, z, yaw):
+    c, s = np.cos(yaw), np.sin(yaw)
+    r = [c, -s, 0, s, c, 0, 0, 0, 1]
+    return ",".join([str(i), repr(x), repr(y), repr(z), "0", "0", repr(yaw)] + [repr(float(v)) for v in r])
+
+
+def _python_labels(xyz):
+    """selectMajorFrames + getKeyFrameLabel (BatchMultiBevGen.cpp:502-636), exhaustive search, float32."""
+    xyz = xyz.astype(np.float32)
+
+    def d2(a, b):
+        r = np.float32(0)
+        for k in range(3):
+            df = np.float32(a[k] - b[k])
+            r = np.float32(r + np.float32(df * df))
+        return r
+
+    major = [0]
+    for i in range(1, len(xyz)):
+        last = xyz[major[-1]]
+        df = (xyz[i] - last).astype(np.float32)
+        dist = np.float32(np.sqrt(np.float32(np.float32(np.float32(df[0] * df[0]) + np.float32(df[1] * df[1])) + np.float32(df[2] * df[2]))))
+        if dist < np.float32(20):
+            continue
+        if min(d2(xyz[i], xyz[m]) for m in major) < np.float32(400):
+            continue
+        major.append(i)
+    labels = np.zeros((len(xyz), len(major)), np.float32)
+    for i in range(len(xyz)):
+        ds = np.array([d2(xyz[i], xyz[m]) for m in major], np.float32)
+        order = np.argsort(ds, kind="stable")
+        if major[order[0]] == i:
+            labels[i, order[0]] = 1
+        else:
+            w0 = np.float32(1.0 / (np.float64(ds[order[0]]) + 1e-5))
+            w1 = np.float32(1.0 / (np.float64(ds[order[1]]) + 1e-5)) if len(major) > 1 else np.float32(1.0 / 1e-5)
+            s = np.float32(w0 + w1)
+            i1 = order[1] if len(major) > 1 else 0
+            labels[i, order[0]] = np.float32(w0 / s)
+            labels[i, i1] = np.float32(w1 / s)
+    return major, labels
+
+
+def test_cli_end_to_end(tmp_path):
+    assert CLI.exists(), "host CLI not built"
+    p = bev_amd.params_for_sensor("HDL_32E")
+    sp = orc.sensor_from_params(p)
+    root = tmp_path / "kf"
+    (root / "keyframe_point_cloud").mkdir(parents=True)
+    frames = {
+        "000000": synth.sweep(p, 0),
+        "000001": synth.sweep_unique(p, 1, 16384),   # BASELINE config 1 cloud
+        "000002": synth.adversarial(p, 3000, 5),     # through the ascii reader
+        "000003": synth.firing_order(p, 2),
+        "000004": np.empty(0, bev_amd.POINT_DTYPE),
+    }
+    for name, pts in frames.items():
+        path = root / "keyframe_point_cloud" / f"{name}.pcd"
+        if name == "000002":
+            pcd_util.write_pcd_ascii(path, pts)
+        elif name == "000003":
+            pcd_util.write_pcd_binary(path, pts, width=0, height=0)  # what the KITTI producer effectively writes
+        else:
+            pcd_util.write_pcd_binary(path, pts)
+    (root / "keyframe_point_cloud" / "notes.txt").write_text("ignored")
+    xyz = np.array([[0, 0, 0], [12, 0, 0], [25, 1, 0], [26, 30, 0.5], [3, 2, 0]], np.float64)
+    (root / "keyframe_pose.csv").write_text("\n".join(_pose_line(i, *xyz[i], 0.1 * i) for i in range(5)) + "\n")
+    (root / "output_multi_bev").mkdir()
+    (root / "output_multi_bev" / "stale.bin").write_text("must be removed")  # rm -rf semantics (:49)
+
+    r = subprocess.run([str(CLI), str(root), "HDL_32E"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Using sensor_type HDL_32E, with params: N_SCAN: 32, Horizon_SCAN: 1056, GROUND_UPPER_SCAN: 20" in r.stdout
+    assert [l for l in r.stdout.splitlines() if l.startswith("Converting file: ")] == [f"Converting file: {n}" for n in frames]
+    assert "[TIME] Average preprocessing and BEV generation: " in r.stdout and "Done." in r.stdout
+    assert not (root / "output_multi_bev" / "stale.bin").exists()
+
+    for name, pts in frames.items():
+        o_ord, _, o_multi, o_single = orc.process_frame(sp, pts)
+        b = (root / "output_multi_bev" / "binary" / f"{name}.bin").read_bytes()
+        assert len(b) == 1204224 and b == o_multi.tobytes()
+        csv = (root / "output_single_bev" / "csv" / f"{name}.csv").read_text()
+        assert len(csv) == 250656
+        assert np.array_equal(np.array([[int(v) for v in l.split(",")] for l in csv.splitlines()], np.uint8), o_single)
+        assert np.array_equal(pcd_util.read_png_gray8(root / "output_single_bev" / "image" / f"{name}.png"), o_single)
+        for l in (0, 7, 23):
+            assert np.array_equal(pcd_util.read_png_gray8(root / "output_multi_bev" / "image" / name / f"{l:02d}.png"), o_multi[l])
+        assert len(list((root / "output_multi_bev" / "image" / name).iterdir())) == 24
+        head, cloud = pcd_util.read_pcd_binary(root / "non_ground_point_cloud" / f"{name}.pcd")
+        assert f"POINTS {p.slots}" in head and "FIELDS x y z intensity row col t label" in head
+        assert cloud.tobytes() == o_ord.tobytes()        # labelled, not filtered: still S points
+
+    major, labels = _python_labels(xyz)
+    got = [[float(v) for v in l.rstrip(",").split(",")] for l in (root / "keyframe_label.csv").read_text().splitlines()]
+    assert len(got) == 5 and all(len(g) == len(major) for g in got)
+    assert np.allclose(np.array(got, np.float32), labels, rtol=2e-6, atol=1e-7)  # csv holds 6 significant digits
+
+
+def test_cli_usage_and_unknown_sensor(tmp_path):
+    r = subprocess.run([str(CLI)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Usage:" in r.stdout
+    (tmp_path / "keyframe_point_cloud").mkdir()
+    r = subprocess.run([str(CLI), str(tmp_path), "VLP_16"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Unknown sensor type" in r.stderr
