@@ -81,7 +81,7 @@ def test_cli_end_to_end(tmp_path):
             pcd_util.write_pcd_binary(path, pts)
     (root / "keyframe_point_cloud" / "notes.txt").write_text("ignored")
     xyz = np.array([[0, 0, 0], [12, 0, 0], [25, 1, 0], [26, 30, 0.5], [3, 2, 0]], np.float64)
-    (root / "keyframe_pose.csv").write_text("\n".join(_pose_line(i, *xyz[i], 0.1 * i) for i in range(5)) + "\n")
+    (root / "keyframe_pose.csv").write_text("\n".join(_pose_line(i, *[float(v) for v in xyz[i]], 0.1 * i) for i in range(5)) + "\n")
     (root / "output_multi_bev").mkdir()
     (root / "output_multi_bev" / "stale.bin").write_text("must be removed")  # rm -rf semantics (:49)
 
