@@ -126,6 +126,8 @@ int validate_params(const bev_params_t *p)
     if (p->ground_upper_scan < 1 || p->ground_upper_scan > p->n_scan - 2) return BEV_ERR_INVALID_ARG;
     if (!(p->interval > 0.0f) || p->max_range <= 0) return BEV_ERR_INVALID_ARG;
     if ((size_t)p->n_scan * (size_t)p->horizon_scan > (size_t)kMaxTiles * kTile) return BEV_ERR_UNSUPPORTED;
+    if ((size_t)(p->ground_upper_scan + 1) * (size_t)((p->horizon_scan + kStripCols - 1) / kStripCols) > (size_t)kMaxSegs)
+        return BEV_ERR_UNSUPPORTED;
     const int M = mat_size_of(p);
     if (M < 16 || M > 512 || (M % 16) != 0) return BEV_ERR_UNSUPPORTED;
     if (p->n_layers < 1 || p->n_layers > 30) return BEV_ERR_UNSUPPORTED;
@@ -139,6 +141,8 @@ void fill_geometry(const bev_params_t *p, Geometry *g)
     g->G = p->ground_upper_scan;
     g->S = p->n_scan * p->horizon_scan;
     g->tiles = (g->S + kTile - 1) / kTile;
+    g->strips = (g->H + kStripCols - 1) / kStripCols;
+    g->segs = (g->G + 1) * g->strips;
     g->rp.max_range_f = (float)p->max_range;
     g->rp.interval = p->interval;
     g->rp.height_res = p->height_res;
@@ -450,8 +454,8 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
         CK(hipMalloc((void **)&ln.winner, nb * S * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.codes, c->codes_elems * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.cand, nb * (size_t)c->geo.tiles * kTile * sizeof(Candidate)));
-        CK(hipMalloc((void **)&ln.ncand, nb * (size_t)c->geo.tiles * sizeof(uint32_t)));
+        CK(hipMalloc((void **)&ln.cand, nb * (size_t)c->geo.segs * kSeg * sizeof(Candidate)));
+        CK(hipMalloc((void **)&ln.ncand, nb * (size_t)c->geo.segs * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.zsorted, nb * S * sizeof(float)));
         CK(hipMalloc((void **)&ln.avg, nb * (size_t)bevx::kGridCells * sizeof(float)));
     }

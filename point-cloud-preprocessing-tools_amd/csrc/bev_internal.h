@@ -18,6 +18,10 @@ constexpr int kGatherThreads = 256;
 constexpr int kSlotsPerThread = 4;
 constexpr int kTile = kGatherThreads * kSlotsPerThread; /* slots per workgroup of the gather kernel */
 constexpr int kMaxTiles = 1024;   /* => at most 2^20 slots per frame (bev_create checks) */
+constexpr int kStripThreads = 256;              /* column-walk workgroup: 252 columns + 2 halo columns each side */
+constexpr int kStripCols = kStripThreads - 4;
+constexpr int kSeg = 256;                       /* capacity of one candidate segment = one (row, strip) */
+constexpr int kMaxSegs = 1024;                  /* (G + 1) * strips must not exceed this (bev_create checks) */
 constexpr int kSumWaves = 8;      /* waves of the per-frame cell-sum workgroup */
 constexpr int kSumThreads = kSumWaves * 64;
 constexpr int kRasterThreads = 1024;
@@ -45,7 +49,9 @@ static_assert(sizeof(bev_point_t) == 32, "bev_point_t must be 32 bytes");
 struct Geometry {
     int N, H, G;       /* N_SCAN, Horizon_SCAN, GROUND_UPPER_SCAN */
     int S;             /* N * H */
-    int tiles;         /* ceil(S / kTile) */
+    int tiles;         /* ceil(S / kTile): slot tiles of the per-slot kernels */
+    int strips;        /* ceil(H / kStripCols): column strips of the walk kernel */
+    int segs;          /* (G + 1) * strips: candidate segments per frame, row-major */
     bevx::RasterParams rp;
 };
 
@@ -56,8 +62,8 @@ struct BatchPtrs {
     uint32_t *winner;            /* [nf][S]  index+1 of the last input point per slot */
     bev_point_t *ordered;        /* [nf][S] */
     uint32_t *codes;             /* [nf][S] */
-    Candidate *cand;             /* [nf][tiles][kTile] */
-    uint32_t *ncand;             /* [nf][tiles] */
+    Candidate *cand;             /* [nf][segs][kSeg] */
+    uint32_t *ncand;             /* [nf][segs] */
     float *zsorted;              /* [nf][S] */
     float *avg;                  /* [nf][3750] */
     int8_t *gm;                  /* [nf][S] or nullptr: phase-A ground_mat */

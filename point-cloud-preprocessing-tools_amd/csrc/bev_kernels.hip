@@ -29,7 +29,7 @@ using namespace bevx;
 namespace bevk {
 
 static const char *const kNames[K_COUNT] = {
-    "k_order_scan", "k_gather_ground", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
+    "k_order_scan", "k_strip_ground", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
@@ -87,107 +87,167 @@ struct SlotFetch {
     }
 };
 
-/* kGatherThreads threads x kSlotsPerThread slots = one tile of kTile consecutive
- * slots.  Writes the ordered cloud (label already 0 for candidates, restored
- * later if phase C un-grounds them), each slot's BEV code, the tile's candidate
- * list IN SLOT ORDER and optionally the phase-A ground_mat.  The kSlotsPerThread
- * independent load chains per thread (winner -> point -> stencil neighbours) are
- * what keeps enough requests in flight to stream from HBM. */
+/* ------------------------------------------------------------------------- */
+/* getOrderedCloud gather + markGroundPoints phase A, as a COLUMN WALK.
+ *
+ * A workgroup owns kStripCols (252) adjacent columns of one frame plus two halo
+ * columns on each side (256 threads) and walks the rows 0 .. N-1.  Thread tid
+ * sits on virtual column v = strip*252 + tid - 2 and, in row r, on flat slot
+ * index r*H + v (v >= H wraps to v - H in the SAME row, v < 0 is the flat index
+ * r*H + v, i.e. the tail of row r-1 — exactly the two index rules of
+ * BatchMultiBevGen.cpp:146-154).  Consequences:
+ *   - every input point is loaded exactly once (winner -> point), rows arrive as
+ *     8 KiB coalesced pieces, the next row's loads are issued a row ahead;
+ *   - the phase-A stencil needs no second pass: "upper" is the thread's own
+ *     previous row (registers), its +-2 fallbacks are the neighbours' previous
+ *     rows (LDS), row-2 is the thread's own row before that;
+ *   - status s[r] is evaluated ONCE per slot; ground_mat(r-1) follows from
+ *     s[r-1] and s[r] (closed form in bev_exact.h), so row r-1 is finished while
+ *     row r is being evaluated, and row r-2 is written out (one barrier per row
+ *     covers both the LDS row buffer and the candidate counts).
+ * Candidates of one (row, strip) are compacted in column order into their own
+ * segment; segments enumerate (row, strip) in row-major order, so the
+ * concatenation of all segments is slot order — what phase B's accumulation
+ * order needs. */
+struct PendingRow {
+    Half lo, hi;
+    uint32_t code;
+    int status;      /* s[row] (kInvalid / kSteep / kGround); kSteep for rows that are not tested */
+    int gflag;       /* ground_mat(row) at the end of phase A */
+};
+
 template <bool kIdentity>
-__global__ __launch_bounds__(kGatherThreads) void k_gather_ground(BatchPtrs b, Geometry g, int nf)
+__global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geometry g)
 {
-    int f, tile;
-    if (!map_block_xcd(blockIdx.x, nf, g.tiles, f, tile)) return;
-    const int tid = threadIdx.x;
-    const size_t fbase = (size_t)f * g.S;
+    const int f = blockIdx.x / g.strips, strip = blockIdx.x - f * g.strips;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int N = g.N, H = g.H, lo_row = g.N - g.G;
+    const size_t frame_off = (size_t)f * g.S;
 
-    const bev_point_t *fpts = kIdentity ? (b.pts + fbase) : (b.pts + b.frames[f].in_offset);
-    SlotFetch<kIdentity> fetch{b.winner + fbase, fpts};
+    const int v = strip * kStripCols + tid - 2;                      /* virtual column */
+    const bool provider = (v < H + 2) && (v >= 0 || strip == 0);     /* has a point to load */
+    const bool outcol = tid >= 2 && tid < 2 + kStripCols && v < H;   /* owns column v's outputs */
+    const int vcol = v >= H ? v - H : v;                             /* wrap; v < 0 keeps the flat rule */
 
-    Half lo[kSlotsPerThread], hi[kSlotsPerThread];
-    int gflag[kSlotsPerThread];
-    uint32_t code[kSlotsPerThread];
-    bool live[kSlotsPerThread];
+    const bev_point_t *fpts = kIdentity ? (b.pts + frame_off) : (b.pts + b.frames[f].in_offset);
+    const uint32_t *fwin = b.winner + frame_off;
 
-    /* issue the self loads of all sub-slots first */
+    __shared__ float4 rowbuf[3][kStripThreads];            /* (x, y, z, intensity) of rows r, r-1, (r-2) */
+    __shared__ uint32_t wave_cnt[2][kStripThreads / 64];   /* per-wave candidate counts of the row being written */
+
+    auto load_winner = [&](int r) -> uint32_t {
+        if (!provider || r >= N) return 0u;
+        const int fl = r * H + vcol;
+        if (fl < 0) return 0u;
+        if (kIdentity) return (uint32_t)fl + 1u;
+        return fwin[fl];
+    };
+    auto load_point = [&](uint32_t w, Half &lo, Half &hi) {
+        lo = Half{{0, 0, 0, 0}};
+        hi = Half{{0, 0, 0, 0}};
+        if (w != 0u) {
+            const Half *src = reinterpret_cast<const Half *>(fpts + (w - 1u));
+            lo = src[0];
+            hi = src[1];
+        }
+    };
+
+    /* software pipeline: nxt = point of the row about to be processed, w_next = winner of the row after it */
+    Half cur_lo, cur_hi, nxt_lo, nxt_hi;
+    load_point(load_winner(0), nxt_lo, nxt_hi);
+    uint32_t w_next = load_winner(1);
+
+    XYZI prev{0.f, 0.f, 0.f, 0.f}, prevprev{0.f, 0.f, 0.f, 0.f};
+    PendingRow p1{}, p2{};              /* rows r-1 (ground flag still open) and r-2 (ready to write) */
+    unsigned long long m_ready = 0;     /* candidate ballot of row r-2 */
+
+    Candidate *fcand = b.cand + (size_t)f * g.segs * kSeg;
+    uint32_t *fncand = b.ncand + (size_t)f * g.segs;
+
+    /* two extra iterations drain the pipeline */
+    for (int r = 0; r < N + 2; ++r) {
+        cur_lo = nxt_lo;
+        cur_hi = nxt_hi;
+        load_point(r + 1 < N ? w_next : 0u, nxt_lo, nxt_hi); /* row r+1, in flight while row r is handled */
+        w_next = load_winner(r + 2);
+
+        const XYZI cur{__uint_as_float(cur_lo.w[0]), __uint_as_float(cur_lo.w[1]), __uint_as_float(cur_lo.w[2]),
+                       __uint_as_float(cur_hi.w[0])};
+        rowbuf[r % 3][tid] = make_float4(cur.x, cur.y, cur.z, cur.i);
+        if (lane == 0) wave_cnt[r & 1][wv] = (uint32_t)__popcll(m_ready);
+        __syncthreads();
+
+        /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
+        int s_r = kSteep;
+        if (outcol && r >= lo_row && r < N) {
+            const float4 *pr = rowbuf[(r + 2) % 3];                              /* row r-1 */
+            XYZI up = prev;                                                      /* (r-1, c)          :143     */
+            if (up.i == -1.0f) { const float4 q = pr[tid + 2]; up = XYZI{q.x, q.y, q.z, q.w}; } /* :146-149 */
+            if (up.i == -1.0f) { const float4 q = pr[tid - 2]; up = XYZI{q.x, q.y, q.z, q.w}; } /* :151-154 */
+            if (up.i == -1.0f && r >= 2) up = prevprev;                          /* (r-2, c)          :157-160 */
+            if (cur.i == -1.0f || up.i == -1.0f) s_r = kInvalid;                 /* :162-167 */
+            else s_r = angle_is_ground(up.x - cur.x, up.y - cur.y, up.z - cur.z) ? kGround : kSteep; /* :169-182 */
+        }
+
+        /* ---- ground_mat of row r-1 is now decided (closed form, see bev_exact.h) ---- */
+        {
+            const int q = r - 1;
+            int gf = 0;
+            if (q >= lo_row) gf = (p1.status == kInvalid) ? -1 : (p1.status == kGround ? 1 : (s_r == kGround ? 1 : 0));
+            else if (q == lo_row - 1) gf = (s_r == kGround) ? 1 : 0;
+            p1.gflag = (q >= 0 && q < N) ? gf : 0;
+        }
+        const unsigned long long m_new = __ballot(outcol && p1.gflag == 1);
+
+        /* ---- write out row r-2 (its per-wave counts were published before the barrier) ---- */
+        if (r >= 2) {
+            const int q = r - 2;
+            const bool is_cand = outcol && p2.gflag == 1;
+            const int rr = q - (lo_row - 1);        /* only rows lo-1 .. N-1 can hold candidates */
+            if (rr >= 0) {
+                uint32_t before = 0, total = 0;
 #pragma unroll
-    for (int k = 0; k < kSlotsPerThread; ++k) {
-        const int slot = tile * kTile + k * kGatherThreads + tid;
-        live[k] = slot < g.S;
-        lo[k] = Half{{0, 0, 0, 0}};
-        hi[k] = Half{{0, 0, 0, 0}};
-        if (live[k]) {
-            long long src = slot;
-            bool have = true;
-            if (!kIdentity) {
-                const uint32_t w = b.winner[fbase + slot];
-                have = (w != 0u);
-                src = (long long)w - 1;
+                for (int w = 0; w < kStripThreads / 64; ++w) {
+                    const uint32_t c = wave_cnt[r & 1][w];
+                    if (w < wv) before += c;
+                    total += c;
+                }
+                const size_t seg = (size_t)rr * g.strips + strip;
+                if (is_cand) {
+                    const uint32_t rank = before + (uint32_t)__popcll(m_ready & ((1ull << lane) - 1ull));
+                    Candidate c;
+                    c.slot = (uint32_t)(q * H + v);
+                    c.z = __uint_as_float(p2.lo.w[2]);
+                    c.code = p2.code;
+                    c.cell = (uint16_t)ground_cell(__uint_as_float(p2.lo.w[0]), __uint_as_float(p2.lo.w[1]));
+                    c.label = (int16_t)(p2.hi.w[3] & 0xffffu);
+                    fcand[seg * kSeg + rank] = c;
+                }
+                if (tid == 2) fncand[seg] = total;
             }
-            if (have) {
-                lo[k] = *reinterpret_cast<const Half *>(fpts + src);
-                hi[k] = *(reinterpret_cast<const Half *>(fpts + src) + 1);
+            if (outcol) {
+                Half hi = p2.hi;
+                if (is_cand) hi.w[3] &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
+                const size_t idx = frame_off + (size_t)(q * H + v);
+                Half *dst = reinterpret_cast<Half *>(b.ordered + idx);
+                dst[0] = p2.lo;
+                dst[1] = hi;
+                b.codes[idx] = is_cand ? kSkip : p2.code;
+                if (b.gm) b.gm[idx] = (int8_t)p2.gflag;
             }
         }
-    }
-#pragma unroll
-    for (int k = 0; k < kSlotsPerThread; ++k) {
-        const int slot = tile * kTile + k * kGatherThreads + tid;
-        gflag[k] = 0;
-        if (live[k]) {
-            const int row = slot / g.H, col = slot - row * g.H;
-            XYZI self{__uint_as_float(lo[k].w[0]), __uint_as_float(lo[k].w[1]), __uint_as_float(lo[k].w[2]),
-                      __uint_as_float(hi[k].w[0])};
-            gflag[k] = phase_a_ground(row, col, g.N, g.H, g.G, self, fetch);
-        }
-        code[k] = bev_code(__uint_as_float(lo[k].w[0]), __uint_as_float(lo[k].w[1]), __uint_as_float(lo[k].w[2]),
-                           (int)(int16_t)(hi[k].w[3] & 0xffffu), g.rp);
-    }
 
-    /* compact the tile's candidates in slot order = (k, tid) order */
-    constexpr int kWaves = kGatherThreads / 64;
-    __shared__ uint32_t wave_cnt[kSlotsPerThread][kWaves];
-    const int lane = tid & 63, wv = tid >> 6;
-    unsigned long long m[kSlotsPerThread];
-#pragma unroll
-    for (int k = 0; k < kSlotsPerThread; ++k) {
-        m[k] = __ballot(live[k] && gflag[k] == 1);
-        if (lane == 0) wave_cnt[k][wv] = (uint32_t)__popcll(m[k]);
+        /* ---- shift the pipeline ---- */
+        p2 = p1;
+        m_ready = m_new;
+        p1.lo = cur_lo;
+        p1.hi = cur_hi;
+        p1.status = s_r;
+        p1.gflag = 0;
+        p1.code = bev_code(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w[3] & 0xffffu), g.rp);
+        prevprev = prev;
+        prev = cur;
     }
-    __syncthreads();
-    uint32_t running = 0;
-    Candidate *tcand = b.cand + ((size_t)f * g.tiles + tile) * kTile;
-#pragma unroll
-    for (int k = 0; k < kSlotsPerThread; ++k) {
-        uint32_t before = running;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            const uint32_t c = wave_cnt[k][w];
-            if (w < wv) before += c;
-            running += c;
-        }
-        const bool is_cand = live[k] && gflag[k] == 1;
-        const int slot = tile * kTile + k * kGatherThreads + tid;
-        if (is_cand) {
-            const uint32_t rank = before + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull));
-            Candidate c;
-            c.slot = (uint32_t)slot;
-            c.z = __uint_as_float(lo[k].w[2]);
-            c.code = code[k];
-            c.cell = (uint16_t)ground_cell(__uint_as_float(lo[k].w[0]), __uint_as_float(lo[k].w[1]));
-            c.label = (int16_t)(hi[k].w[3] & 0xffffu);
-            tcand[rank] = c;
-            hi[k].w[3] &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
-        }
-        if (live[k]) {
-            Half *dst = reinterpret_cast<Half *>(b.ordered + fbase + slot);
-            dst[0] = lo[k];
-            dst[1] = hi[k];
-            b.codes[fbase + slot] = is_cand ? kSkip : code[k];
-            if (b.gm) b.gm[fbase + slot] = (int8_t)gflag[k];
-        }
-    }
-    if (tid == 0) b.ncand[(size_t)f * g.tiles + tile] = running;
 }
 
 /* getOrderedCloud alone (bev_order_cloud): no ground work. */
@@ -234,11 +294,11 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_only(BatchPtrs b, Geo
 constexpr int kCells = kGridCells;
 constexpr int kScanPerThread = (kCells + kSumThreads - 1) / kSumThreads; /* 8 */
 constexpr int kChunk = kSumWaves * kCells;  /* floats staged per pass-3 chunk (the dead hist region) */
-constexpr int kMaxTilesPerWave = kMaxTiles / kSumWaves + 1;
+constexpr int kMaxSegsPerWave = kMaxSegs / kSumWaves + 1;
 
 size_t cell_sums_lds_bytes()
 {
-    return sizeof(uint32_t) * ((size_t)kSumWaves * kCells + 2 * kCells + (size_t)kSumWaves * kMaxTilesPerWave + 16);
+    return sizeof(uint32_t) * ((size_t)kSumWaves * kCells + 2 * kCells + (size_t)kSumWaves * kMaxSegsPerWave + 16);
 }
 
 __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry g)
@@ -247,18 +307,18 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     uint32_t *hist = lds;                         /* [kSumWaves][kCells] */
     uint32_t *cell_start = hist + kSumWaves * kCells;
     uint32_t *cell_total = cell_start + kCells;
-    uint32_t *tile_cnt = cell_total + kCells;     /* [kSumWaves][kMaxTilesPerWave] */
-    uint32_t *wave_sum = tile_cnt + kSumWaves * kMaxTilesPerWave; /* [kSumWaves] */
+    uint32_t *tile_cnt = cell_total + kCells;     /* [kSumWaves][kMaxSegsPerWave] */
+    uint32_t *wave_sum = tile_cnt + kSumWaves * kMaxSegsPerWave; /* [kSumWaves] */
 
     const int f = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int T = g.tiles;
-    const Candidate *cand = b.cand + (size_t)f * T * kTile;
+    const int T = g.segs;
+    const Candidate *cand = b.cand + (size_t)f * T * kSeg;
     const uint32_t *ncand = b.ncand + (size_t)f * T;
     float *zs = b.zsorted + (size_t)f * g.S;
 
     const int t0 = (int)((long long)T * wv / kSumWaves), t1 = (int)((long long)T * (wv + 1) / kSumWaves);
-    uint32_t *mycnt = tile_cnt + wv * kMaxTilesPerWave;
+    uint32_t *mycnt = tile_cnt + wv * kMaxSegsPerWave;
     for (int t = t0 + lane; t < t1; t += 64) mycnt[t - t0] = ncand[t];
     for (int k = tid; k < kSumWaves * kCells; k += kSumThreads) hist[k] = 0u;
     __syncthreads();
@@ -268,7 +328,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     /* pass 1: order-free histogram of this wave's range */
     for (int t = t0; t < t1; ++t) {
         const int n = (int)mycnt[t - t0];
-        const Candidate *tc = cand + (size_t)t * kTile;
+        const Candidate *tc = cand + (size_t)t * kSeg;
         int i = lane;
         for (; i + 192 < n; i += 256) {
             const uint32_t c0 = tc[i].cell, c1 = tc[i + 64].cell, c2 = tc[i + 128].cell, c3 = tc[i + 192].cell;
@@ -334,7 +394,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
         Candidate cur{};
         if (t < t1) {
             valid = (i0 + lane) < n;
-            if (valid) cur = cand[(size_t)t * kTile + i0 + lane];
+            if (valid) cur = cand[(size_t)t * kSeg + i0 + lane];
         }
         while (t < t1) {
             /* locate and prefetch the next slice */
@@ -347,7 +407,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
             Candidate nxt{};
             if (nt < t1) {
                 nvalid = (ni0 + lane) < nn;
-                if (nvalid) nxt = cand[(size_t)nt * kTile + ni0 + lane];
+                if (nvalid) nxt = cand[(size_t)nt * kSeg + ni0 + lane];
             }
             /* rank the current slice: lanes holding the same cell find each other with
              * one ballot per key bit (12 bits cover 3750 cells) — constant work however
@@ -424,19 +484,18 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
 /* markGroundPoints phase C for the candidates, BatchMultiBevGen.cpp:216-250.
  * A candidate that is higher than a neighbour cell's average + 0.30 stops
  * being ground: its label is restored and it gets its BEV code back.        */
-__global__ __launch_bounds__(kGatherThreads) void k_ground_resolve(BatchPtrs b, Geometry g, int nf)
+__global__ __launch_bounds__(kSeg) void k_ground_resolve(BatchPtrs b, Geometry g)
 {
-    int f, tile;
-    if (!map_block_xcd(blockIdx.x, nf, g.tiles, f, tile)) return;
-    const uint32_t n = b.ncand[(size_t)f * g.tiles + tile];
+    /* one workgroup per candidate segment */
+    const int f = blockIdx.x / g.segs;
+    const uint32_t n = b.ncand[blockIdx.x];
+    if (threadIdx.x >= n) return;
+    const Candidate c = b.cand[(size_t)blockIdx.x * kSeg + threadIdx.x];
     const float *avg = b.avg + (size_t)f * kCells;
-    for (uint32_t i = threadIdx.x; i < n; i += kGatherThreads) {
-        const Candidate c = b.cand[((size_t)f * g.tiles + tile) * kTile + i];
-        if (above_neighbour_ground(c.z, (int)c.cell, avg)) {
-            const size_t idx = (size_t)f * g.S + c.slot;
-            reinterpret_cast<int16_t *>(b.ordered + idx)[14] = c.label; /* byte offset 28 */
-            b.codes[idx] = c.code;
-        }
+    if (above_neighbour_ground(c.z, (int)c.cell, avg)) {
+        const size_t idx = (size_t)f * g.S + c.slot;
+        reinterpret_cast<int16_t *>(b.ordered + idx)[14] = c.label; /* byte offset 28 */
+        b.codes[idx] = c.code;
     }
 }
 
@@ -572,11 +631,11 @@ void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t m
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st)
 {
     if (nf == 0) return;
-    const int grid = xcd_grid(nf, g.tiles);
+    const int grid = nf * g.strips;
     if (identity)
-        hipLaunchKernelGGL(k_gather_ground<true>, dim3(grid), dim3(kGatherThreads), 0, st, b, g, nf);
+        hipLaunchKernelGGL(k_strip_ground<true>, dim3(grid), dim3(kStripThreads), 0, st, b, g);
     else
-        hipLaunchKernelGGL(k_gather_ground<false>, dim3(grid), dim3(kGatherThreads), 0, st, b, g, nf);
+        hipLaunchKernelGGL(k_strip_ground<false>, dim3(grid), dim3(kStripThreads), 0, st, b, g);
 }
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {
@@ -591,7 +650,7 @@ void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_ground_resolve, dim3(xcd_grid(nf, g.tiles)), dim3(kGatherThreads), 0, st, b, g, nf);
+    hipLaunchKernelGGL(k_ground_resolve, dim3(nf * g.segs), dim3(kSeg), 0, st, b, g);
 }
 void launch_bev_raster(const Geometry &g, const uint32_t *codes, size_t code_stride, uint32_t n_codes,
                        uint8_t *multi, uint8_t *single, bool want_multi, bool want_single, int nf,
