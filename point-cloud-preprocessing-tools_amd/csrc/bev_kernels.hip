@@ -52,18 +52,30 @@ static inline int xcd_grid(int nf, int tiles) { return 8 * ((nf + 7) / 8) * tile
 /* ------------------------------------------------------------------------- */
 /* getOrderedCloud, BatchMultiBevGen.cpp:102-116: bounds test + slot index;
  * "last point in input order wins" == max input index per slot.            */
+constexpr int kScanPerThread = 4;
 __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restrict__ pts,
                                                     const FrameDesc *__restrict__ frames,
                                                     uint32_t *__restrict__ winner, int N, int H, int S)
 {
     const int f = blockIdx.y;
     const FrameDesc fd = frames[f];
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= fd.n_pts) return;
-    const uint32_t rc = reinterpret_cast<const uint32_t *>(pts + fd.in_offset + i)[5]; /* row | col << 16 */
-    const uint32_t row = rc & 0xffffu, col = rc >> 16;
-    if (row >= (uint32_t)N || col >= (uint32_t)H) return; /* :106-111 (the "< 0" tests are dead: u16) */
-    atomicMax(&winner[(size_t)f * S + row * H + col], i + 1u);
+    const uint32_t base = blockIdx.x * (256u * kScanPerThread) + threadIdx.x;
+    if (base >= fd.n_pts) return;
+    const bev_point_t *fp = pts + fd.in_offset;
+    uint32_t rc[kScanPerThread];
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) { /* all loads in flight before the first atomic */
+        const uint32_t i = base + 256u * k;
+        rc[k] = i < fd.n_pts ? reinterpret_cast<const uint32_t *>(fp + i)[5] : 0xffffffffu; /* row | col << 16 */
+    }
+    uint32_t *fw = winner + (size_t)f * S;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        const uint32_t i = base + 256u * k;
+        const uint32_t row = rc[k] & 0xffffu, col = rc[k] >> 16;
+        if (i < fd.n_pts && row < (uint32_t)N && col < (uint32_t)H) /* :106-111 (the "< 0" tests are dead: u16) */
+            atomicMax(&fw[row * H + col], i + 1u);
+    }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_only(BatchPtrs b, Geo
  *           from 0.01f) — the reference's accumulation order — then
  *           avg = sum / cnt.                                                  */
 constexpr int kCells = kGridCells;
-constexpr int kScanPerThread = (kCells + kSumThreads - 1) / kSumThreads; /* 8 */
+constexpr int kCellsPerThread = (kCells + kSumThreads - 1) / kSumThreads; /* 8 */
 constexpr int kChunk = kSumWaves * kCells;  /* floats staged per pass-3 chunk (the dead hist region) */
 constexpr int kMaxSegsPerWave = kMaxSegs / kSumWaves + 1;
 
@@ -354,13 +366,13 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     }
     __syncthreads();
 
-    /* exclusive scan of cell_total: thread owns kScanPerThread consecutive cells */
+    /* exclusive scan of cell_total: thread owns kCellsPerThread consecutive cells */
     {
-        const int c0 = tid * kScanPerThread;
-        uint32_t loc[kScanPerThread];
+        const int c0 = tid * kCellsPerThread;
+        uint32_t loc[kCellsPerThread];
         uint32_t s = 0;
 #pragma unroll
-        for (int k = 0; k < kScanPerThread; ++k) {
+        for (int k = 0; k < kCellsPerThread; ++k) {
             const int c = c0 + k;
             loc[k] = (c < kCells) ? cell_total[c] : 0u;
             s += loc[k];
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
         for (int w = 0; w < wv; ++w) base += wave_sum[w];
         uint32_t run = base + incl - s;
 #pragma unroll
-        for (int k = 0; k < kScanPerThread; ++k) {
+        for (int k = 0; k < kCellsPerThread; ++k) {
             const int c = c0 + k;
             if (c < kCells) cell_start[c] = run;
             run += loc[k];
@@ -436,9 +448,9 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     __syncthreads();
 
     /* pass 3: in-order float accumulation; thread owns cells tid + 512*j */
-    float sum[kScanPerThread], cnt[kScanPerThread];
+    float sum[kCellsPerThread], cnt[kCellsPerThread];
 #pragma unroll
-    for (int j = 0; j < kScanPerThread; ++j) {
+    for (int j = 0; j < kCellsPerThread; ++j) {
         sum[j] = 0.0f;   /* :133-134 */
         cnt[j] = 0.01f;  /* :135-136 */
     }
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
         for (int i = tid; i < cn; i += kSumThreads) zchunk[i] = zs[chunk0 + i];
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < kScanPerThread; ++j) {
+        for (int j = 0; j < kCellsPerThread; ++j) {
             const int c = tid + j * kSumThreads;
             if (c < kCells) {
                 const int st = (int)cell_start[c];
@@ -474,7 +486,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     }
     float *avg = b.avg + (size_t)f * kCells;
 #pragma unroll
-    for (int j = 0; j < kScanPerThread; ++j) {
+    for (int j = 0; j < kCellsPerThread; ++j) {
         const int c = tid + j * kSumThreads;
         if (c < kCells) avg[c] = sum[j] / cnt[j]; /* :210 */
     }
@@ -543,14 +555,18 @@ size_t raster_lds_bytes(const Geometry &g)
 
 __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(const uint32_t *__restrict__ codes, size_t code_stride,
                                                               uint32_t n_codes, uint8_t *__restrict__ multi,
-                                                              uint8_t *__restrict__ single, int M, int L)
+                                                              uint8_t *__restrict__ single, int M, int L, int nf)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int band_rows = M / kRasterSplit;
     const int cells = band_rows * M;
     uint32_t *mask = lds;
     uint32_t *hmax = lds + cells;
-    const int f = blockIdx.x / kRasterSplit, band = blockIdx.x % kRasterSplit;
+    /* the kRasterSplit bands of a frame read the same codes: give them to ONE XCD (blocks b and
+     * b+8 share an L2) and adjacent launch slots, so three of the four reads are L2 hits */
+    const int xl = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int f = (jj / kRasterSplit) * 8 + xl, band = jj % kRasterSplit;
+    if (f >= nf) return;
     const int x0 = band * band_rows;
     const int tid = threadIdx.x;
 
@@ -558,16 +574,26 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(const uint32_t *_
     __syncthreads();
 
     const uint32_t *fc = codes + (size_t)f * code_stride;
-    for (uint32_t i = tid; i < n_codes; i += kRasterThreads) {
-        const uint32_t c = fc[i];
-        if (c == kSkip) continue;
+    auto splat = [&](uint32_t c) {
+        if (c == kSkip) return;
         const int x = code_x(c) - x0;
-        if (x < 0 || x >= band_rows) continue;
+        if (x < 0 || x >= band_rows) return;
         const int idx = x * M + code_y(c);
         atomicMax(&hmax[idx], (uint32_t)code_h(c));      /* :353-355 */
         const uint32_t l = code_layer(c);
         if (l != kNoLayer) atomicOr(&mask[idx], 1u << l); /* :289-291 */
+    };
+    /* 8 coalesced loads in flight per thread before the first LDS atomic */
+    constexpr int kU = 8;
+    uint32_t i = tid;
+    for (; i + (kU - 1) * kRasterThreads < n_codes; i += kU * kRasterThreads) {
+        uint32_t c[kU];
+#pragma unroll
+        for (int k = 0; k < kU; ++k) c[k] = fc[i + k * kRasterThreads];
+#pragma unroll
+        for (int k = 0; k < kU; ++k) splat(c[k]);
     }
+    for (; i < n_codes; i += kRasterThreads) splat(fc[i]);
     __syncthreads();
 
     const int chunks_per_row = M / 16;
@@ -625,7 +651,8 @@ hipError_t configure_kernels(const Geometry &g)
 void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, hipStream_t st)
 {
     if (max_pts == 0 || nf == 0) return;
-    dim3 grid((max_pts + 255u) / 256u, (unsigned)nf);
+    const unsigned per_block = 256u * kScanPerThread;
+    dim3 grid((max_pts + per_block - 1u) / per_block, (unsigned)nf);
     hipLaunchKernelGGL(k_order_scan, grid, dim3(256), 0, st, b.pts, b.frames, b.winner, g.N, g.H, g.S);
 }
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st)
@@ -657,9 +684,9 @@ void launch_bev_raster(const Geometry &g, const uint32_t *codes, size_t code_str
                        hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_bev_raster, dim3(nf * kRasterSplit), dim3(kRasterThreads), raster_lds_bytes(g), st, codes,
-                       code_stride, n_codes, want_multi ? multi : nullptr, want_single ? single : nullptr,
-                       g.rp.mat_size, g.rp.n_layers);
+    hipLaunchKernelGGL(k_bev_raster, dim3(8 * ((nf + 7) / 8) * kRasterSplit), dim3(kRasterThreads), raster_lds_bytes(g),
+                       st, codes, code_stride, n_codes, want_multi ? multi : nullptr, want_single ? single : nullptr,
+                       g.rp.mat_size, g.rp.n_layers, nf);
 }
 void launch_ground_mat(const Geometry &g, const BatchPtrs &b, int8_t *out, int nf, hipStream_t st)
 {
