@@ -34,16 +34,14 @@ struct FrameDesc {
     uint32_t _pad;
 };
 
-/* A slot that phase A marked ground_mat == 1: the only slots whose label
- * depends on the per-cell averages (BatchMultiBevGen.cpp:244-246). 16 bytes. */
-struct Candidate {
-    uint32_t slot;   /* flat slot index inside the frame */
-    float z;
-    uint32_t code;   /* BEV code the point gets if phase C un-grounds it */
-    uint16_t cell;   /* getBelongingGrid cell, row * 50 + col */
-    int16_t label;   /* label the point came in with */
-};
-static_assert(sizeof(Candidate) == 16, "Candidate must be 16 bytes");
+/* A "candidate" is a slot that phase A marked ground_mat == 1: the only slots whose
+ * label depends on the per-cell averages (BatchMultiBevGen.cpp:244-246).  Stored as
+ * three parallel arrays per (row, strip) segment so that the per-cell sum kernel reads
+ * 2 (cell) resp. 6 (cell + z) bytes per candidate instead of a 16-byte record:
+ *   cand_cell u16 : getBelongingGrid cell, row * 50 + col
+ *   cand_z    f32 : the height that is summed
+ *   cand_aux  2xu32 : x = column offset inside the strip (8 bit) | original label << 8,
+ *                     y = BEV code the point gets back if phase C un-grounds it */
 static_assert(sizeof(bev_point_t) == 32, "bev_point_t must be 32 bytes");
 
 struct Geometry {
@@ -62,7 +60,9 @@ struct BatchPtrs {
     uint32_t *winner;            /* [nf][S]  index+1 of the last input point per slot */
     bev_point_t *ordered;        /* [nf][S] */
     uint32_t *codes;             /* [nf][S] */
-    Candidate *cand;             /* [nf][segs][kSeg] */
+    uint16_t *cand_cell;         /* [nf][segs][kSeg] */
+    float *cand_z;               /* [nf][segs][kSeg] */
+    uint2 *cand_aux;             /* [nf][segs][kSeg] */
     uint32_t *ncand;             /* [nf][segs] */
     float *zsorted;              /* [nf][S] */
     float *avg;                  /* [nf][3750] */

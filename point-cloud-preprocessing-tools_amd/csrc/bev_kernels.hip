@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     PendingRow p1{}, p2{};              /* rows r-1 (ground flag still open) and r-2 (ready to write) */
     unsigned long long m_ready = 0;     /* candidate ballot of row r-2 */
 
-    Candidate *fcand = b.cand + (size_t)f * g.segs * kSeg;
+    const size_t cand_base = (size_t)f * g.segs * kSeg;
     uint32_t *fncand = b.ncand + (size_t)f * g.segs;
 
     /* two extra iterations drain the pipeline */
@@ -227,13 +227,10 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
                 const size_t seg = (size_t)rr * g.strips + strip;
                 if (is_cand) {
                     const uint32_t rank = before + (uint32_t)__popcll(m_ready & ((1ull << lane) - 1ull));
-                    Candidate c;
-                    c.slot = (uint32_t)(q * H + v);
-                    c.z = __uint_as_float(p2.lo.w[2]);
-                    c.code = p2.code;
-                    c.cell = (uint16_t)ground_cell(__uint_as_float(p2.lo.w[0]), __uint_as_float(p2.lo.w[1]));
-                    c.label = (int16_t)(p2.hi.w[3] & 0xffffu);
-                    fcand[seg * kSeg + rank] = c;
+                    const size_t at = cand_base + seg * kSeg + rank;
+                    b.cand_cell[at] = (uint16_t)ground_cell(__uint_as_float(p2.lo.w[0]), __uint_as_float(p2.lo.w[1]));
+                    b.cand_z[at] = __uint_as_float(p2.lo.w[2]);
+                    b.cand_aux[at] = make_uint2((uint32_t)(tid - 2) | ((p2.hi.w[3] & 0xffffu) << 8), p2.code);
                 }
                 if (tid == 2) fncand[seg] = total;
             }
@@ -325,7 +322,8 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     const int f = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int T = g.segs;
-    const Candidate *cand = b.cand + (size_t)f * T * kSeg;
+    const uint16_t *ccell = b.cand_cell + (size_t)f * T * kSeg;
+    const float *cz = b.cand_z + (size_t)f * T * kSeg;
     const uint32_t *ncand = b.ncand + (size_t)f * T;
     float *zs = b.zsorted + (size_t)f * g.S;
 
@@ -337,19 +335,26 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
 
     uint32_t *myhist = hist + wv * kCells;
 
-    /* pass 1: order-free histogram of this wave's range */
-    for (int t = t0; t < t1; ++t) {
-        const int n = (int)mycnt[t - t0];
-        const Candidate *tc = cand + (size_t)t * kSeg;
-        int i = lane;
-        for (; i + 192 < n; i += 256) {
-            const uint32_t c0 = tc[i].cell, c1 = tc[i + 64].cell, c2 = tc[i + 128].cell, c3 = tc[i + 192].cell;
-            atomicAdd(&myhist[c0], 1u);
-            atomicAdd(&myhist[c1], 1u);
-            atomicAdd(&myhist[c2], 1u);
-            atomicAdd(&myhist[c3], 1u);
+    /* pass 1: order-free histogram of this wave's range; a segment holds at most kSeg = 4 x 64
+     * candidates, all four (predicated) loads of the NEXT segment are issued before the LDS
+     * atomics of the current one */
+    constexpr int kSl = kSeg / 64;
+    {
+        uint32_t cc[kSl], nc[kSl];
+        int n = (t0 < t1) ? (int)mycnt[0] : 0;
+#pragma unroll
+        for (int k = 0; k < kSl; ++k) cc[k] = (lane + 64 * k < n) ? (uint32_t)ccell[(size_t)t0 * kSeg + lane + 64 * k] : 0xffffu;
+        for (int t = t0; t < t1; ++t) {
+            const int nn = (t + 1 < t1) ? (int)mycnt[t + 1 - t0] : 0;
+#pragma unroll
+            for (int k = 0; k < kSl; ++k)
+                nc[k] = (lane + 64 * k < nn) ? (uint32_t)ccell[(size_t)(t + 1) * kSeg + lane + 64 * k] : 0xffffu;
+#pragma unroll
+            for (int k = 0; k < kSl; ++k)
+                if (cc[k] != 0xffffu) atomicAdd(&myhist[cc[k]], 1u);
+#pragma unroll
+            for (int k = 0; k < kSl; ++k) cc[k] = nc[k];
         }
-        for (; i < n; i += 64) atomicAdd(&myhist[tc[i].cell], 1u);
     }
     __syncthreads();
 
@@ -397,51 +402,53 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     }
     __syncthreads();
 
-    /* pass 2: stable placement, one 64-slice at a time, next slice prefetched */
+    /* pass 2: stable placement.  Segments are walked IN ORDER; the (cell, z) pairs of the next
+     * segment are in flight while the up to four 64-slices of the current one are ranked. */
     {
-        int t = t0, i0 = 0;
-        int n = (t < t1) ? (int)mycnt[0] : 0;
-        while (t < t1 && n == 0) { ++t; n = (t < t1) ? (int)mycnt[t - t0] : 0; }
-        bool valid = false;
-        Candidate cur{};
-        if (t < t1) {
-            valid = (i0 + lane) < n;
-            if (valid) cur = cand[(size_t)t * kSeg + i0 + lane];
-        }
-        while (t < t1) {
-            /* locate and prefetch the next slice */
-            int nt = t, ni0 = i0 + 64, nn = n;
-            if (ni0 >= nn) {
-                ni0 = 0;
-                do { ++nt; nn = (nt < t1) ? (int)mycnt[nt - t0] : 0; } while (nt < t1 && nn == 0);
-            }
-            bool nvalid = false;
-            Candidate nxt{};
-            if (nt < t1) {
-                nvalid = (ni0 + lane) < nn;
-                if (nvalid) nxt = cand[(size_t)nt * kSeg + ni0 + lane];
-            }
-            /* rank the current slice: lanes holding the same cell find each other with
-             * one ballot per key bit (12 bits cover 3750 cells) — constant work however
-             * many distinct cells the 64 candidates have */
-            const uint32_t cell = valid ? (uint32_t)cur.cell : 0xfffu; /* 4095 is not a cell */
-            unsigned long long peers = __ballot(valid);
+        uint32_t cc[kSl], nc[kSl];
+        float zz[kSl], nz[kSl];
+        int n = (t0 < t1) ? (int)mycnt[0] : 0;
 #pragma unroll
-            for (int bit = 0; bit < 12; ++bit) {
-                const bool one = (cell >> bit) & 1u;
-                const unsigned long long bal = __ballot(one);
-                peers &= one ? bal : ~bal;
+        for (int k = 0; k < kSl; ++k) {
+            const bool ok = lane + 64 * k < n;
+            cc[k] = ok ? (uint32_t)ccell[(size_t)t0 * kSeg + lane + 64 * k] : 0xfffu;
+            zz[k] = ok ? cz[(size_t)t0 * kSeg + lane + 64 * k] : 0.f;
+        }
+        for (int t = t0; t < t1; ++t) {
+            const int nn = (t + 1 < t1) ? (int)mycnt[t + 1 - t0] : 0;
+#pragma unroll
+            for (int k = 0; k < kSl; ++k) {
+                const bool ok = lane + 64 * k < nn;
+                nc[k] = ok ? (uint32_t)ccell[(size_t)(t + 1) * kSeg + lane + 64 * k] : 0xfffu;
+                nz[k] = ok ? cz[(size_t)(t + 1) * kSeg + lane + 64 * k] : 0.f;
             }
-            uint32_t pos = 0;
-            if (valid) {
-                const uint32_t below = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
-                pos = cell_start[cell] + myhist[cell] + below;
+#pragma unroll
+            for (int k = 0; k < kSl; ++k) {
+                if (64 * k >= n) break; /* wave-uniform */
+                const bool valid = lane + 64 * k < n;
+                /* lanes holding the same cell find each other with one ballot per key bit (12 bits
+                 * cover 3750 cells; 0xfff is not a cell): constant work however many distinct cells
+                 * the 64 candidates have */
+                const uint32_t cell = cc[k];
+                unsigned long long peers = __ballot(valid);
+#pragma unroll
+                for (int bit = 0; bit < 12; ++bit) {
+                    const bool one = (cell >> bit) & 1u;
+                    const unsigned long long bal = __ballot(one);
+                    peers &= one ? bal : ~bal;
+                }
+                const unsigned long long lower = peers & ((1ull << lane) - 1ull);
+                if (valid) {
+                    const uint32_t pos = cell_start[cell] + myhist[cell] + (uint32_t)__popcll(lower);
+                    zs[pos] = zz[k];
+                }
+                /* the lowest lane of each peer group advances the wave's cursor for that cell; every
+                 * read above is issued before this write (same wave, program order) */
+                if (valid && lower == 0ull) myhist[cell] += (uint32_t)__popcll(peers);
             }
-            /* the lowest lane of each peer group advances the wave's cursor for that cell;
-             * every read above is issued before this write (same wave, program order) */
-            if (valid && (peers & ((1ull << lane) - 1ull)) == 0ull) myhist[cell] += (uint32_t)__popcll(peers);
-            if (valid) zs[pos] = cur.z;
-            t = nt; i0 = ni0; n = nn; valid = nvalid; cur = nxt;
+            n = nn;
+#pragma unroll
+            for (int k = 0; k < kSl; ++k) { cc[k] = nc[k]; zz[k] = nz[k]; }
         }
     }
     __threadfence_block();
@@ -498,16 +505,21 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
  * being ground: its label is restored and it gets its BEV code back.        */
 __global__ __launch_bounds__(kSeg) void k_ground_resolve(BatchPtrs b, Geometry g)
 {
-    /* one workgroup per candidate segment */
-    const int f = blockIdx.x / g.segs;
+    /* one workgroup per candidate segment = one (row, strip) of one frame */
+    const int f = blockIdx.x / g.segs, seg = blockIdx.x - f * g.segs;
     const uint32_t n = b.ncand[blockIdx.x];
     if (threadIdx.x >= n) return;
-    const Candidate c = b.cand[(size_t)blockIdx.x * kSeg + threadIdx.x];
+    const size_t at = (size_t)blockIdx.x * kSeg + threadIdx.x;
+    const float z = b.cand_z[at];
+    const int cell = (int)b.cand_cell[at];
     const float *avg = b.avg + (size_t)f * kCells;
-    if (above_neighbour_ground(c.z, (int)c.cell, avg)) {
-        const size_t idx = (size_t)f * g.S + c.slot;
-        reinterpret_cast<int16_t *>(b.ordered + idx)[14] = c.label; /* byte offset 28 */
-        b.codes[idx] = c.code;
+    if (above_neighbour_ground(z, cell, avg)) {
+        const uint2 aux = b.cand_aux[at];
+        const int rr = seg / g.strips, strip = seg - rr * g.strips;
+        const int row = rr + (g.N - g.G - 1), col = strip * kStripCols + (int)(aux.x & 0xffu);
+        const size_t idx = (size_t)f * g.S + (size_t)row * g.H + col;
+        reinterpret_cast<uint16_t *>(b.ordered + idx)[14] = (uint16_t)(aux.x >> 8); /* label, byte offset 28 */
+        b.codes[idx] = aux.y;
     }
 }
 
