@@ -11,7 +11,7 @@
  *                                     BEV code, candidate list               (getOrderedCloud + markGroundPoints phase A)
  *   cell_sums       per frame       : stable counting sort of candidates by
  *                                     2 m cell, then IN-ORDER float sums     (markGroundPoints phase B + divide)
- *   ground_resolve  per candidate   : 4-neighbour height test, label fix-up (markGroundPoints phase C)
+ *   ground_resolve  per frame row   : 4-neighbour height test, label fix-up (markGroundPoints phase C)
  *   bev_raster      per frame band  : LDS atomics, then coalesced 16 B stores
  *                                     of the 24 occupancy planes + max-height
  *                                     plane                                  (computeAndSave{Multi,Single}Bev rasters)
@@ -500,29 +500,45 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
 }
 
 /* ------------------------------------------------------------------------- */
-/* markGroundPoints phase C for the candidates, BatchMultiBevGen.cpp:216-250.
- * A candidate that is higher than a neighbour cell's average + 0.30 stops
- * being ground: its label is restored and it gets its BEV code back.        */
+/* markGroundPoints phase C for the candidates, BatchMultiBevGen.cpp:216-250.  A candidate that is
+ * higher than a neighbour cell's average + 0.30 stops being ground: its label is restored and it
+ * gets its BEV code back.  One workgroup per (frame, candidate row): all strips' loads are issued
+ * before the first test, so a thread has up to 2 * kMaxResolveStrips loads in flight. */
+constexpr int kMaxResolveStrips = 12;
 __global__ __launch_bounds__(kSeg) void k_ground_resolve(BatchPtrs b, Geometry g)
 {
-    /* one workgroup per candidate segment = one (row, strip) of one frame */
-    const int f = blockIdx.x / g.segs, seg = blockIdx.x - f * g.segs;
-    const uint32_t n = b.ncand[blockIdx.x];
-    if (threadIdx.x >= n) return;
-    const size_t at = (size_t)blockIdx.x * kSeg + threadIdx.x;
-    const float z = b.cand_z[at];
-    const int cell = (int)b.cand_cell[at];
+    const int rows = g.G + 1;
+    const int f = blockIdx.x / rows, rr = blockIdx.x - f * rows;
+    const int tid = threadIdx.x;
     const float *avg = b.avg + (size_t)f * kCells;
-    if (above_neighbour_ground(z, cell, avg)) {
-        const uint2 aux = b.cand_aux[at];
-        const int rr = seg / g.strips, strip = seg - rr * g.strips;
-        const int row = rr + (g.N - g.G - 1), col = strip * kStripCols + (int)(aux.x & 0xffu);
-        const size_t idx = (size_t)f * g.S + (size_t)row * g.H + col;
-        reinterpret_cast<uint16_t *>(b.ordered + idx)[14] = (uint16_t)(aux.x >> 8); /* label, byte offset 28 */
-        b.codes[idx] = aux.y;
+    const size_t seg0 = (size_t)f * g.segs + (size_t)rr * g.strips;
+    const size_t row_off = (size_t)f * g.S + (size_t)(rr + g.N - g.G - 1) * g.H;
+    for (int s0 = 0; s0 < g.strips; s0 += kMaxResolveStrips) {
+        uint32_t cell[kMaxResolveStrips];
+        float z[kMaxResolveStrips];
+        bool ok[kMaxResolveStrips];
+#pragma unroll
+        for (int k = 0; k < kMaxResolveStrips; ++k) {
+            const int st = s0 + k;
+            ok[k] = st < g.strips && (uint32_t)tid < b.ncand[seg0 + (st < g.strips ? st : 0)];
+            const size_t at = (seg0 + st) * kSeg + tid;
+            cell[k] = ok[k] ? (uint32_t)b.cand_cell[at] : 0u;
+            z[k] = ok[k] ? b.cand_z[at] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < kMaxResolveStrips; ++k) {
+            if (ok[k] && above_neighbour_ground(z[k], (int)cell[k], avg)) {
+                const int st = s0 + k;
+                const uint2 aux = b.cand_aux[(seg0 + st) * kSeg + tid];
+                const size_t idx = row_off + st * kStripCols + (int)(aux.x & 0xffu);
+                reinterpret_cast<uint16_t *>(b.ordered + idx)[14] = (uint16_t)(aux.x >> 8); /* label @28 */
+                b.codes[idx] = aux.y;
+            }
+        }
     }
 }
 
+/* ------------------------------------------------------------------------- */
 /* Final cv::Mat ground_mat (optional output): phase C writes 0 wherever the
  * neighbour test fires, for EVERY slot (:236-240). */
 __global__ __launch_bounds__(kGatherThreads) void k_ground_mat(BatchPtrs b, Geometry g, int8_t *out, int nf)
@@ -689,7 +705,7 @@ void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_ground_resolve, dim3(nf * g.segs), dim3(kSeg), 0, st, b, g);
+    hipLaunchKernelGGL(k_ground_resolve, dim3(nf * (g.G + 1)), dim3(kSeg), 0, st, b, g);
 }
 void launch_bev_raster(const Geometry &g, const uint32_t *codes, size_t code_stride, uint32_t n_codes,
                        uint8_t *multi, uint8_t *single, bool want_multi, bool want_single, int nf,

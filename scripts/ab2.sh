@@ -1,0 +1,6 @@
+for sb in 199 227 256 398; do for lanes in 2; do
+BEV_LANES=$lanes timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu --sub-batch $sb 2>/dev/null | tail -1 > /tmp/b.json; python - <<PY
+import json
+d=json.loads(open("/tmp/b.json").read()); print("lanes $lanes sb", d["config"]["sub_batch"], round(d["value"]), [(k["name"][2:8], round(k["avg_launch_ms"]*1e3/ (1000/ (k["launches"]/5)),2)) for k in d["kernels"]])
+PY
+done; done
