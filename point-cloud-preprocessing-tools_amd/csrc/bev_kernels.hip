@@ -502,37 +502,43 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
 /* ------------------------------------------------------------------------- */
 /* markGroundPoints phase C for the candidates, BatchMultiBevGen.cpp:216-250.  A candidate that is
  * higher than a neighbour cell's average + 0.30 stops being ground: its label is restored and it
- * gets its BEV code back.  One workgroup per (frame, candidate row): all strips' loads are issued
- * before the first test, so a thread has up to 2 * kMaxResolveStrips loads in flight. */
+ * gets its BEV code back.  kResolveGroups workgroups per frame, each stages the frame's averages in
+ * LDS once and takes every 8th candidate row; all strips' loads of a row are issued before the
+ * first test, so a thread has up to 2 * kMaxResolveStrips loads in flight. */
 constexpr int kMaxResolveStrips = 12;
+constexpr int kResolveGroups = 8; /* workgroups per frame; each takes every 8th candidate row */
 __global__ __launch_bounds__(kSeg) void k_ground_resolve(BatchPtrs b, Geometry g)
 {
+    __shared__ float avg[kCells]; /* the frame's 75 x 50 averages: 4 look-ups per candidate */
     const int rows = g.G + 1;
-    const int f = blockIdx.x / rows, rr = blockIdx.x - f * rows;
+    const int f = blockIdx.x / kResolveGroups, grp = blockIdx.x - f * kResolveGroups;
     const int tid = threadIdx.x;
-    const float *avg = b.avg + (size_t)f * kCells;
-    const size_t seg0 = (size_t)f * g.segs + (size_t)rr * g.strips;
-    const size_t row_off = (size_t)f * g.S + (size_t)(rr + g.N - g.G - 1) * g.H;
-    for (int s0 = 0; s0 < g.strips; s0 += kMaxResolveStrips) {
-        uint32_t cell[kMaxResolveStrips];
-        float z[kMaxResolveStrips];
-        bool ok[kMaxResolveStrips];
+    for (int c = tid; c < kCells; c += kSeg) avg[c] = b.avg[(size_t)f * kCells + c];
+    __syncthreads();
+    for (int rr = grp; rr < rows; rr += kResolveGroups) {
+        const size_t seg0 = (size_t)f * g.segs + (size_t)rr * g.strips;
+        const size_t row_off = (size_t)f * g.S + (size_t)(rr + g.N - g.G - 1) * g.H;
+        for (int s0 = 0; s0 < g.strips; s0 += kMaxResolveStrips) {
+            uint32_t cell[kMaxResolveStrips];
+            float z[kMaxResolveStrips];
+            bool ok[kMaxResolveStrips];
 #pragma unroll
-        for (int k = 0; k < kMaxResolveStrips; ++k) {
-            const int st = s0 + k;
-            ok[k] = st < g.strips && (uint32_t)tid < b.ncand[seg0 + (st < g.strips ? st : 0)];
-            const size_t at = (seg0 + st) * kSeg + tid;
-            cell[k] = ok[k] ? (uint32_t)b.cand_cell[at] : 0u;
-            z[k] = ok[k] ? b.cand_z[at] : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < kMaxResolveStrips; ++k) {
-            if (ok[k] && above_neighbour_ground(z[k], (int)cell[k], avg)) {
+            for (int k = 0; k < kMaxResolveStrips; ++k) { /* every strip's loads issued before the first test */
                 const int st = s0 + k;
-                const uint2 aux = b.cand_aux[(seg0 + st) * kSeg + tid];
-                const size_t idx = row_off + st * kStripCols + (int)(aux.x & 0xffu);
-                reinterpret_cast<uint16_t *>(b.ordered + idx)[14] = (uint16_t)(aux.x >> 8); /* label @28 */
-                b.codes[idx] = aux.y;
+                ok[k] = st < g.strips && (uint32_t)tid < b.ncand[seg0 + (st < g.strips ? st : 0)];
+                const size_t at = (seg0 + st) * kSeg + tid;
+                cell[k] = ok[k] ? (uint32_t)b.cand_cell[at] : 0u;
+                z[k] = ok[k] ? b.cand_z[at] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < kMaxResolveStrips; ++k) {
+                if (ok[k] && above_neighbour_ground(z[k], (int)cell[k], avg)) {
+                    const int st = s0 + k;
+                    const uint2 aux = b.cand_aux[(seg0 + st) * kSeg + tid];
+                    const size_t idx = row_off + st * kStripCols + (int)(aux.x & 0xffu);
+                    reinterpret_cast<uint16_t *>(b.ordered + idx)[14] = (uint16_t)(aux.x >> 8); /* label @28 */
+                    b.codes[idx] = aux.y;
+                }
             }
         }
     }
@@ -705,7 +711,7 @@ void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_ground_resolve, dim3(nf * (g.G + 1)), dim3(kSeg), 0, st, b, g);
+    hipLaunchKernelGGL(k_ground_resolve, dim3(nf * kResolveGroups), dim3(kSeg), 0, st, b, g);
 }
 void launch_bev_raster(const Geometry &g, const uint32_t *codes, size_t code_stride, uint32_t n_codes,
                        uint8_t *multi, uint8_t *single, bool want_multi, bool want_single, int nf,
