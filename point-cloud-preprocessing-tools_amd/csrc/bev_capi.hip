@@ -220,7 +220,7 @@ int ensure_gm(bev_ctx *c)
 /* The whole pipeline on device pointers.  `identity`: d_pts already holds
  * ordered clouds (n_frames * S points) and the order stage is skipped.       */
 int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint64_t *h_offsets, bool identity,
-                 bev_point_t *d_ordered, uint8_t *d_multi, uint8_t *d_single, int8_t *d_gm)
+                 bev_point_t *d_ordered, uint8_t *d_multi, uint8_t *d_single, int8_t *d_gm, bool fork = true)
 {
     if (n_frames == 0) return BEV_OK;
     const Geometry &g = c->geo;
@@ -251,11 +251,17 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         HIPCK(c, hipStreamWaitEvent(c->stream, c->desc_copied[ds], 0));
     }
 
-    /* fork: every lane starts after whatever the caller already queued on the main stream */
+    /* fork: every lane starts after whatever the caller already queued on the main stream (the staged
+     * host->device copies of the host-buffer entry points).  The device-resident entry point has nothing
+     * on the main stream to wait for, so its lanes free-run from call to call and stay staggered. */
     const int n_sub = (n_frames + c->max_batch - 1) / c->max_batch;
     const int lanes_used = std::min(c->n_lanes, n_sub);
-    HIPCK(c, hipEventRecord(c->fork_ev, c->stream));
-    for (int l = 0; l < lanes_used; ++l) HIPCK(c, hipStreamWaitEvent(c->lanes[l].st, c->fork_ev, 0));
+    if (fork) {
+        HIPCK(c, hipEventRecord(c->fork_ev, c->stream));
+        for (int l = 0; l < lanes_used; ++l) HIPCK(c, hipStreamWaitEvent(c->lanes[l].st, c->fork_ev, 0));
+    } else if (!identity) {
+        for (int l = 0; l < lanes_used; ++l) HIPCK(c, hipStreamWaitEvent(c->lanes[l].st, c->desc_copied[ds], 0));
+    }
 
     int sub = 0;
     for (int f0 = 0; f0 < n_frames; f0 += c->max_batch, ++sub) {
@@ -525,7 +531,8 @@ int bev_process_device_resident(bev_ctx_t *c, int n_frames, const bev_point_t *d
 {
     if (!c || n_frames < 0 || !h_offsets || !d_ordered) return BEV_ERR_INVALID_ARG;
     if (n_frames > 0 && !d_pts && h_offsets[n_frames] != h_offsets[0]) return BEV_ERR_INVALID_ARG;
-    return run_pipeline(c, n_frames, d_pts, h_offsets, false, d_ordered, d_multi, d_single, d_ground_mat);
+    return run_pipeline(c, n_frames, d_pts, h_offsets, false, d_ordered, d_multi, d_single, d_ground_mat,
+                        /*fork=*/false);
 }
 
 int bev_process_batch(bev_ctx_t *c, int n_frames, const bev_point_t *const *pts, const uint32_t *n_pts,

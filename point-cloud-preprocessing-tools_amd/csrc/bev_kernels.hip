@@ -112,7 +112,8 @@ struct SlotFetch {
  *     8 KiB coalesced pieces, the next row's loads are issued a row ahead;
  *   - the phase-A stencil needs no second pass: "upper" is the thread's own
  *     previous row (registers), its +-2 fallbacks are the neighbours' previous
- *     rows (LDS), row-2 is the thread's own row before that;
+ *     rows (wave shuffles, LDS only across wave edges), row-2 is the thread's
+ *     own row before that;
  *   - status s[r] is evaluated ONCE per slot; ground_mat(r-1) follows from
  *     s[r-1] and s[r] (closed form in bev_exact.h), so row r-1 is finished while
  *     row r is being evaluated, and row r-2 is written out (one barrier per row
@@ -144,8 +145,12 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     const bev_point_t *fpts = kIdentity ? (b.pts + frame_off) : (b.pts + b.frames[f].in_offset);
     const uint32_t *fwin = b.winner + frame_off;
 
-    __shared__ float4 rowbuf[3][kStripThreads];            /* (x, y, z, intensity) of rows r, r-1, (r-2) */
-    __shared__ uint32_t wave_cnt[2][kStripThreads / 64];   /* per-wave candidate counts of the row being written */
+    /* Neighbour exchange: lanes l+-2 of the same wave are reached with shuffles; only the two edge
+     * lanes on each side of a wave go through LDS (768 B instead of a 12 KiB row buffer, so that these
+     * workgroups can share a CU with the 151 KiB cell-sum and 98 KiB raster workgroups of the other lane). */
+    constexpr int kWaves = kStripThreads / 64;
+    __shared__ float4 edge[3][kWaves][4];                  /* rows r, r-1, (r-2): lanes 0, 1, 62, 63 of every wave */
+    __shared__ uint32_t wave_cnt[2][kWaves];               /* per-wave candidate counts of the row being written */
 
     auto load_winner = [&](int r) -> uint32_t {
         if (!provider || r >= N) return 0u;
@@ -185,20 +190,27 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
 
         const XYZI cur{__uint_as_float(cur_lo.w[0]), __uint_as_float(cur_lo.w[1]), __uint_as_float(cur_lo.w[2]),
                        __uint_as_float(cur_hi.w[0])};
-        rowbuf[r % 3][tid] = make_float4(cur.x, cur.y, cur.z, cur.i);
+        if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
         if (lane == 0) wave_cnt[r & 1][wv] = (uint32_t)__popcll(m_ready);
         __syncthreads();
 
         /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
         int s_r = kSteep;
-        if (outcol && r >= lo_row && r < N) {
-            const float4 *pr = rowbuf[(r + 2) % 3];                              /* row r-1 */
-            XYZI up = prev;                                                      /* (r-1, c)          :143     */
-            if (up.i == -1.0f) { const float4 q = pr[tid + 2]; up = XYZI{q.x, q.y, q.z, q.w}; } /* :146-149 */
-            if (up.i == -1.0f) { const float4 q = pr[tid - 2]; up = XYZI{q.x, q.y, q.z, q.w}; } /* :151-154 */
-            if (up.i == -1.0f && r >= 2) up = prevprev;                          /* (r-2, c)          :157-160 */
-            if (cur.i == -1.0f || up.i == -1.0f) s_r = kInvalid;                 /* :162-167 */
-            else s_r = angle_is_ground(up.x - cur.x, up.y - cur.y, up.z - cur.z) ? kGround : kSteep; /* :169-182 */
+        if (r >= lo_row && r < N) { /* workgroup-uniform */
+            /* row r-1 of the threads two to the right / left */
+            XYZI right{__shfl(prev.x, lane + 2), __shfl(prev.y, lane + 2), __shfl(prev.z, lane + 2), __shfl(prev.i, lane + 2)};
+            XYZI left{__shfl(prev.x, lane - 2), __shfl(prev.y, lane - 2), __shfl(prev.z, lane - 2), __shfl(prev.i, lane - 2)};
+            const float4(*pe)[4] = edge[(r + 2) % 3];
+            if (lane >= 62 && wv + 1 < kWaves) { const float4 q = pe[wv + 1][lane - 62]; right = XYZI{q.x, q.y, q.z, q.w}; }
+            if (lane < 2 && wv > 0) { const float4 q = pe[wv - 1][lane + 2]; left = XYZI{q.x, q.y, q.z, q.w}; }
+            if (outcol) {
+                XYZI up = prev;                                  /* (r-1, c)                  :143     */
+                if (up.i == -1.0f) up = right;                   /* (r-1, (c+2) % H)          :146-149 */
+                if (up.i == -1.0f) up = left;                    /* flat (r-1)*H + c - 2      :151-154 */
+                if (up.i == -1.0f && r >= 2) up = prevprev;      /* (r-2, c)                  :157-160 */
+                if (cur.i == -1.0f || up.i == -1.0f) s_r = kInvalid; /* :162-167 */
+                else s_r = angle_is_ground(up.x - cur.x, up.y - cur.y, up.z - cur.z) ? kGround : kSteep; /* :169-182 */
+            }
         }
 
         /* ---- ground_mat of row r-1 is now decided (closed form, see bev_exact.h) ---- */
