@@ -159,6 +159,16 @@ int bev_multi_bev(bev_ctx_t *ctx, const bev_point_t *cloud, uint32_t n,
 int bev_single_bev(bev_ctx_t *ctx, const bev_point_t *cloud, uint32_t n,
                    uint8_t *single_out);
 
+/* Float max-height BEV of the older tools: saveAsMat of batch_cloud_manip
+ * (BatchCloudManip.cpp:201-225, skip_label0 = 1) and cloud_manip
+ * (CloudManip.cpp:79-99, skip_label0 = 0): grid M x M, M = 200/interval + 1,
+ * cell = max(0, max over points of z + 2.0f), float32.  out: M*M floats,
+ * row index = x.  interval must give M <= 1024.  Bit-exact (a max has no
+ * rounding), i.e. well inside the 1e-5 the float height channel is allowed. */
+int bev_float_bev(bev_ctx_t *ctx, const bev_point_t *cloud, uint32_t n, float interval,
+                  int skip_label0, float *out);
+size_t bev_float_bev_size(float interval); /* M for a given interval (0 if unsupported) */
+
 /* ---- measurement ------------------------------------------------------- */
 #define BEV_MAX_KERNELS 16
 typedef struct bev_kernel_stat {

@@ -72,6 +72,7 @@ ABI_SYMBOLS = [
     "bev_create", "bev_destroy", "bev_strerror", "bev_last_error",
     "bev_process_batch", "bev_process_device_resident", "bev_synchronize",
     "bev_order_cloud", "bev_mark_ground", "bev_multi_bev", "bev_single_bev",
+    "bev_float_bev", "bev_float_bev_size",
     "bev_profile_enable", "bev_profile_reset", "bev_profile_get",
     "bev_debug_get_cell_avg", "bev_debug_angle_predicate", "bev_abi_version",
 ]
@@ -121,6 +122,9 @@ def load_lib() -> C.CDLL:
     lib.bev_mark_ground.argtypes = [vp, vp, vp]
     lib.bev_multi_bev.argtypes = [vp, vp, u32, vp]
     lib.bev_single_bev.argtypes = [vp, vp, u32, vp]
+    lib.bev_float_bev.argtypes = [vp, vp, u32, C.c_float, i32, vp]
+    lib.bev_float_bev_size.argtypes = [C.c_float]
+    lib.bev_float_bev_size.restype = sz
     lib.bev_profile_enable.argtypes = [vp, i32]
     lib.bev_profile_reset.argtypes = [vp]
     lib.bev_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32]
@@ -234,6 +238,14 @@ class BevContext:
         out = np.empty((self.M, self.M), dtype=np.uint8)
         self._check(self.lib.bev_single_bev(self._h, _ptr(cloud) if len(cloud) else None, len(cloud), _ptr(out)),
                     "bev_single_bev")
+        return out
+
+    def float_bev(self, cloud, interval=1.0, skip_label0=True):
+        cloud = np.ascontiguousarray(cloud, dtype=POINT_DTYPE)
+        M = int(self.lib.bev_float_bev_size(interval))
+        out = np.empty((M, M), dtype=np.float32)
+        self._check(self.lib.bev_float_bev(self._h, _ptr(cloud) if len(cloud) else None, len(cloud), interval,
+                                           1 if skip_label0 else 0, _ptr(out)), "bev_float_bev")
         return out
 
     # ---- measurement / test hooks ------------------------------------------

@@ -673,6 +673,37 @@ int bev_single_bev(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, uint8_t *
     return raster_cloud(c, cloud, n, nullptr, single_out);
 }
 
+size_t bev_float_bev_size(float interval)
+{
+    if (!(interval > 0.0f)) return 0;
+    /* static int MAT_SIZE = MAX_RANGE*2 / interval + 1;  BatchCloudManip.cpp:210 */
+    const int M = bevx::cvtt_f32((float)200 / interval + 1);
+    return (M >= 1 && M <= 1024) ? (size_t)M : 0;
+}
+
+int bev_float_bev(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, float interval, int skip_label0, float *out)
+{
+    if (!c || !out || (n && !cloud)) return BEV_ERR_INVALID_ARG;
+    const size_t M = bev_float_bev_size(interval);
+    if (M == 0) return BEV_ERR_UNSUPPORTED;
+    if ((size_t)n > std::max(c->max_points, (size_t)c->geo.S)) return BEV_ERR_TOO_LARGE;
+    if (M * M > c->codes_elems) return BEV_ERR_UNSUPPORTED; /* the grid borrows lane 0's code buffer */
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c);
+    if (rc != BEV_OK) return rc;
+    float *grid = reinterpret_cast<float *>(c->codes);
+    if (n) HIPCK(c, hipMemcpyAsync(c->st_in, cloud, (size_t)n * sizeof(bev_point_t), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemsetAsync(grid, 0, M * M * sizeof(float), c->stream));
+    {
+        ProfScope ps(c, K_FLOAT_BEV, 1);
+        launch_float_bev(c->st_in, n, interval, (int)M, skip_label0 != 0, grid, c->stream);
+    }
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(out, grid, M * M * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BEV_OK;
+}
+
 int bev_profile_enable(bev_ctx_t *c, int on)
 {
     if (!c) return BEV_ERR_INVALID_ARG;

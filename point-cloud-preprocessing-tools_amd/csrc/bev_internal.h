@@ -81,6 +81,7 @@ enum KernelId {
     K_GROUND_MAT,
     K_CLOUD_CODES,
     K_ANGLE_DEBUG,
+    K_FLOAT_BEV,
     K_COUNT
 };
 const char *kernel_name(int id);
@@ -96,6 +97,8 @@ void launch_bev_raster(const Geometry &g, const uint32_t *codes, size_t code_str
                        int nf, hipStream_t st);
 void launch_ground_mat(const Geometry &g, const BatchPtrs &b, int8_t *out, int nf, hipStream_t st);
 void launch_cloud_codes(const Geometry &g, const bev_point_t *cloud, uint32_t n, uint32_t *codes, hipStream_t st);
+void launch_float_bev(const bev_point_t *cloud, uint32_t n, float interval, int M, bool skip_label0, float *grid,
+                      hipStream_t st);
 void launch_angle_debug(const float *dx, const float *dy, const float *dz, uint8_t *out, size_t n, hipStream_t st);
 /* opt in to > 64 KiB of dynamic LDS for the two kernels that need it */
 hipError_t configure_kernels(const Geometry &g);

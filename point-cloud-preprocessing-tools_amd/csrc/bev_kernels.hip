@@ -30,7 +30,7 @@ namespace bevk {
 
 static const char *const kNames[K_COUNT] = {
     "k_order_scan", "k_strip_ground", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
-    "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug",
+    "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
 
@@ -676,6 +676,24 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(const uint32_t *_
     }
 }
 
+/* saveAsMat of batch_cloud_manip / cloud_manip (BatchCloudManip.cpp:213-225, CloudManip.cpp:84-95):
+ * float32 max of z + 2.0f per cell over a grid initialised to 0.  A stored value is always > 0, and
+ * positive IEEE floats order like their bit patterns, so the max is an integer atomicMax. */
+__global__ __launch_bounds__(256) void k_float_bev(const bev_point_t *__restrict__ cloud, uint32_t n, float interval,
+                                                   int M, int skip_label0, uint32_t *__restrict__ grid)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = *reinterpret_cast<const float4 *>(cloud + i);
+    const int label = (int)reinterpret_cast<const int16_t *>(cloud + i)[14];
+    const int x = bev_bin(a.x, 100.0f, interval); /* MAX_RANGE = 100, :209 / :81 */
+    const int y = bev_bin(a.y, 100.0f, interval);
+    if (x < 0 || x >= M || y < 0 || y >= M) return;
+    if (skip_label0 && label == 0) return;         /* :218 (batch variant only) */
+    const float h = a.z + 2.0f;                    /* :222 / :92 */
+    if (h > 0.0f) atomicMax(&grid[(size_t)x * M + y], __float_as_uint(h)); /* "h > cell" with cells >= 0 */
+}
+
 /* test hook: the phase-A angle predicate on raw difference vectors */
 __global__ __launch_bounds__(256) void k_angle_debug(const float *dx, const float *dy, const float *dz,
                                                      uint8_t *out, size_t n)
@@ -743,6 +761,13 @@ void launch_cloud_codes(const Geometry &g, const bev_point_t *cloud, uint32_t n,
 {
     if (n == 0) return;
     hipLaunchKernelGGL(k_cloud_codes, dim3((n + 255u) / 256u), dim3(256), 0, st, cloud, n, codes, g.rp);
+}
+void launch_float_bev(const bev_point_t *cloud, uint32_t n, float interval, int M, bool skip_label0, float *grid,
+                      hipStream_t st)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_float_bev, dim3((n + 255u) / 256u), dim3(256), 0, st, cloud, n, interval, M,
+                       skip_label0 ? 1 : 0, reinterpret_cast<uint32_t *>(grid));
 }
 void launch_angle_debug(const float *dx, const float *dy, const float *dz, uint8_t *out, size_t n, hipStream_t st)
 {

@@ -131,6 +131,7 @@ void write_single_outputs(const std::string &name, const uint8_t *single, bool w
 } // namespace
 
 void bevhost_recreate_dir(const std::string &dir) { recreate_dir(dir); }
+bev_ctx_t *bevhost_context() { return context(); }
 
 void setBevDevice(int device) { g_device = device; }
 void shutdownBev()

@@ -175,3 +175,19 @@ def test_device_resident_matches_host_entry(ctxs):
     assert d_ord.cpu().numpy().tobytes() == ordered.tobytes()
     assert d_multi.cpu().numpy().tobytes() == multi.tobytes()
     assert d_single.cpu().numpy().tobytes() == single.tobytes()
+
+
+# ---- float max-height BEV of batch_cloud_manip / cloud_manip ----
+@pytest.mark.parametrize("sensor", ["HDL_64E", "HDL_32E"])
+def test_float_bev(ctxs, sensor):
+    p, ctx = ctxs(sensor)
+    sp = orc.sensor_from_params(p)
+    marked, _, _ = orc.mark_ground(sp, orc.order_cloud(sp, synth.sweep(p, 21)))
+    for cloud in (marked, synth.adversarial(p, 40000, 17, True)):
+        for interval, skip in ((1.0, True), (1.0, False), (2.0, True), (0.5, False)):
+            got = ctx.float_bev(cloud, interval, skip)
+            want = orc.float_bev(cloud, interval, skip)
+            assert got.shape == want.shape
+            # north_star allows 1e-5 on float height channels; a max has no rounding, so demand equality
+            assert got.tobytes() == want.tobytes(), (interval, skip, np.abs(got - want).max())
+    assert ctx.float_bev(marked, 1.0, True).shape == (201, 201)
