@@ -31,6 +31,7 @@ namespace bevk {
 static const char *const kNames[K_COUNT] = {
     "k_order_scan", "k_strip_ground", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev",
+    "k_prefix_len", "k_prefix_bounds", "k_tail_zero", "k_tail_scan", "k_strip_ground_fast", "k_winner_zero_failed",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
 
@@ -55,9 +56,11 @@ static inline int xcd_grid(int nf, int tiles) { return 8 * ((nf + 7) / 8) * tile
 constexpr int kScanPerThread = 4;
 __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restrict__ pts,
                                                     const FrameDesc *__restrict__ frames,
-                                                    uint32_t *__restrict__ winner, int N, int H, int S)
+                                                    uint32_t *__restrict__ winner, int N, int H, int S,
+                                                    const uint32_t *__restrict__ only_failed)
 {
     const int f = blockIdx.y;
+    if (only_failed && only_failed[f] == 0u) return;
     const FrameDesc fd = frames[f];
     const uint32_t base = blockIdx.x * (256u * kScanPerThread) + threadIdx.x;
     if (base >= fd.n_pts) return;
@@ -100,6 +103,130 @@ struct SlotFetch {
 };
 
 /* ------------------------------------------------------------------------- */
+/* SORTED-PREFIX FAST PATH.
+ *
+ * The general path reads the input twice: k_order_scan (all points -> winner table) and the column
+ * walk (winner -> point).  Structured clouds — and BASELINE's synthetic sweeps — come in slot order
+ * with few exceptions, e.g. a tail of appended duplicates.  For such a frame the first read is
+ * avoidable, WITHOUT trusting the input:
+ *   k_prefix_len     guesses M, the length of the slot-sorted prefix (sampled, then refined);
+ *   k_prefix_bounds  binary-searches, as if [0, M) were sorted, where each (row, strip) tile starts;
+ *   k_tail_zero/scan builds the winner table for the tail [M, P) only, plus a bitmap of the slots it
+ *                    overrides (a tail point has a larger input index than any prefix point, so it
+ *                    wins its slot: last writer wins);
+ *   the column walk (STRIP_FAST) reads each tile's points where the bounds say they are and VERIFIES
+ *   while it consumes them: tiles are contiguous and ascending, every point of a tile lies in that
+ *   tile's slot range, and slots inside a tile strictly increase.  Together that proves [0, M) is
+ *   strictly slot-sorted, hence duplicate-free, hence each slot's prefix owner is the point found.
+ *   Any violation sets the frame's fail flag; flagged frames are redone by the general path
+ *   (k_winner_zero_failed + k_order_scan + column walk, all predicated on the flag).
+ * Results never depend on the guesses: a wrong M or wrong bounds can only cost speed. */
+__device__ __forceinline__ uint32_t point_slot(const bev_point_t *p, uint32_t i, int N, int H)
+{
+    const uint32_t rc = reinterpret_cast<const uint32_t *>(p + i)[5];
+    const uint32_t row = rc & 0xffffu, col = rc >> 16;
+    return (row < (uint32_t)N && col < (uint32_t)H) ? row * (uint32_t)H + col : 0xffffffffu;
+}
+
+__global__ __launch_bounds__(256) void k_prefix_len(BatchPtrs b, Geometry g)
+{
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const FrameDesc fd = b.frames[f];
+    const bev_point_t *fp = b.pts + fd.in_offset;
+    const uint32_t P = fd.n_pts;
+    __shared__ uint32_t first_bad, best;
+    if (tid == 0) { first_bad = 256u; best = 0xffffffffu; }
+    __syncthreads();
+    const uint32_t step = P / 256u + 1u;
+    /* coarse: 256 samples of "slot(i) is valid and >= i" (true on a sorted duplicate-free prefix) */
+    {
+        const uint32_t i = (uint32_t)tid * step;
+        bool bad = false;
+        if (i < P) {
+            const uint32_t s = point_slot(fp, i, g.N, g.H);
+            bad = (s == 0xffffffffu) || (s < i);
+        } else {
+            bad = true; /* virtual sample past the end */
+        }
+        if (bad) atomicMin(&first_bad, (uint32_t)tid);
+    }
+    __syncthreads();
+    const uint32_t kb = first_bad; /* 256 if none: then 256*step > P, the window below ends at P */
+    const uint32_t start = kb == 0u ? 0u : (kb - 1u) * step;
+    const uint32_t end = min(P, kb * step); /* exclusive bound of the refine scan, M <= end */
+    /* refine: first index in [start, end) that breaks "valid, >= i, strictly above its predecessor" */
+    for (uint32_t i = start + tid; i < end; i += 256u) {
+        const uint32_t s = point_slot(fp, i, g.N, g.H);
+        bool ok = (s != 0xffffffffu) && (s >= i);
+        if (ok && i > 0u) {
+            const uint32_t sp = point_slot(fp, i - 1u, g.N, g.H);
+            ok = (sp != 0xffffffffu) && (s > sp);
+        }
+        if (!ok) atomicMin(&best, i);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        b.fast_len[f] = min(best, end);
+        b.fast_fail[f] = 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_prefix_bounds(BatchPtrs b, Geometry g)
+{
+    const int f = blockIdx.y;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t > (uint32_t)g.rs_tiles) return;
+    const bev_point_t *fp = b.pts + b.frames[f].in_offset;
+    const uint32_t M = b.fast_len[f];
+    uint32_t lo = 0u, hi = M;
+    if (t < (uint32_t)g.rs_tiles) {
+        const uint32_t row = t / (uint32_t)g.strips, strip = t - row * (uint32_t)g.strips;
+        const uint32_t target = row * (uint32_t)g.H + strip * (uint32_t)kStripCols; /* first slot of the tile */
+        while (lo < hi) { /* lower_bound under the sortedness assumption (verified later) */
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (point_slot(fp, mid, g.N, g.H) < target) lo = mid + 1u; else hi = mid;
+        }
+    } else {
+        lo = M;
+    }
+    b.bounds[(size_t)f * (g.rs_tiles + 1) + t] = lo;
+}
+
+/* winner table + override bitmap for the tail [M, P): zero first (plain stores), then atomicMax */
+constexpr int kTailBlocks = 8; /* workgroups per frame; they stride over the tail */
+template <bool kZero>
+__global__ __launch_bounds__(256) void k_tail(BatchPtrs b, Geometry g)
+{
+    const int f = blockIdx.y;
+    const FrameDesc fd = b.frames[f];
+    const uint32_t M = b.fast_len[f];
+    const bev_point_t *fp = b.pts + fd.in_offset;
+    uint32_t *fw = b.winner + (size_t)f * g.S;
+    uint32_t *bits = b.tail_bits + (size_t)f * g.bit_words;
+    for (uint32_t i = M + blockIdx.x * 256u + threadIdx.x; i < fd.n_pts; i += kTailBlocks * 256u) {
+        const uint32_t s = point_slot(fp, i, g.N, g.H);
+        if (s == 0xffffffffu) continue; /* BatchMultiBevGen.cpp:106-111 */
+        if (kZero) {
+            fw[s] = 0u;
+        } else {
+            atomicMax(&fw[s], i + 1u);
+            atomicOr(&bits[s >> 5], 1u << (s & 31u));
+        }
+    }
+}
+
+/* frames whose prefix verification failed get a clean winner table for the general path */
+__global__ __launch_bounds__(256) void k_winner_zero_failed(BatchPtrs b, Geometry g)
+{
+    const int f = blockIdx.y;
+    if (b.fast_fail[f] == 0u) return;
+    uint4 *w = reinterpret_cast<uint4 *>(b.winner + (size_t)f * g.S);
+    const int n16 = g.S / 4;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) w[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < (g.S & 3)) b.winner[(size_t)f * g.S + (size_t)n16 * 4 + threadIdx.x] = 0u;
+}
+
+/* ------------------------------------------------------------------------- */
 /* getOrderedCloud gather + markGroundPoints phase A, as a COLUMN WALK.
  *
  * A workgroup owns kStripCols (252) adjacent columns of one frame plus two halo
@@ -129,10 +256,13 @@ struct PendingRow {
     int gflag;       /* ground_mat(row) at the end of phase A */
 };
 
-template <bool kIdentity>
-__global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geometry g)
+template <int kMode>
+__global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geometry g, int only_failed)
 {
+    constexpr bool kIdentity = kMode == STRIP_IDENTITY;
+    constexpr bool kFast = kMode == STRIP_FAST;
     const int f = blockIdx.x / g.strips, strip = blockIdx.x - f * g.strips;
+    if (only_failed && b.fast_fail[f] == 0u) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int N = g.N, H = g.H, lo_row = g.N - g.G;
     const size_t frame_off = (size_t)f * g.S;
@@ -159,6 +289,86 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         if (kIdentity) return (uint32_t)fl + 1u;
         return fwin[fl];
     };
+
+    /* ---- fast mode: the winners of a row come from the tile's own input range ---- */
+    __shared__ uint32_t idx[2][kStripThreads]; /* row q -> idx[q & 1][pos] = input index + 1 of virtual column pos */
+    constexpr int kMaxRowsLds = 128;           /* rows whose tile bounds are staged in LDS (else read from global) */
+    __shared__ uint32_t bnd_lds[kMaxRowsLds][3]; /* per row: tile start, tile end, row start */
+    const uint32_t M = kFast ? b.fast_len[f] : 0u;
+    const uint32_t *bnd = kFast ? b.bounds + (size_t)f * (g.rs_tiles + 1) : nullptr;
+    const bool bnd_staged = kFast && N <= kMaxRowsLds;
+    if (bnd_staged) {
+        for (int q = tid; q < N; q += kStripThreads) {
+            bnd_lds[q][0] = bnd[q * g.strips + strip];
+            bnd_lds[q][1] = bnd[q * g.strips + strip + 1];
+            bnd_lds[q][2] = bnd[q * g.strips];
+        }
+    }
+    const uint32_t *bits = kFast ? b.tail_bits + (size_t)f * g.bit_words : nullptr;
+    const bool last_strip = strip == g.strips - 1;
+    bool my_fail = false;
+    /* candidate of thread k for row q: input index ci (or < 0), its slot cs, and the slot before it */
+    struct Key { long long ci; uint32_t cs, cprev; int cnt; bool wrap; };
+    auto load_key = [&](int q) -> Key {
+        Key k{-1, 0xffffffffu, 0xffffffffu, 0, false};
+        if (q >= N) return k;
+        const uint32_t a = bnd_staged ? bnd_lds[q][0] : bnd[q * g.strips + strip];
+        const uint32_t e = bnd_staged ? bnd_lds[q][1] : bnd[q * g.strips + strip + 1];
+        const int cnt = (int)e - (int)a;
+        k.cnt = cnt;
+        if (cnt < 0 || cnt > kStripCols) return k; /* flagged in place_key */
+        long long ci = (long long)a - 2 + tid;
+        bool use = tid < cnt + 4;
+        if (last_strip && tid >= cnt + 2 && tid < cnt + 4) { /* right halo wraps to columns 0, 1 of the same row */
+            ci = (long long)(bnd_staged ? bnd_lds[q][2] : bnd[q * g.strips]) + (tid - (cnt + 2));
+            k.wrap = true;
+        }
+        if (use && ci >= 0 && ci < (long long)M) {
+            k.ci = ci;
+            k.cs = point_slot(fpts, (uint32_t)ci, N, H);
+            const bool main_pt = !k.wrap && tid >= 2 && tid < cnt + 2;
+            if (main_pt && tid > 2) k.cprev = point_slot(fpts, (uint32_t)ci - 1u, N, H);
+        }
+        return k;
+    };
+    auto place_key = [&](int q, const Key &k) {
+        if (q >= N) return;
+        if (k.cnt < 0 || k.cnt > kStripCols) { my_fail = true; return; }
+        if (k.ci < 0) return;
+        const long long base = (long long)q * H + (long long)strip * kStripCols - 2; /* flat slot of pos 0 */
+        const bool main_pt = !k.wrap && tid >= 2 && tid < k.cnt + 2;
+        long long pos = -1;
+        if (k.cs != 0xffffffffu) {
+            if (k.wrap) {
+                const long long w = (long long)k.cs - (long long)q * H; /* 0 or 1 expected */
+                if (w >= 0 && w < 2) pos = (long long)H + w - ((long long)strip * kStripCols - 2);
+            } else if ((long long)k.cs < (long long)(q + 1) * H) {
+                pos = (long long)k.cs - base;
+            }
+        }
+        if (main_pt) {
+            /* verification: in the tile's own column range, strictly above the previous point */
+            if (pos < 2 || pos >= 2 + kStripCols) { my_fail = true; return; }
+            if (tid > 2 && !(k.cprev != 0xffffffffu && k.cprev < k.cs)) { my_fail = true; return; }
+        }
+        if (pos >= 0 && pos < kStripThreads) {
+            const uint32_t old = atomicExch(&idx[q & 1][pos], (uint32_t)k.ci + 1u);
+            if (old != 0u) my_fail = true;
+        }
+    };
+    auto tail_word = [&](int q) -> uint32_t { /* override bitmap word of this thread's slot in row q */
+        if (!provider || q >= N) return 0u;
+        const int fl = q * H + vcol;
+        return fl >= 0 ? bits[fl >> 5] : 0u;
+    };
+    auto fast_winner = [&](int q, uint32_t word) -> uint32_t { /* after the barrier that follows place_key(q) */
+        uint32_t w = idx[q & 1][tid];
+        idx[q & 1][tid] = 0u;
+        if (!provider || q >= N) return 0u;
+        const int fl = q * H + vcol;
+        if (fl >= 0 && ((word >> (fl & 31)) & 1u)) w = fwin[fl]; /* a tail point owns this slot */
+        return w;
+    };
     auto load_point = [&](uint32_t w, Half &lo, Half &hi) {
         lo = Half{{0, 0, 0, 0}};
         hi = Half{{0, 0, 0, 0}};
@@ -171,8 +381,27 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
 
     /* software pipeline: nxt = point of the row about to be processed, w_next = winner of the row after it */
     Half cur_lo, cur_hi, nxt_lo, nxt_hi;
-    load_point(load_winner(0), nxt_lo, nxt_hi);
-    uint32_t w_next = load_winner(1);
+    Half nx2_lo{{0, 0, 0, 0}}, nx2_hi{{0, 0, 0, 0}}; /* general/identity: point of row r+2 (two rows in flight) */
+    uint32_t w_next = 0u, w_nx2 = 0u;                /* general/identity: winners of rows r+3 and r+4 */
+    Key key_next{-1, 0xffffffffu, 0xffffffffu, 0, false}; /* fast: keys of row r+1, loaded a row ahead */
+    uint32_t word_next = 0u;                               /* fast: bitmap word of row r+1 */
+    if (kFast) {
+        idx[0][tid] = 0u;
+        idx[1][tid] = 0u;
+        __syncthreads();
+        const Key k0 = load_key(0);
+        const uint32_t word0 = tail_word(0);
+        place_key(0, k0);
+        key_next = load_key(1);
+        word_next = tail_word(1);
+        __syncthreads();
+        load_point(fast_winner(0, word0), nxt_lo, nxt_hi);
+    } else {
+        load_point(load_winner(0), nxt_lo, nxt_hi);
+        load_point(load_winner(1), nx2_lo, nx2_hi);
+        w_next = load_winner(2);
+        w_nx2 = load_winner(3);
+    }
 
     XYZI prev{0.f, 0.f, 0.f, 0.f}, prevprev{0.f, 0.f, 0.f, 0.f};
     PendingRow p1{}, p2{};              /* rows r-1 (ground flag still open) and r-2 (ready to write) */
@@ -185,14 +414,27 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     for (int r = 0; r < N + 2; ++r) {
         cur_lo = nxt_lo;
         cur_hi = nxt_hi;
-        load_point(r + 1 < N ? w_next : 0u, nxt_lo, nxt_hi); /* row r+1, in flight while row r is handled */
-        w_next = load_winner(r + 2);
+        uint32_t word_cur = 0u;
+        if (kFast) {
+            place_key(r + 1, key_next);   /* scatter row r+1's input indices into idx[(r+1) & 1] */
+            word_cur = word_next;
+            key_next = load_key(r + 2);   /* a row ahead */
+            word_next = tail_word(r + 2);
+        } else {
+            /* points of rows r+1 and r+2 and winners of rows r+3 and r+4 are in flight while row r is handled */
+            nxt_lo = nx2_lo;
+            nxt_hi = nx2_hi;
+            load_point(r + 2 < N ? w_next : 0u, nx2_lo, nx2_hi);
+            w_next = w_nx2;
+            w_nx2 = load_winner(r + 4);
+        }
 
         const XYZI cur{__uint_as_float(cur_lo.w[0]), __uint_as_float(cur_lo.w[1]), __uint_as_float(cur_lo.w[2]),
                        __uint_as_float(cur_hi.w[0])};
         if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
         if (lane == 0) wave_cnt[r & 1][wv] = (uint32_t)__popcll(m_ready);
         __syncthreads();
+        if (kFast) load_point(fast_winner(r + 1, word_cur), nxt_lo, nxt_hi); /* row r+1 */
 
         /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
         int s_r = kSteep;
@@ -269,6 +511,7 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         prevprev = prev;
         prev = cur;
     }
+    if (kFast && my_fail) atomicOr(&b.fast_fail[f], 1u);
 }
 
 /* getOrderedCloud alone (bev_order_cloud): no ground work. */
@@ -712,21 +955,43 @@ hipError_t configure_kernels(const Geometry &g)
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)raster_lds_bytes(g));
 }
-void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, hipStream_t st)
+void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, bool only_failed, hipStream_t st)
 {
     if (max_pts == 0 || nf == 0) return;
     const unsigned per_block = 256u * kScanPerThread;
     dim3 grid((max_pts + per_block - 1u) / per_block, (unsigned)nf);
-    hipLaunchKernelGGL(k_order_scan, grid, dim3(256), 0, st, b.pts, b.frames, b.winner, g.N, g.H, g.S);
+    hipLaunchKernelGGL(k_order_scan, grid, dim3(256), 0, st, b.pts, b.frames, b.winner, g.N, g.H, g.S,
+                       only_failed ? b.fast_fail : nullptr);
 }
-void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st)
+void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, StripMode mode, bool only_failed, hipStream_t st)
 {
     if (nf == 0) return;
     const int grid = nf * g.strips;
-    if (identity)
-        hipLaunchKernelGGL(k_strip_ground<true>, dim3(grid), dim3(kStripThreads), 0, st, b, g);
+    const int of = only_failed ? 1 : 0;
+    if (mode == STRIP_IDENTITY)
+        hipLaunchKernelGGL(k_strip_ground<STRIP_IDENTITY>, dim3(grid), dim3(kStripThreads), 0, st, b, g, of);
+    else if (mode == STRIP_FAST)
+        hipLaunchKernelGGL(k_strip_ground<STRIP_FAST>, dim3(grid), dim3(kStripThreads), 0, st, b, g, of);
     else
-        hipLaunchKernelGGL(k_strip_ground<false>, dim3(grid), dim3(kStripThreads), 0, st, b, g);
+        hipLaunchKernelGGL(k_strip_ground<STRIP_GENERAL>, dim3(grid), dim3(kStripThreads), 0, st, b, g, of);
+}
+void launch_prefix_probe(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
+{
+    if (nf == 0) return;
+    hipLaunchKernelGGL(k_prefix_len, dim3(nf), dim3(256), 0, st, b, g);
+    hipLaunchKernelGGL(k_prefix_bounds, dim3((g.rs_tiles + 1 + 255) / 256, nf), dim3(256), 0, st, b, g);
+}
+void launch_tail_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, hipStream_t st)
+{
+    if (nf == 0 || max_pts == 0) return;
+    dim3 grid(kTailBlocks, (unsigned)nf);
+    hipLaunchKernelGGL(k_tail<true>, grid, dim3(256), 0, st, b, g);
+    hipLaunchKernelGGL(k_tail<false>, grid, dim3(256), 0, st, b, g);
+}
+void launch_winner_zero_failed(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
+{
+    if (nf == 0) return;
+    hipLaunchKernelGGL(k_winner_zero_failed, dim3(32, nf), dim3(256), 0, st, b, g);
 }
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {
