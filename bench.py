@@ -158,15 +158,26 @@ def main() -> int:
         avg_ms = dom["total_ms"] / dom["launches"]
         dom_bytes = own_bytes.get(dom["name"], 0.0) * per_launch_frames
         achieved = dom_bytes / (avg_ms * 1e-3) / 1e9
-        pipe_achieved = b_frame * sum(s["frames"] for s in stats if s["name"] == "k_cell_sums") / (tot_ms * 1e-3) / 1e9
+        # HBM bytes of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs, gfx950 FETCH correction applied; see profiles/): per frame, scaled to this launch size
+        traffic, traffic_src = None, None
+        pmc_file = REPO / "profiles" / "r01_final_pmc_traffic.json"
+        if pmc_file.exists():
+            pmc = json.loads(pmc_file.read_text())
+            for kname, kv in pmc["kernels"].items():
+                if kname.split("<")[0] == dom["name"]:
+                    traffic = kv["hbm_bytes_per_frame"] * per_launch_frames
+                    traffic_src = "profiles/r01_final_pmc_traffic.json (rocprofv3 --pmc, earlier run of the same kernel and workload)"
+        # whole hot path against the wall clock of the timed region (this rank): B_frame * frames / time
+        pipe_achieved = b_frame * (count * args.steps) / elapsed / 1e9
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": dom["name"], "frames_per_launch": per_launch_frames,
             "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": avg_ms,
-            # whole hot path: B_frame * frames / (sum of ALL kernel durations)
+            "note": "kernels of two sub-batch lanes overlap in the timed region, so a launch shares the GPU with the other lane's kernels",
             "pipeline": {"bytes_per_frame": b_frame, "achieved": pipe_achieved, "frac": pipe_achieved / HBM_PEAK_GBPS,
-                         "kernel_ms_per_frame": tot_ms / max(1, sum(s["frames"] for s in stats if s["name"] == "k_cell_sums"))},
+                         "definition": "algorithmic bytes of the whole hot path / wall time of the timed region, this GPU"},
         }
 
     # ---- CPU baseline: the oracle (a port of the reference algorithm), 1 thread, bounded sample

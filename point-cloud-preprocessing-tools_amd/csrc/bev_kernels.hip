@@ -307,49 +307,49 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     const uint32_t *bits = kFast ? b.tail_bits + (size_t)f * g.bit_words : nullptr;
     const bool last_strip = strip == g.strips - 1;
     bool my_fail = false;
-    /* candidate of thread k for row q: input index ci (or < 0), its slot cs, and the slot before it */
-    struct Key { long long ci; uint32_t cs, cprev; int cnt; bool wrap; };
+    /* candidate of thread tid for row q: input index ci (< 0: none) and its slot cs */
+    struct Key { int ci; uint32_t cs; int cnt; bool wrap; };
     auto load_key = [&](int q) -> Key {
-        Key k{-1, 0xffffffffu, 0xffffffffu, 0, false};
+        Key k{-1, 0xffffffffu, 0, false};
         if (q >= N) return k;
         const uint32_t a = bnd_staged ? bnd_lds[q][0] : bnd[q * g.strips + strip];
         const uint32_t e = bnd_staged ? bnd_lds[q][1] : bnd[q * g.strips + strip + 1];
         const int cnt = (int)e - (int)a;
         k.cnt = cnt;
         if (cnt < 0 || cnt > kStripCols) return k; /* flagged in place_key */
-        long long ci = (long long)a - 2 + tid;
-        bool use = tid < cnt + 4;
+        int ci = (int)a - 2 + tid;                 /* input indices fit 31 bits: bev_create caps max_points */
         if (last_strip && tid >= cnt + 2 && tid < cnt + 4) { /* right halo wraps to columns 0, 1 of the same row */
-            ci = (long long)(bnd_staged ? bnd_lds[q][2] : bnd[q * g.strips]) + (tid - (cnt + 2));
+            ci = (int)(bnd_staged ? bnd_lds[q][2] : bnd[q * g.strips]) + (tid - (cnt + 2));
             k.wrap = true;
         }
-        if (use && ci >= 0 && ci < (long long)M) {
+        if (tid < cnt + 4 && ci >= 0 && ci < (int)M) {
             k.ci = ci;
             k.cs = point_slot(fpts, (uint32_t)ci, N, H);
-            const bool main_pt = !k.wrap && tid >= 2 && tid < cnt + 2;
-            if (main_pt && tid > 2) k.cprev = point_slot(fpts, (uint32_t)ci - 1u, N, H);
         }
         return k;
     };
     auto place_key = [&](int q, const Key &k) {
-        if (q >= N) return;
+        if (q >= N) return; /* workgroup-uniform */
+        /* slot of the candidate one thread to the left (the previous input point for main points) */
+        uint32_t cprev = __shfl_up(k.cs, 1);
+        if (lane == 0 && tid > 2 && k.ci > 0 && !k.wrap) cprev = point_slot(fpts, (uint32_t)k.ci - 1u, N, H);
         if (k.cnt < 0 || k.cnt > kStripCols) { my_fail = true; return; }
         if (k.ci < 0) return;
-        const long long base = (long long)q * H + (long long)strip * kStripCols - 2; /* flat slot of pos 0 */
+        const int base = q * H + strip * kStripCols - 2; /* flat slot of pos 0 (may be -2) */
         const bool main_pt = !k.wrap && tid >= 2 && tid < k.cnt + 2;
-        long long pos = -1;
+        int pos = -1;
         if (k.cs != 0xffffffffu) {
             if (k.wrap) {
-                const long long w = (long long)k.cs - (long long)q * H; /* 0 or 1 expected */
-                if (w >= 0 && w < 2) pos = (long long)H + w - ((long long)strip * kStripCols - 2);
-            } else if ((long long)k.cs < (long long)(q + 1) * H) {
-                pos = (long long)k.cs - base;
+                const int w = (int)k.cs - q * H; /* 0 or 1 expected */
+                if (w >= 0 && w < 2) pos = H + w - (strip * kStripCols - 2);
+            } else if ((int)k.cs < (q + 1) * H) {
+                pos = (int)k.cs - base;
             }
         }
         if (main_pt) {
             /* verification: in the tile's own column range, strictly above the previous point */
             if (pos < 2 || pos >= 2 + kStripCols) { my_fail = true; return; }
-            if (tid > 2 && !(k.cprev != 0xffffffffu && k.cprev < k.cs)) { my_fail = true; return; }
+            if (tid > 2 && !(cprev != 0xffffffffu && cprev < k.cs)) { my_fail = true; return; }
         }
         if (pos >= 0 && pos < kStripThreads) {
             const uint32_t old = atomicExch(&idx[q & 1][pos], (uint32_t)k.ci + 1u);
@@ -383,19 +383,23 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     Half cur_lo, cur_hi, nxt_lo, nxt_hi;
     Half nx2_lo{{0, 0, 0, 0}}, nx2_hi{{0, 0, 0, 0}}; /* general/identity: point of row r+2 (two rows in flight) */
     uint32_t w_next = 0u, w_nx2 = 0u;                /* general/identity: winners of rows r+3 and r+4 */
-    Key key_next{-1, 0xffffffffu, 0xffffffffu, 0, false}; /* fast: keys of row r+1, loaded a row ahead */
-    uint32_t word_next = 0u;                               /* fast: bitmap word of row r+1 */
+    /* fast: keys / bitmap words of rows r+3 and r+4 are in flight, like the points of rows r+1 and r+2 */
+    Key key_a{-1, 0xffffffffu, 0, false}, key_b{-1, 0xffffffffu, 0, false};
+    uint32_t word_a = 0u, word_b = 0u;
     if (kFast) {
         idx[0][tid] = 0u;
         idx[1][tid] = 0u;
         __syncthreads();
-        const Key k0 = load_key(0);
-        const uint32_t word0 = tail_word(0);
+        const Key k0 = load_key(0), k1 = load_key(1);
+        const uint32_t word0 = tail_word(0), word1 = tail_word(1);
+        key_a = load_key(2); word_a = tail_word(2);
+        key_b = load_key(3); word_b = tail_word(3);
         place_key(0, k0);
-        key_next = load_key(1);
-        word_next = tail_word(1);
+        place_key(1, k1);
         __syncthreads();
         load_point(fast_winner(0, word0), nxt_lo, nxt_hi);
+        load_point(fast_winner(1, word1), nx2_lo, nx2_hi);
+        __syncthreads(); /* every thread has read and cleared both buffers before row 2 is scattered */
     } else {
         load_point(load_winner(0), nxt_lo, nxt_hi);
         load_point(load_winner(1), nx2_lo, nx2_hi);
@@ -416,10 +420,12 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         cur_hi = nxt_hi;
         uint32_t word_cur = 0u;
         if (kFast) {
-            place_key(r + 1, key_next);   /* scatter row r+1's input indices into idx[(r+1) & 1] */
-            word_cur = word_next;
-            key_next = load_key(r + 2);   /* a row ahead */
-            word_next = tail_word(r + 2);
+            place_key(r + 2, key_a);      /* scatter row r+2's input indices into idx[r & 1] */
+            word_cur = word_a;
+            key_a = key_b;
+            word_a = word_b;
+            key_b = load_key(r + 4);      /* two rows ahead of its use */
+            word_b = tail_word(r + 4);
         } else {
             /* points of rows r+1 and r+2 and winners of rows r+3 and r+4 are in flight while row r is handled */
             nxt_lo = nx2_lo;
@@ -434,7 +440,11 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
         if (lane == 0) wave_cnt[r & 1][wv] = (uint32_t)__popcll(m_ready);
         __syncthreads();
-        if (kFast) load_point(fast_winner(r + 1, word_cur), nxt_lo, nxt_hi); /* row r+1 */
+        if (kFast) { /* row r+1 is already in flight; issue row r+2 */
+            nxt_lo = nx2_lo;
+            nxt_hi = nx2_hi;
+            load_point(fast_winner(r + 2, word_cur), nx2_lo, nx2_hi);
+        }
 
         /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
         int s_r = kSteep;
