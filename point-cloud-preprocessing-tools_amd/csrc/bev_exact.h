@@ -86,13 +86,23 @@ BEVX_HD bool angle_is_ground(float dx, float dy, float dz)
     return q <= bits_to_float(kTanThresholdBits);
 }
 
-/* getBelongingGrid, BatchMultiBevGen.h:73-99 -> cell = row * 50 + col */
+/* getBelongingGrid, BatchMultiBevGen.h:73-99 -> cell = row * 50 + col.
+ * The reference mixes float and double here; every step has an exact float-only equivalent
+ * (checked for ALL 2^32 float inputs by tests/test_exact_forms.py against the literal expressions):
+ *   (float)((double)x + 75.0) == x + 75.0f       one correctly rounded sum either way
+ *   floor((double)nx / 2.0)    == floorf(nx * 0.5f) scaling by 2 is exact (nx is never subnormal)      */
+BEVX_HD int floor_half_to_int(float nx)
+{
+    const float h = nx * 0.5f; /* exact, except that -FLT_TRUE_MIN * 0.5f rounds to -0 */
+    if (nx < 0.0f && h == 0.0f) return -1;
+    return (h >= -2147483648.0f && h < 2147483648.0f) ? (int)floorf(h) : kIntMin; /* cvttsd2si on NaN / overflow */
+}
 BEVX_HD int ground_cell(float x, float y)
 {
-    float nx = (float)((double)x + 75.0); /* :78 */
-    float ny = (float)((double)y + 50.0); /* :79 */
-    int r = cvtt_f64(floor((double)nx * 0.5)); /* :81, /2.0 is exact */
-    int c = cvtt_f64(floor((double)ny * 0.5)); /* :82 */
+    const float nx = x + 75.0f; /* :78 */
+    const float ny = y + 50.0f; /* :79 */
+    int r = floor_half_to_int(nx); /* :81 */
+    int c = floor_half_to_int(ny); /* :82 */
     if (r >= kGridRows) r = kGridRows - 1; /* :84-89 */
     if (r < 0) r = 0;
     if (c >= kGridCols) c = kGridCols - 1; /* :91-96 */
@@ -107,10 +117,12 @@ BEVX_HD bool above_neighbour_ground(float z, int cell, AvgPtr avg)
 {
     const int sr = cell / kGridCols, sc = cell % kGridCols;
     bool hit = false;
-    if (sr - 1 >= 0)        hit = hit || ((double)(z - avg[cell - kGridCols]) > 0.30);
-    if (sc + 1 < kGridCols) hit = hit || ((double)(z - avg[cell + 1]) > 0.30);
-    if (sc - 1 >= 0)        hit = hit || ((double)(z - avg[cell - 1]) > 0.30);
-    if (sr + 1 < kGridRows) hit = hit || ((double)(z - avg[cell + kGridCols]) > 0.30);
+    /* (double)d > 0.30 for a float d  <=>  d >= 0.3f: 0.3f = 0.300000011920929 is the smallest float
+     * above the double 0.30 (all 2^32 values of d checked by tests/test_exact_forms.py) */
+    if (sr - 1 >= 0)        hit = hit || ((z - avg[cell - kGridCols]) >= 0.3f);
+    if (sc + 1 < kGridCols) hit = hit || ((z - avg[cell + 1]) >= 0.3f);
+    if (sc - 1 >= 0)        hit = hit || ((z - avg[cell - 1]) >= 0.3f);
+    if (sr + 1 < kGridRows) hit = hit || ((z - avg[cell + kGridCols]) >= 0.3f);
     return hit;
 }
 
@@ -135,10 +147,29 @@ struct RasterParams {
     int n_layers;        /* :268 */
 };
 
+/* (int)round((double)v + 0.5), half away from zero, without doubles.  d = v + 0.5 in double:
+ *   v >= 0            : d is exact, round(d) = floor(d + 0.5) = floor(v) + 1
+ *   -0.5 <= v < 0     : 0 <= d < 0.5 -> 0, except that for |v| <= 2^-55 the double sum rounds to 0.5 -> 1
+ *   v < -0.5          : d is exact and negative, round(d) = -floor(-d + 0.5) = ceil(v)
+ * Callers only test the result against [0, M), M <= 1024; values the reference would see outside
+ * +-2^31 (cvttsd2si -> INT_MIN) are reported as kIntMin as well.  Checked for all 2^32 floats. */
+BEVX_HD int round_half_up_bin(float v)
+{
+    if (!(v > -2147483000.0f && v < 2147483000.0f)) return kIntMin;
+    if (v >= 0.0f) return (int)floorf(v) + 1;
+    if (v >= -0.5f) return v >= -0x1p-55f ? 1 : 0;
+    return (int)ceilf(v);
+}
 BEVX_HD int bev_bin(float p, float max_range_f, float interval)
 {
-    float shifted = (p + max_range_f) / interval;          /* float */
-    return cvtt_f64(round((double)shifted + 0.5));        /* double, half away from zero */
+    const float shifted = (p + max_range_f) / interval;    /* float, BatchMultiBevGen.cpp:279 */
+    return round_half_up_bin(shifted);
+}
+/* (int)((double)(z + 2.0f) * 4.0): scaling by 4 is exact in float too */
+BEVX_HD int height_times4(float t)
+{
+    const float u = t * 4.0f;
+    return (u >= -2147483648.0f && u < 2147483648.0f) ? (int)u : kIntMin;
 }
 
 BEVX_HD uint32_t bev_code(float px, float py, float pz, int label, const RasterParams &rp)
@@ -148,7 +179,7 @@ BEVX_HD uint32_t bev_code(float px, float py, float pz, int label, const RasterP
     int y = bev_bin(py, rp.max_range_f, rp.interval);                  /* :280, :344 */
     if (x < 0 || x >= rp.mat_size || y < 0 || y >= rp.mat_size) return kSkip;
     int layer = cvtt_f32(roundf(pz / rp.height_res + rp.lidar_to_ground)); /* :281 */
-    int h = cvtt_f64((double)(pz + rp.lidar_to_ground) * 4.0);         /* :345 */
+    int h = height_times4(pz + rp.lidar_to_ground);                    /* :345 */
     h = h < 0 ? 0 : (h > 255 ? 255 : h);                               /* :346 */
     uint32_t l = (layer >= 0 && layer < rp.n_layers) ? (uint32_t)layer : kNoLayer;
     return (uint32_t)x | ((uint32_t)y << 9) | ((uint32_t)h << 18) | (l << 26);

@@ -131,6 +131,40 @@ uint32_t hc_bev_code(const bev_params_t *p, float x, float y, float z, int label
     return bev_code(x, y, z, label, raster_params(p));
 }
 
+/* Exhaustive equivalence of the float-only forms in bev_exact.h with the reference's literal mixed
+ * float/double expressions, over all 2^32 float bit patterns.  out[k] = number of mismatches:
+ *   0: x + 75.0f            vs (float)((double)x + 75.0)         (bit patterns compared, NaN == NaN)
+ *   1: floor_half_to_int(n) vs cvttsd2si(floor((double)n / 2.0))
+ *   2: round_half_up_bin(v) vs cvttsd2si(round((double)v + 0.5))  (compared after mapping out-of-[0,4096) to -1)
+ *   3: height_times4(t)     vs cvttsd2si((double)t * 4.0)
+ *   4: d >= 0.3f            vs (double)d > 0.30 */
+void hc_exhaustive_exact_forms(uint64_t *out)
+{
+    uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+#pragma omp parallel for reduction(+ : m0, m1, m2, m3, m4) schedule(static)
+    for (int64_t u = 0; u <= 0xffffffffLL; ++u) {
+        const float f = bits_to_float((uint32_t)u);
+        {
+            const float a = f + 75.0f, b = (float)((double)f + 75.0);
+            uint32_t ua, ub; std::memcpy(&ua, &a, 4); std::memcpy(&ub, &b, 4);
+            if (ua != ub && !(a != a && b != b)) ++m0;
+            const float a2 = f + 50.0f, b2 = (float)((double)f + 50.0);
+            std::memcpy(&ua, &a2, 4); std::memcpy(&ub, &b2, 4);
+            if (ua != ub && !(a2 != a2 && b2 != b2)) ++m0;
+        }
+        if (floor_half_to_int(f) != cvtt_f64(std::floor((double)f / 2.0))) ++m1;
+        {
+            int a = round_half_up_bin(f), b = cvtt_f64(std::round((double)f + 0.5));
+            if (a < 0 || a >= 4096) a = -1;
+            if (b < 0 || b >= 4096) b = -1;
+            if (a != b) ++m2;
+        }
+        if (height_times4(f) != cvtt_f64((double)f * 4.0)) ++m3;
+        if ((f >= 0.3f) != ((double)f > 0.30)) ++m4;
+    }
+    out[0] = m0; out[1] = m1; out[2] = m2; out[3] = m3; out[4] = m4;
+}
+
 /* Whole frame, composed like the kernels. gm_phase_a / gm_final / avg may be NULL. */
 void hc_process_frame(const bev_params_t *p, const bev_point_t *in, uint32_t n_in, bev_point_t *ordered,
                       int8_t *gm_phase_a, int8_t *gm_final, float *avg_out, uint8_t *multi, uint8_t *single)

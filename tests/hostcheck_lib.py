@@ -25,6 +25,8 @@ def lib():
         l.hc_bev_code.restype = C.c_uint32
         l.hc_process_frame.argtypes = [C.POINTER(BevParams), vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
         l.hc_process_frame.restype = None
+        l.hc_exhaustive_exact_forms.argtypes = [vp]
+        l.hc_exhaustive_exact_forms.restype = None
         l.hc_derive_angle_threshold.argtypes = [vp]
         l.hc_derive_angle_threshold.restype = None
         l.hc_angle_vs_libm.argtypes = [C.c_uint64, C.c_uint64]

@@ -1,0 +1,13 @@
+"""CPU: csrc/bev_exact.h evaluates the reference's mixed float/double expressions with float-only
+forms (fewer, cheaper device instructions).  Each form is compared with the literal expression for
+ALL 2^32 float inputs."""
+import ctypes as C
+
+import hostcheck_lib as hc
+
+
+def test_float_only_forms_equal_the_literal_expressions_for_every_float():
+    out = (C.c_uint64 * 5)()
+    hc.lib().hc_exhaustive_exact_forms(out)
+    names = ["x + 75.0f / y + 50.0f", "floor(n / 2.0)", "round(v + 0.5) bin", "(z + 2) * 4 height", "d > 0.30"]
+    assert {n: int(v) for n, v in zip(names, out)} == {n: 0 for n in names}
