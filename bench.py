@@ -58,13 +58,15 @@ def main() -> int:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to fall back to)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run even a single rank goes through RCCL
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     if rank == 0:
         ge.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     lib_missing = not bev_amd.LIB_PATH.exists()
     if lib_missing:
@@ -75,7 +77,7 @@ def main() -> int:
     F = args.frames
 
     # ---- frame-range table: rank 0 decides, RCCL broadcast (the path's only collective)
-    table = shard.broadcast_ranges(F * world, rank, world, device=dev)
+    table = shard.broadcast_ranges(F * world, rank, world, device=dev, force_collective=use_dist)
     first, count = int(table[rank, 0]), int(table[rank, 1])
     assert count == F
 
@@ -113,7 +115,7 @@ def main() -> int:
     def fence():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -128,8 +130,8 @@ def main() -> int:
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    elapsed = shard.max_over_ranks(elapsed, world, device=dev)
-    total_frames = shard.sum_over_ranks(float(count * args.steps), world, device=dev)
+    elapsed = shard.max_over_ranks(elapsed, world, device=dev, force_collective=use_dist)
+    total_frames = shard.sum_over_ranks(float(count * args.steps), world, device=dev, force_collective=use_dist)
 
     # ---- per-kernel HIP-event durations of the timed region (rank 0's stream)
     stats = [] if args.no_profile else ctx.profile_get()
@@ -234,7 +236,7 @@ def main() -> int:
         }
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     return 0
 

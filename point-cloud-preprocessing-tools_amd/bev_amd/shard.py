@@ -17,7 +17,7 @@ def frame_ranges(total_frames: int, world_size: int) -> np.ndarray:
     return np.stack([firsts, counts], axis=1)
 
 
-def broadcast_ranges(total_frames: int, rank: int, world_size: int, device="cpu") -> np.ndarray:
+def broadcast_ranges(total_frames: int, rank: int, world_size: int, device="cpu", force_collective=False) -> np.ndarray:
     """Rank 0 computes the table and broadcasts it (the one collective of the path)."""
     import torch
     import torch.distributed as dist
@@ -25,26 +25,26 @@ def broadcast_ranges(total_frames: int, rank: int, world_size: int, device="cpu"
     table = torch.zeros((world_size, 2), dtype=torch.int64, device=device)
     if rank == 0:
         table.copy_(torch.from_numpy(frame_ranges(total_frames, world_size)))
-    if world_size > 1:
+    if world_size > 1 or force_collective:
         dist.broadcast(table, src=0)
     return table.cpu().numpy()
 
 
-def max_over_ranks(value: float, world_size: int, device="cpu") -> float:
+def max_over_ranks(value: float, world_size: int, device="cpu", force_collective=False) -> float:
     import torch
     import torch.distributed as dist
 
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    if world_size > 1:
+    if world_size > 1 or force_collective:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def sum_over_ranks(value: float, world_size: int, device="cpu") -> float:
+def sum_over_ranks(value: float, world_size: int, device="cpu", force_collective=False) -> float:
     import torch
     import torch.distributed as dist
 
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    if world_size > 1:
+    if world_size > 1 or force_collective:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
