@@ -69,3 +69,61 @@ def read_png_gray8(path):
     rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w + 1)
     assert (rows[:, 0] == 0).all()
     return rows[:, 1:]
+
+
+def lzf_compress(data: bytes) -> bytes:
+    """Small LZF encoder (liblzf format, as PCL's binary_compressed uses): greedy 3-byte hash matches
+    within 8 KiB, literal runs of at most 32 bytes.  Good enough to exercise both token kinds."""
+    out = bytearray()
+    n = len(data)
+    table = {}
+    lit = bytearray()
+
+    def flush():
+        nonlocal lit
+        i = 0
+        while i < len(lit):
+            run = lit[i:i + 32]
+            out.append(len(run) - 1)
+            out.extend(run)
+            i += 32
+        lit = bytearray()
+
+    i = 0
+    while i < n:
+        m = None
+        if i + 2 < n:
+            key = data[i:i + 3]
+            j = table.get(key)
+            table[key] = i
+            if j is not None and 0 < i - j <= 8191:
+                ln = 3
+                while i + ln < n and ln < 264 and data[j + ln] == data[i + ln]:
+                    ln += 1
+                m = (i - j - 1, ln)
+        if m is None:
+            lit.append(data[i])
+            i += 1
+            continue
+        flush()
+        off, ln = m
+        l2 = ln - 2
+        if l2 < 7:
+            out.append((l2 << 5) | (off >> 8))
+        else:
+            out.append((7 << 5) | (off >> 8))
+            out.append(l2 - 7)
+        out.append(off & 0xFF)
+        i += ln
+    flush()
+    return bytes(out)
+
+
+def write_pcd_binary_compressed(path, pts):
+    packed = to_packed(pts)
+    soa = b"".join(np.ascontiguousarray(packed[k]).tobytes() for k in PACKED.names)  # field-by-field
+    comp = lzf_compress(soa)
+    with open(path, "wb") as f:
+        f.write(_header(len(pts), "binary_compressed"))
+        f.write(struct.pack("<II", len(comp), len(soa)))
+        f.write(comp)

@@ -77,6 +77,8 @@ def test_cli_end_to_end(tmp_path):
             pcd_util.write_pcd_ascii(path, pts)
         elif name == "000003":
             pcd_util.write_pcd_binary(path, pts, width=0, height=0)  # what the KITTI producer effectively writes
+        elif name == "000001":
+            pcd_util.write_pcd_binary_compressed(path, pts)           # PCL's LZF + field-major layout
         else:
             pcd_util.write_pcd_binary(path, pts)
     (root / "keyframe_point_cloud" / "notes.txt").write_text("ignored")
