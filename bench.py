@@ -34,7 +34,10 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU (BASELINE config: 1000)")
-    ap.add_argument("--sensor", default="HDL_64E")
+    ap.add_argument("--sensor", default=None)
+    ap.add_argument("--workload", default="hdl64_sweep", choices=["hdl64_sweep", "os1_firing", "oxford_concat"],
+                    help="hdl64_sweep = BASELINE configs[1]/[3] (default, the graded metric); os1_firing = configs[2] "
+                         "(MulRan-style unordered OS1_64); oxford_concat = configs[4] (HDL_32E, ~2M points per frame)")
     ap.add_argument("--sub-batch", type=int, default=int(os.environ.get("BEV_SUB_BATCH", "256")))
     ap.add_argument("--cpu-sample", type=int, default=400, help="frames timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -72,6 +75,8 @@ def main() -> int:
     if lib_missing:
         raise SystemExit(f"{bev_amd.LIB_PATH} missing")
 
+    default_sensor = {"hdl64_sweep": "HDL_64E", "os1_firing": "OS1_64", "oxford_concat": "HDL_32E"}[args.workload]
+    args.sensor = args.sensor or default_sensor
     p = bev_amd.params_for_sensor(args.sensor)
     S, M, L = p.slots, p.mat_size, p.n_layers
     F = args.frames
@@ -83,13 +88,23 @@ def main() -> int:
 
     # ---- synthetic frames, generated on the host cores, then made resident in HBM
     n_dup = 5000
-    cap = S + n_dup
+    n_sweeps = 60
+    cap = {"hdl64_sweep": S + n_dup, "os1_firing": S, "oxford_concat": S * n_sweeps}[args.workload]
     t_gen = time.time()
     host = np.empty((count, cap), dtype=bev_amd.POINT_DTYPE)
     counts = np.zeros(count, dtype=np.int64)
 
     def gen(i):
-        counts[i] = len(synth.sweep(p, first + i, keep=0.98, n_dup=n_dup, out=host[i]))
+        if args.workload == "hdl64_sweep":
+            counts[i] = len(synth.sweep(p, first + i, keep=0.98, n_dup=n_dup, out=host[i]))
+        elif args.workload == "os1_firing":
+            pts = synth.firing_order(p, first + i)
+            host[i, :len(pts)] = pts
+            counts[i] = len(pts)
+        else:
+            pts = synth.concat(p, first + i, n_sweeps=n_sweeps)
+            host[i, :len(pts)] = pts
+            counts[i] = len(pts)
 
     with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as ex:
         list(ex.map(gen, range(count)))
@@ -213,7 +228,8 @@ def main() -> int:
 
     if rank == 0:
         out = {
-            "metric": "BEV frames/sec (131k-pt HDL-64E cloud)",
+            "metric": "BEV frames/sec (131k-pt HDL-64E cloud)" if args.workload == "hdl64_sweep"
+                      else f"BEV frames/sec ({args.workload})",
             "value": total_frames / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
@@ -225,7 +241,7 @@ def main() -> int:
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{F} synthetic KITTI {args.sensor} clouds per GPU (mean {mean_pts:.0f} input pts, "
+            "config": {"workload": f"{F} synthetic {args.workload} {args.sensor} clouds per GPU (mean {mean_pts:.0f} input pts, "
                                    f"{S} slots), single+multi BEV, device-resident",
                        "frames_per_gpu": F, "sub_batch": args.sub_batch, "sensor": args.sensor,
                        "algorithmic_bytes_per_frame": b_frame, "parallelism": f"frames x{world}"},
