@@ -54,6 +54,7 @@ static inline int xcd_grid(int nf, int tiles) { return 8 * ((nf + 7) / 8) * tile
 /* getOrderedCloud, BatchMultiBevGen.cpp:102-116: bounds test + slot index;
  * "last point in input order wins" == max input index per slot.            */
 constexpr int kScanPerThread = 4;
+constexpr int kScanRowBins = 128; /* rows the LDS regrouping below can bin (more rows: plain path) */
 __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restrict__ pts,
                                                     const FrameDesc *__restrict__ frames,
                                                     uint32_t *__restrict__ winner, int N, int H, int S,
@@ -63,21 +64,82 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
     if (only_failed && only_failed[f] == 0u) return;
     const FrameDesc fd = frames[f];
     const uint32_t base = blockIdx.x * (256u * kScanPerThread) + threadIdx.x;
-    if (base >= fd.n_pts) return;
+    if (blockIdx.x * (256u * kScanPerThread) >= fd.n_pts) return;
     const bev_point_t *fp = pts + fd.in_offset;
-    uint32_t rc[kScanPerThread];
+    uint32_t slot[kScanPerThread];
+    bool spread = false; /* does any wave-instruction's worth of 64 points straddle far-apart slots? */
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k) { /* all loads in flight before the first atomic */
         const uint32_t i = base + 256u * k;
-        rc[k] = i < fd.n_pts ? reinterpret_cast<const uint32_t *>(fp + i)[5] : 0xffffffffu; /* row | col << 16 */
+        slot[k] = 0xffffffffu;
+        if (i < fd.n_pts) {
+            const uint32_t rc = reinterpret_cast<const uint32_t *>(fp + i)[5]; /* row | col << 16 */
+            const uint32_t row = rc & 0xffffu, col = rc >> 16;
+            if (row < (uint32_t)N && col < (uint32_t)H) slot[k] = row * (uint32_t)H + col; /* :106-111 ("< 0" is dead: u16) */
+        }
     }
     uint32_t *fw = winner + (size_t)f * S;
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k) {
-        const uint32_t i = base + 256u * k;
-        const uint32_t row = rc[k] & 0xffffu, col = rc[k] >> 16;
-        if (i < fd.n_pts && row < (uint32_t)N && col < (uint32_t)H) /* :106-111 (the "< 0" tests are dead: u16) */
-            atomicMax(&fw[row * H + col], i + 1u);
+        /* slots of a sorted cloud rise by ~1 per lane; a wave whose first and last valid lanes are more
+         * than 4 rows apart is scattering (e.g. firing-order input: consecutive points = consecutive rows) */
+        const unsigned long long vm = __ballot(slot[k] != 0xffffffffu);
+        if (vm) {
+            const int lo_lane = __ffsll((long long)vm) - 1, hi_lane = 63 - __clzll((long long)vm);
+            const uint32_t a = __shfl(slot[k], lo_lane), z = __shfl(slot[k], hi_lane);
+            const uint32_t d = a > z ? a - z : z - a;
+            spread = spread || d > 4u * (uint32_t)H;
+        }
+    }
+    __shared__ uint32_t any_spread;
+    __shared__ uint32_t row_fill[kScanRowBins];
+    __shared__ uint2 pairs[256 * kScanPerThread]; /* (slot, index + 1) regrouped by row */
+    if (threadIdx.x == 0) any_spread = 0u;
+    __syncthreads();
+    if (spread && (threadIdx.x & 63) == 0) any_spread = 1u;
+    __syncthreads();
+    if (any_spread == 0u || N > kScanRowBins) {
+        /* coalesced already (or too many rows to bin): one atomicMax per point, in input order */
+#pragma unroll
+        for (int k = 0; k < kScanPerThread; ++k)
+            if (slot[k] != 0xffffffffu) atomicMax(&fw[slot[k]], base + 256u * k + 1u);
+        return;
+    }
+    /* Scattering input: regroup the block's (slot, index) pairs by row in LDS (atomicMax is order-free,
+     * so an unstable counting sort is enough); a wave then sends its atomics to one row and nearby
+     * columns instead of 64 different rows — scattered device atomics run ~15x slower than contiguous ones. */
+    for (int r = threadIdx.x; r < kScanRowBins; r += 256) row_fill[r] = 0u;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) pairs[threadIdx.x + 256u * k] = make_uint2(0u, 0u); /* y == 0: empty */
+    __syncthreads();
+    uint32_t rank[kScanPerThread];
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k)
+        rank[k] = slot[k] != 0xffffffffu ? atomicAdd(&row_fill[slot[k] / (uint32_t)H], 1u) : 0u;
+    __syncthreads();
+    /* exclusive scan of the row counts (N <= 128 bins: two per thread of the first wave) */
+    if (threadIdx.x < 64) {
+        const uint32_t c0 = row_fill[2 * threadIdx.x], c1 = row_fill[2 * threadIdx.x + 1];
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d);
+            if ((int)threadIdx.x >= d) incl += v;
+        }
+        row_fill[2 * threadIdx.x] = incl - c0 - c1;
+        row_fill[2 * threadIdx.x + 1] = incl - c1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k)
+        if (slot[k] != 0xffffffffu)
+            pairs[row_fill[slot[k] / (uint32_t)H] + rank[k]] = make_uint2(slot[k], base + 256u * k + 1u);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        const uint32_t j = threadIdx.x + 256u * k;
+        const uint2 pr = pairs[j];
+        if (pr.y != 0u) atomicMax(&fw[pr.x], pr.y);
     }
 }
 
