@@ -1,0 +1,72 @@
+"""GPU: the batch machinery at BASELINE scale — many frames, device-resident, through the sub-batch
+lanes.  Size-independent properties: results do not depend on how frames are cut into sub-batches or
+dealt to lanes; a checksum over all frames is stable across repeated asynchronous calls; sampled frames
+equal the oracle."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import bev_amd
+import oracle_lib as orc
+from bev_amd import synth
+
+pytestmark = pytest.mark.gpu
+N_FRAMES = 300
+
+
+def _run(p, frames, sub_batch, lanes, repeats=1):
+    import torch
+
+    old = os.environ.get("BEV_LANES")
+    os.environ["BEV_LANES"] = str(lanes)
+    try:
+        ctx = bev_amd.BevContext(p, device=0, max_batch=sub_batch, max_points=max(len(f) for f in frames))
+    finally:
+        if old is None:
+            os.environ.pop("BEV_LANES", None)
+        else:
+            os.environ["BEV_LANES"] = old
+    dev = torch.device("cuda:0")
+    S, M, L = p.slots, p.mat_size, p.n_layers
+    offs = np.zeros(len(frames) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(f) for f in frames])
+    d_in = torch.from_numpy(np.concatenate(frames).view(np.uint8).reshape(-1)).to(dev)
+    d_ord = torch.zeros(len(frames) * S * 32, dtype=torch.uint8, device=dev)
+    d_multi = torch.zeros(len(frames) * L * M * M, dtype=torch.uint8, device=dev)
+    d_single = torch.zeros(len(frames) * M * M, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(repeats):  # back-to-back asynchronous calls over the same buffers
+        ctx.process_device(len(frames), d_in.data_ptr(), offs, d_ord.data_ptr(), d_multi.data_ptr(), d_single.data_ptr())
+    ctx.synchronize()
+    out = (d_ord.cpu().numpy(), d_multi.cpu().numpy(), d_single.cpu().numpy())
+    ctx.close()
+    return out
+
+
+def _digest(arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def test_sub_batching_and_lanes_do_not_change_results():
+    p = bev_amd.params_for_sensor("HDL_64E")
+    frames = [synth.sweep(p, 5000 + f) for f in range(N_FRAMES)]
+    ref = _run(p, frames, sub_batch=64, lanes=2, repeats=3)
+    assert _digest(ref) == _digest(_run(p, frames, sub_batch=7, lanes=1))     # 43 ragged sub-batches, one lane
+    assert _digest(ref) == _digest(_run(p, frames, sub_batch=300, lanes=3))   # one sub-batch
+    assert _digest(ref) == _digest(_run(p, frames, sub_batch=37, lanes=4, repeats=2))
+    S, M, L = p.slots, p.mat_size, p.n_layers
+    sp = orc.sensor_from_params(p)
+    for i in (0, 63, 64, 150, N_FRAMES - 1):  # sub-batch edges and the last frame
+        o_ord, _, o_multi, o_single = orc.process_frame(sp, frames[i], want_gm=False)
+        assert ref[0][i * S * 32:(i + 1) * S * 32].tobytes() == o_ord.tobytes()
+        assert ref[1][i * L * M * M:(i + 1) * L * M * M].tobytes() == o_multi.tobytes()
+        assert ref[2][i * M * M:(i + 1) * M * M].tobytes() == o_single.tobytes()
+    # every frame produced something plausible: a ground ring and an occupied BEV
+    labels = ref[0].view(bev_amd.POINT_DTYPE).reshape(N_FRAMES, S)["label"]
+    assert ((labels == 0).sum(axis=1) > 20000).all()
+    assert (ref[1].reshape(N_FRAMES, -1).astype(np.int64).sum(axis=1) > 0).all()
