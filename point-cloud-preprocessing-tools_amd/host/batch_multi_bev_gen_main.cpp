@@ -10,9 +10,13 @@
  *   BEV_NO_PNG=1    skip the 25 PNG files per frame
  */
 #include <chrono>
+#include <cstdint>
 #include <cstdlib>
 #include <iostream>
 #include <thread>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 
 #include "BatchMultiBevGen.h"
 #include "LabelStep.h"
@@ -53,13 +57,56 @@ int main(int argc, char **argv)
     const int batch = std::max(1, std::atoi(std::getenv("BEV_BATCH") ? std::getenv("BEV_BATCH") : "32"));
     const bool png = std::getenv("BEV_NO_PNG") == nullptr;
 
-    /* Step 1: frames are independent -> contiguous shards of the sorted list, one GPU each */
+    /* Step 1: frames are independent -> contiguous shards of the sorted list, one GPU each.  GPU 0 owns
+     * the frame-range table; the other GPUs get it by an RCCL broadcast (over xGMI on a multi-GPU node) —
+     * the only inter-GPU communication of the whole tool. */
     std::vector<double> ms(n_dev, 0.0);
     std::vector<int> bad(n_dev, 0);
     std::vector<std::thread> workers;
     const size_t F = files.size();
+    std::vector<int64_t> ranges(2 * (size_t)n_dev, 0);
+    {
+        std::vector<int64_t> table(2 * (size_t)n_dev);
+        for (int d = 0; d < n_dev; ++d) {
+            table[2 * d] = (int64_t)(F * d / n_dev);
+            table[2 * d + 1] = (int64_t)(F * (d + 1) / n_dev) - table[2 * d];
+        }
+        std::vector<int> devs(n_dev);
+        std::vector<ncclComm_t> comms(n_dev);
+        std::vector<hipStream_t> streams(n_dev);
+        std::vector<int64_t *> bufs(n_dev, nullptr);
+        for (int d = 0; d < n_dev; ++d) devs[d] = d;
+        bool ok = ncclCommInitAll(comms.data(), n_dev, devs.data()) == ncclSuccess;
+        for (int d = 0; ok && d < n_dev; ++d) {
+            ok = hipSetDevice(d) == hipSuccess && hipStreamCreate(&streams[d]) == hipSuccess &&
+                 hipMalloc((void **)&bufs[d], table.size() * sizeof(int64_t)) == hipSuccess;
+            if (ok && d == 0)
+                ok = hipMemcpy(bufs[0], table.data(), table.size() * sizeof(int64_t), hipMemcpyHostToDevice) == hipSuccess;
+        }
+        if (ok) {
+            ncclGroupStart();
+            for (int d = 0; d < n_dev; ++d)
+                ok = ok && ncclBroadcast(bufs[d], bufs[d], table.size(), ncclInt64, 0, comms[d], streams[d]) == ncclSuccess;
+            ncclGroupEnd();
+        }
+        for (int d = 0; ok && d < n_dev; ++d) {
+            ok = hipSetDevice(d) == hipSuccess && hipStreamSynchronize(streams[d]) == hipSuccess;
+            /* every GPU reads ITS row from ITS copy of the table */
+            if (ok) ok = hipMemcpy(&ranges[2 * d], bufs[d] + 2 * d, 2 * sizeof(int64_t), hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        for (int d = 0; d < n_dev; ++d) {
+            if (bufs[d]) { (void)hipSetDevice(d); (void)hipFree(bufs[d]); (void)hipStreamDestroy(streams[d]); }
+        }
+        if (!ok) {
+            std::cerr << "no usable HIP device / RCCL broadcast of the frame ranges failed (GPUs requested: " << n_dev
+                      << "); there is no CPU path\n";
+            return 1;
+        }
+        for (int d = 0; d < n_dev; ++d) ncclCommDestroy(comms[d]);
+        (void)hipSetDevice(0);
+    }
     for (int d = 0; d < n_dev; ++d) {
-        const size_t first = F * d / n_dev, count = F * (d + 1) / n_dev - first;
+        const size_t first = (size_t)ranges[2 * d], count = (size_t)ranges[2 * d + 1];
         workers.emplace_back([&, d, first, count]() {
             BatchMultiBevGen gen(root, argv[2], d, batch);
             if (!gen.ok()) { bad[d] = 1; return; }
