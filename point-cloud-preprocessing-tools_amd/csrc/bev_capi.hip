@@ -65,6 +65,8 @@ struct bev_ctx {
     int n_lanes = 1;
     bool fast_path = false; /* BEV_FAST=1 enables the (experimental) sorted-prefix fast path */
     hipEvent_t fork_ev = nullptr;
+    hipEvent_t stagger_ev = nullptr; /* recorded on a lane after its bandwidth-bound kernels */
+    bool staggered[kMaxLanes] = {false, false, false, false};
     uint32_t *winner = nullptr;
     uint32_t *codes = nullptr;
     size_t codes_elems = 0;
@@ -330,6 +332,18 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                 launch_gather_ground(g, b, nb, STRIP_GENERAL, c->fast_path, st);
             }
         }
+        /* One-time stagger: a lane's FIRST sub-batch starts only after the previous lane has issued its
+         * bandwidth-bound kernels (order scan + column walk), so that from then on one lane's latency-bound
+         * per-frame kernels run beside the other lane's streaming kernels instead of in lock-step. */
+        if (c->n_lanes > 1 && !fork) {
+            const int li = sub % lanes_used;
+            HIPCK(c, hipEventRecord(c->stagger_ev, st));
+            const int nxt = (li + 1) % lanes_used;
+            if (nxt != li && !c->staggered[nxt]) {
+                HIPCK(c, hipStreamWaitEvent(c->lanes[nxt].st, c->stagger_ev, 0));
+                c->staggered[nxt] = true;
+            }
+        }
         {
             ProfScope ps(c, K_CELL_SUMS, nb, st);
             launch_cell_sums(g, b, nb, st);
@@ -488,6 +502,8 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         c->fast_path = fp && atoi(fp) != 0;
     }
     CK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+    CK(hipEventCreateWithFlags(&c->stagger_ev, hipEventDisableTiming));
+    c->staggered[0] = true;
     /* Streams of equal priority may be multiplexed onto ONE hardware queue (observed:
      * two such lanes never overlapped); streams of different priority get different
      * queues, so each lane takes its own priority level where the device has enough. */
@@ -544,6 +560,7 @@ void bev_destroy(bev_ctx_t *c)
         if (ln.st) (void)hipStreamDestroy(ln.st);
     }
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->stagger_ev) (void)hipEventDestroy(c->stagger_ev);
     void *dev[] = {c->st_in, c->st_ordered, c->st_multi, c->st_single, c->st_gm};
     for (void *p : dev)
         if (p) (void)hipFree(p);
