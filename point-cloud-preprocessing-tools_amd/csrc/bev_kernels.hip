@@ -353,9 +353,11 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     };
 
     /* ---- fast mode: the winners of a row come from the tile's own input range ---- */
-    __shared__ uint32_t idx[2][kStripThreads]; /* row q -> idx[q & 1][pos] = input index + 1 of virtual column pos */
+    /* (sized 1 in the other modes: the general walk keeps its LDS under 1 KiB so that 7 of its workgroups
+     * fit beside a 151 KiB cell-sum workgroup on one CU) */
+    __shared__ uint32_t idx[2][kFast ? kStripThreads : 1]; /* row q -> idx[q & 1][pos] = input index + 1 of virtual column pos */
     constexpr int kMaxRowsLds = 128;           /* rows whose tile bounds are staged in LDS (else read from global) */
-    __shared__ uint32_t bnd_lds[kMaxRowsLds][3]; /* per row: tile start, tile end, row start */
+    __shared__ uint32_t bnd_lds[kFast ? kMaxRowsLds : 1][3]; /* per row: tile start, tile end, row start */
     const uint32_t M = kFast ? b.fast_len[f] : 0u;
     const uint32_t *bnd = kFast ? b.bounds + (size_t)f * (g.rs_tiles + 1) : nullptr;
     const bool bnd_staged = kFast && N <= kMaxRowsLds;
