@@ -169,6 +169,18 @@ int bev_float_bev(bev_ctx_t *ctx, const bev_point_t *cloud, uint32_t n, float in
                   int skip_label0, float *out);
 size_t bev_float_bev_size(float interval); /* M for a given interval (0 if unsupported) */
 
+/* Range-image projection of raw XYZI returns — the selectors' row / col assignment ("polar binning"):
+ *   BEV_PROJECT_MULRAN_OS1_64   extractPointCloud, MulranPointCloudSelect.cpp:112-130:
+ *                               xyzi = n * (x, y, z, intensity); row = k % 64, col from the azimuth (0..1024)
+ *   BEV_PROJECT_OXFORD_HDL_32E  extractPointCloud, OxfordPointCloudSelect.cpp:172-218:
+ *                               xyzi = x[n] y[n] z[n] intensity[n]; x and z are negated, row from the
+ *                               elevation (0..31), col from the azimuth (0..1055)
+ * out: n points with label = -2; t and padding are 0 (the reference leaves them uninitialised).
+ * atan2f is evaluated on the device by a restatement of glibc's algorithm (bit-identical, csrc/bev_libm.h). */
+#define BEV_PROJECT_MULRAN_OS1_64 0
+#define BEV_PROJECT_OXFORD_HDL_32E 1
+int bev_project_xyzi(bev_ctx_t *ctx, int kind, const float *xyzi, uint32_t n, bev_point_t *out);
+
 /* ---- measurement ------------------------------------------------------- */
 #define BEV_MAX_KERNELS 16
 typedef struct bev_kernel_stat {

@@ -266,3 +266,52 @@ void oracle_float_bev(const oracle_point_t *cloud, size_t n, float interval,
         if (h > out[(size_t)x * M + y]) out[(size_t)x * M + y] = h;
     }
 }
+
+/* x86-64 static_cast<uint16_t>(float): cvttss2si, low 16 bits */
+static uint16_t cvtt_f32_to_u16(float v) { return (uint16_t)(uint32_t)cvtt_f32_to_i32(v); }
+
+/* MulranPointCloudSelect.cpp:112-130 (float overloads of atan2 / round: the file is compiled with
+ * "using namespace std") */
+void oracle_project_mulran(const float *xyzi, size_t n, oracle_point_t *out)
+{
+    for (size_t k = 0; k < n; ++k) {
+        oracle_point_t p;
+        memset(&p, 0, sizeof p);
+        p.x = xyzi[4 * k];           /* :116-119 */
+        p.y = xyzi[4 * k + 1];
+        p.z = xyzi[4 * k + 2];
+        p.intensity = xyzi[4 * k + 3];
+        p.row = (uint16_t)(k % 64);  /* :120 */
+        float az = (float)((double)atan2f(p.y, p.x) / M_PI * 180.0f); /* :121 */
+        if (az > 360.0f) az = az - 360.0f;       /* :122 */
+        else if (az < 0.0f) az = az + 360.0f;    /* :123 */
+        p.col = cvtt_f32_to_u16(roundf(az / 360.0f * 1024)); /* :125 */
+        p.label = -2;                /* :126 */
+        out[k] = p;
+    }
+}
+
+/* OxfordPointCloudSelect.cpp:172-218 */
+void oracle_project_oxford(const float *xyzi, size_t n, oracle_point_t *out)
+{
+    for (size_t i = 0; i < n; ++i) {
+        oracle_point_t p;
+        memset(&p, 0, sizeof p);
+        p.x = -xyzi[i];               /* :178, :203 the lidar is mounted upside-down */
+        p.y = xyzi[n + i];            /* :184 */
+        p.z = -xyzi[2 * n + i];       /* :189, :204 */
+        p.intensity = xyzi[3 * n + i];
+        p.label = -2;                 /* :206 */
+        float elev = (float)((double)atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)) / M_PI * 180.0f); /* :208 */
+        int row = cvtt_f64_to_i32(round(((double)(-elev) + 10.67) / 1.3335)); /* :209 */
+        if (row < 0) row = 0;         /* :210 std::min(31, std::max(0, row)) */
+        if (row > 31) row = 31;
+        p.row = (uint16_t)row;
+        float az = (float)((double)atan2f(p.y, p.x) / M_PI * 180.0f); /* :213 */
+        if (az > 360.0f) az = az - 360.0f;
+        else if (az < 0.0f) az = az + 360.0f;
+        p.col = cvtt_f32_to_u16(roundf(az / 360.0f * 1056)); /* :216 */
+        if (p.col >= 1056) p.col -= 1056; /* :217 */
+        out[i] = p;
+    }
+}

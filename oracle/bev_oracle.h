@@ -98,6 +98,13 @@ void oracle_process_frame(const oracle_sensor_t *sp, const oracle_point_t *in,
 void oracle_float_bev(const oracle_point_t *cloud, size_t n, float interval,
                       int skip_label0, float *out);
 
+/* Range-image projection of the keyframe selectors ("next" row N3).  The reference declares the point
+ * without initialising it, so t and the padding are indeterminate there; the oracle writes 0.
+ * MulRan (MulranPointCloudSelect.cpp:112-130): xyzi = n * (x, y, z, intensity) interleaved.
+ * Oxford (OxfordPointCloudSelect.cpp:172-218): xyzi = x[n] y[n] z[n] intensity[n] (four planes). */
+void oracle_project_mulran(const float *xyzi, size_t n, oracle_point_t *out);
+void oracle_project_oxford(const float *xyzi, size_t n, oracle_point_t *out);
+
 #ifdef __cplusplus
 }
 #endif

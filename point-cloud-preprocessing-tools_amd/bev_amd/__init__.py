@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "bev_create", "bev_destroy", "bev_strerror", "bev_last_error",
     "bev_process_batch", "bev_process_device_resident", "bev_synchronize",
     "bev_order_cloud", "bev_mark_ground", "bev_multi_bev", "bev_single_bev",
-    "bev_float_bev", "bev_float_bev_size",
+    "bev_float_bev", "bev_float_bev_size", "bev_project_xyzi",
     "bev_profile_enable", "bev_profile_reset", "bev_profile_get",
     "bev_debug_get_cell_avg", "bev_debug_get_fast_path", "bev_debug_angle_predicate", "bev_abi_version",
 ]
@@ -125,6 +125,7 @@ def load_lib() -> C.CDLL:
     lib.bev_float_bev.argtypes = [vp, vp, u32, C.c_float, i32, vp]
     lib.bev_float_bev_size.argtypes = [C.c_float]
     lib.bev_float_bev_size.restype = sz
+    lib.bev_project_xyzi.argtypes = [vp, i32, vp, u32, vp]
     lib.bev_profile_enable.argtypes = [vp, i32]
     lib.bev_profile_reset.argtypes = [vp]
     lib.bev_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32]
@@ -247,6 +248,15 @@ class BevContext:
         out = np.empty((M, M), dtype=np.float32)
         self._check(self.lib.bev_float_bev(self._h, _ptr(cloud) if len(cloud) else None, len(cloud), interval,
                                            1 if skip_label0 else 0, _ptr(out)), "bev_float_bev")
+        return out
+
+    def project_xyzi(self, kind: int, xyzi):
+        """kind 0: MulRan/Ouster (n, 4) interleaved; kind 1: Oxford (4, n) planes."""
+        xyzi = np.ascontiguousarray(xyzi, dtype=np.float32)
+        n = xyzi.size // 4
+        out = np.empty(n, dtype=POINT_DTYPE)
+        self._check(self.lib.bev_project_xyzi(self._h, kind, _ptr(xyzi) if n else None, n, _ptr(out) if n else None),
+                    "bev_project_xyzi")
         return out
 
     # ---- measurement / test hooks ------------------------------------------

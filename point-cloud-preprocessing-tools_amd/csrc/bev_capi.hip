@@ -733,6 +733,29 @@ int bev_single_bev(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, uint8_t *
     return raster_cloud(c, cloud, n, nullptr, single_out);
 }
 
+int bev_project_xyzi(bev_ctx_t *c, int kind, const float *xyzi, uint32_t n, bev_point_t *out)
+{
+    if (!c || (n && (!xyzi || !out))) return BEV_ERR_INVALID_ARG;
+    if (kind != BEV_PROJECT_MULRAN_OS1_64 && kind != BEV_PROJECT_OXFORD_HDL_32E) return BEV_ERR_INVALID_ARG;
+    if ((size_t)n > std::max(c->max_points, (size_t)c->geo.S)) return BEV_ERR_TOO_LARGE;
+    if (n == 0) return BEV_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c);
+    if (rc != BEV_OK) return rc;
+    /* raw floats are staged in the ordered-cloud staging buffer (16 B per point fit its 32 B per slot) */
+    float *d_raw = reinterpret_cast<float *>(c->st_ordered);
+    if ((size_t)n * 16 > (size_t)c->max_batch * c->geo.S * sizeof(bev_point_t)) return BEV_ERR_TOO_LARGE;
+    HIPCK(c, hipMemcpyAsync(d_raw, xyzi, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, K_PROJECT, 1);
+        launch_project(kind, d_raw, n, c->st_in, c->stream);
+    }
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(out, c->st_in, (size_t)n * sizeof(bev_point_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BEV_OK;
+}
+
 size_t bev_float_bev_size(float interval)
 {
     if (!(interval > 0.0f)) return 0;

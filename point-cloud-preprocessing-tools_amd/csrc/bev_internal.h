@@ -89,6 +89,7 @@ enum KernelId {
     K_CLOUD_CODES,
     K_ANGLE_DEBUG,
     K_FLOAT_BEV,
+    K_PROJECT,
     K_PREFIX_LEN,
     K_PREFIX_BOUNDS,
     K_TAIL_ZERO,
@@ -117,6 +118,7 @@ void launch_ground_mat(const Geometry &g, const BatchPtrs &b, int8_t *out, int n
 void launch_cloud_codes(const Geometry &g, const bev_point_t *cloud, uint32_t n, uint32_t *codes, hipStream_t st);
 void launch_float_bev(const bev_point_t *cloud, uint32_t n, float interval, int M, bool skip_label0, float *grid,
                       hipStream_t st);
+void launch_project(int kind, const float *xyzi, uint32_t n, bev_point_t *out, hipStream_t st);
 void launch_angle_debug(const float *dx, const float *dy, const float *dz, uint8_t *out, size_t n, hipStream_t st);
 /* opt in to > 64 KiB of dynamic LDS for the two kernels that need it */
 hipError_t configure_kernels(const Geometry &g);

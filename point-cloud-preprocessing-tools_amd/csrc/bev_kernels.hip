@@ -23,6 +23,7 @@
  *     sequentially (a tree or atomic float reduction would change low bits).
  */
 #include "bev_internal.h"
+#include "bev_libm.h"
 
 using namespace bevx;
 
@@ -30,7 +31,7 @@ namespace bevk {
 
 static const char *const kNames[K_COUNT] = {
     "k_order_scan", "k_strip_ground", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
-    "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev",
+    "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project",
     "k_prefix_len", "k_prefix_bounds", "k_tail_zero", "k_tail_scan", "k_strip_ground_fast", "k_winner_zero_failed",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
@@ -1011,6 +1012,31 @@ __global__ __launch_bounds__(256) void k_float_bev(const bev_point_t *__restrict
     if (h > 0.0f) atomicMax(&grid[(size_t)x * M + y], __float_as_uint(h)); /* "h > cell" with cells >= 0 */
 }
 
+/* Range-image projection of raw returns (see bev_libm.h): one thread per point. */
+__global__ __launch_bounds__(256) void k_project(int kind, const float *__restrict__ xyzi, uint32_t n,
+                                                 bev_point_t *__restrict__ out)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n) return;
+    float x, y, z, it;
+    uint16_t row, col;
+    if (kind == BEV_PROJECT_MULRAN_OS1_64) {
+        const float4 v = reinterpret_cast<const float4 *>(xyzi)[k];
+        x = v.x; y = v.y; z = v.z; it = v.w;
+        project_mulran(k, x, y, row, col);
+    } else {
+        x = -xyzi[k]; y = xyzi[(size_t)n + k]; z = -xyzi[2 * (size_t)n + k]; it = xyzi[3 * (size_t)n + k];
+        project_oxford(x, y, z, row, col);
+    }
+    Half lo, hi;
+    lo.w[0] = __float_as_uint(x); lo.w[1] = __float_as_uint(y); lo.w[2] = __float_as_uint(z); lo.w[3] = 0u;
+    hi.w[0] = __float_as_uint(it); hi.w[1] = (uint32_t)row | ((uint32_t)col << 16); hi.w[2] = 0u;
+    hi.w[3] = (uint32_t)(uint16_t)(int16_t)-2; /* label = -2 */
+    Half *dst = reinterpret_cast<Half *>(out + k);
+    dst[0] = lo;
+    dst[1] = hi;
+}
+
 /* test hook: the phase-A angle predicate on raw difference vectors */
 __global__ __launch_bounds__(256) void k_angle_debug(const float *dx, const float *dy, const float *dz,
                                                      uint8_t *out, size_t n)
@@ -1107,6 +1133,11 @@ void launch_float_bev(const bev_point_t *cloud, uint32_t n, float interval, int 
     if (n == 0) return;
     hipLaunchKernelGGL(k_float_bev, dim3((n + 255u) / 256u), dim3(256), 0, st, cloud, n, interval, M,
                        skip_label0 ? 1 : 0, reinterpret_cast<uint32_t *>(grid));
+}
+void launch_project(int kind, const float *xyzi, uint32_t n, bev_point_t *out, hipStream_t st)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_project, dim3((n + 255u) / 256u), dim3(256), 0, st, kind, xyzi, n, out);
 }
 void launch_angle_debug(const float *dx, const float *dy, const float *dz, uint8_t *out, size_t n, hipStream_t st)
 {

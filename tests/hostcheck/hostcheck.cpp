@@ -15,6 +15,7 @@
 
 #include "../../include/bev_mi355x.h"
 #include "../../point-cloud-preprocessing-tools_amd/csrc/bev_exact.h"
+#include "../../point-cloud-preprocessing-tools_amd/csrc/bev_libm.h"
 
 using namespace bevx;
 
@@ -163,6 +164,62 @@ void hc_exhaustive_exact_forms(uint64_t *out)
         if ((f >= 0.3f) != ((double)f > 0.30)) ++m4;
     }
     out[0] = m0; out[1] = m1; out[2] = m2; out[3] = m3; out[4] = m4;
+}
+
+/* bev_libm.h against the host libm: out[0] = atanf mismatches over ALL 2^32 floats,
+ * out[1] = atan2f mismatches over n random / structured pairs + special values (NaN == NaN). */
+void hc_libm_vs_host(uint64_t n, uint64_t *out)
+{
+    uint64_t b0 = 0, b1 = 0;
+#pragma omp parallel for reduction(+ : b0) schedule(static)
+    for (int64_t u = 0; u <= 0xffffffffLL; ++u) {
+        const float x = bits_to_float((uint32_t)u);
+        const float a = atanf(x), b = fd_atanf(x);
+        if (float_bits(a) != float_bits(b) && !(a != a && b != b)) ++b0;
+    }
+#pragma omp parallel for reduction(+ : b1) schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        uint64_t z = 0x243f6a8885a308d3ULL + 0x9e3779b97f4a7c15ULL * (uint64_t)(i + 1);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; z ^= z >> 31;
+        uint64_t z2 = (z + 0x9e3779b97f4a7c15ULL); z2 = (z2 ^ (z2 >> 30)) * 0xbf58476d1ce4e5b9ULL; z2 ^= z2 >> 29;
+        float y, x;
+        switch (z & 3) {
+        case 0: y = bits_to_float((uint32_t)(z >> 32)); x = bits_to_float((uint32_t)z2); break; /* any bit patterns */
+        case 1: y = ((int)((z >> 8) & 0xfffff) - 524288) / 1024.0f; x = ((int)((z >> 28) & 0xfffff) - 524288) / 1024.0f; break;
+        default: {
+            const float sc = std::ldexp(1.0f, (int)((z >> 4) % 80) - 40);
+            y = sc * ((int)((z >> 16) & 0xffff) - 32768) / 777.0f;
+            x = ((int)((z >> 32) & 0xffff) - 32768) / 333.0f / sc;
+        }
+        }
+        const float a = atan2f(y, x), b = fd_atan2f(y, x);
+        if (float_bits(a) != float_bits(b) && !(a != a && b != b)) ++b1;
+    }
+    const float sp[] = {0.0f, -0.0f, 1.0f, -1.0f, INFINITY, -INFINITY, NAN, 1e-45f, -1e-45f, 3.4e38f, -3.4e38f, 1e-38f, 2.0f, 0.5f};
+    for (float yy : sp)
+        for (float xx : sp) {
+            const float a = atan2f(yy, xx), b = fd_atan2f(yy, xx);
+            if (float_bits(a) != float_bits(b) && !(a != a && b != b)) ++b1;
+        }
+    out[0] = b0; out[1] = b1;
+}
+
+/* the projection helpers of bev_libm.h on the host: kind 0 MulRan (interleaved), 1 Oxford (planes) */
+void hc_project(int kind, const float *xyzi, uint32_t n, bev_point_t *out)
+{
+    for (uint32_t k = 0; k < n; ++k) {
+        bev_point_t p;
+        memset(&p, 0, sizeof p);
+        if (kind == 0) {
+            p.x = xyzi[4 * k]; p.y = xyzi[4 * k + 1]; p.z = xyzi[4 * k + 2]; p.intensity = xyzi[4 * k + 3];
+            project_mulran(k, p.x, p.y, p.row, p.col);
+        } else {
+            p.x = -xyzi[k]; p.y = xyzi[(size_t)n + k]; p.z = -xyzi[2 * (size_t)n + k]; p.intensity = xyzi[3 * (size_t)n + k];
+            project_oxford(p.x, p.y, p.z, p.row, p.col);
+        }
+        p.label = -2;
+        out[k] = p;
+    }
 }
 
 /* Whole frame, composed like the kernels. gm_phase_a / gm_final / avg may be NULL. */

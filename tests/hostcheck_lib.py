@@ -25,6 +25,10 @@ def lib():
         l.hc_bev_code.restype = C.c_uint32
         l.hc_process_frame.argtypes = [C.POINTER(BevParams), vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
         l.hc_process_frame.restype = None
+        l.hc_libm_vs_host.argtypes = [C.c_uint64, vp]
+        l.hc_libm_vs_host.restype = None
+        l.hc_project.argtypes = [C.c_int, vp, C.c_uint32, vp]
+        l.hc_project.restype = None
         l.hc_exhaustive_exact_forms.argtypes = [vp]
         l.hc_exhaustive_exact_forms.restype = None
         l.hc_derive_angle_threshold.argtypes = [vp]
@@ -56,3 +60,11 @@ def process_frame(p: BevParams, pts):
     lib().hc_process_frame(C.byref(p), pts.ctypes.data, len(pts), ordered.ctypes.data, gm_a.ctypes.data,
                            gm.ctypes.data, avg.ctypes.data, multi.ctypes.data, single.ctypes.data)
     return ordered, gm, avg, multi, single
+
+
+def project(kind: int, xyzi):
+    xyzi = np.ascontiguousarray(xyzi, np.float32)
+    n = xyzi.size // 4
+    out = np.empty(n, POINT_DTYPE)
+    lib().hc_project(kind, xyzi.ctypes.data, n, out.ctypes.data)
+    return out

@@ -41,6 +41,10 @@ def lib():
         l.oracle_process_frame.restype = None
         l.oracle_float_bev.argtypes = [vp, sz, C.c_float, C.c_int, vp]
         l.oracle_float_bev.restype = None
+        l.oracle_project_mulran.argtypes = [vp, sz, vp]
+        l.oracle_project_mulran.restype = None
+        l.oracle_project_oxford.argtypes = [vp, sz, vp]
+        l.oracle_project_oxford.restype = None
         _lib = l
     return _lib
 
@@ -109,4 +113,12 @@ def float_bev(cloud: np.ndarray, interval: float = 1.0, skip_label0: bool = True
     M = int(np.float32(np.float32(200) / np.float32(interval)) + np.float32(1))
     out = np.empty((M, M), dtype=np.float32)
     lib().oracle_float_bev(cloud.ctypes.data, len(cloud), interval, 1 if skip_label0 else 0, out.ctypes.data)
+    return out
+
+
+def project(kind: int, xyzi: np.ndarray) -> np.ndarray:
+    xyzi = np.ascontiguousarray(xyzi, dtype=np.float32)
+    n = xyzi.size // 4
+    out = np.empty(n, dtype=POINT_DTYPE)
+    (lib().oracle_project_mulran if kind == 0 else lib().oracle_project_oxford)(xyzi.ctypes.data, n, out.ctypes.data)
     return out

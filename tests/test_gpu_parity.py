@@ -191,3 +191,24 @@ def test_float_bev(ctxs, sensor):
             # north_star allows 1e-5 on float height channels; a max has no rounding, so demand equality
             assert got.tobytes() == want.tobytes(), (interval, skip, np.abs(got - want).max())
     assert ctx.float_bev(marked, 1.0, True).shape == (201, 201)
+
+
+# ---- range-image projection of raw XYZI returns (atan2f restated on the device) ----
+@pytest.mark.parametrize("kind", [0, 1])
+def test_projection_matches_oracle(ctxs, kind):
+    from projection_data import raw_returns
+
+    p, ctx = ctxs("OS1_64" if kind == 0 else "HDL_32E", 4, 300000)
+    for seed in (0, 1):
+        pts = raw_returns(250_000, seed)
+        xyzi = pts if kind == 0 else np.ascontiguousarray(pts.T)
+        got = ctx.project_xyzi(kind, xyzi)
+        want = orc.project(kind, xyzi)
+        assert got.tobytes() == want.tobytes(), np.flatnonzero((got["col"] != want["col"]) | (got["row"] != want["row"]))[:8]
+    # projected returns feed the hot path like any selector output
+    sp = orc.sensor_from_params(p)
+    cloud = ctx.project_xyzi(kind, xyzi)[:65536 if kind == 0 else 120000]
+    ordered, multi, single, gm = ctx.process_batch([cloud], want_ground_mat=True)
+    o_ord, o_gm, o_multi, o_single = orc.process_frame(sp, cloud)
+    assert ordered[0].tobytes() == o_ord.tobytes() and np.array_equal(gm[0], o_gm)
+    assert np.array_equal(multi[0], o_multi) and np.array_equal(single[0], o_single)
