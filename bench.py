@@ -137,9 +137,6 @@ def main() -> int:
     for _ in range(args.warmup):
         step()
     fence()
-    if not args.no_profile:
-        ctx.profile_enable(True)
-        ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -148,8 +145,21 @@ def main() -> int:
     elapsed = shard.max_over_ranks(elapsed, world, device=dev, force_collective=use_dist)
     total_frames = shard.sum_over_ranks(float(count * args.steps), world, device=dev, force_collective=use_dist)
 
-    # ---- per-kernel HIP-event durations of the timed region (rank 0's stream)
-    stats = [] if args.no_profile else ctx.profile_get()
+    # ---- roofline pass: the same steps again with ONE lane, every launch bracketed by HIP events on its
+    # stream.  In the timed region two sub-batch lanes overlap, which makes a single kernel's duration depend
+    # on what the other lane happens to run beside it; back to back, a launch's duration is its own.
+    stats = []
+    if not args.no_profile:
+        lanes_timed = ctx.set_lanes(1)
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        for _ in range(args.steps):
+            step()
+        fence()
+        stats = ctx.profile_get()
+        ctx.profile_enable(False)
+
+    # ---- per-kernel HIP-event durations of the roofline pass (this rank)
     mean_pts = total_pts / count
     b_frame = bev_amd.algorithmic_bytes_per_frame(p, mean_pts)  # 32P + 32S + L*M*M + M*M
     # which part of B_frame each kernel is the one to move (DESIGN.md "Kernels")
@@ -192,7 +202,8 @@ def main() -> int:
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
             "kernel": dom["name"], "frames_per_launch": per_launch_frames,
             "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": avg_ms,
-            "note": "kernels of two sub-batch lanes overlap in the timed region, so a launch shares the GPU with the other lane's kernels",
+            "note": "kernel durations from a one-lane pass of the same steps right after the timed region (back-to-back launches); "
+                    "the timed region itself runs two overlapping sub-batch lanes",
             "pipeline": {"bytes_per_frame": b_frame, "achieved": pipe_achieved, "frac": pipe_achieved / HBM_PEAK_GBPS,
                          "definition": "algorithmic bytes of the whole hot path / wall time of the timed region, this GPU"},
         }

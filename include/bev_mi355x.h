@@ -182,6 +182,11 @@ size_t bev_float_bev_size(float interval); /* M for a given interval (0 if unsup
 int bev_project_xyzi(bev_ctx_t *ctx, int kind, const float *xyzi, uint32_t n, bev_point_t *out);
 
 /* ---- measurement ------------------------------------------------------- */
+/* Sub-batches of bev_process_* are dealt to up to BEV_LANES (default 2, max 4) streams so that kernels of
+ * consecutive sub-batches overlap.  bev_set_lanes(ctx, 1) makes them run back to back (clean per-kernel
+ * durations for profiling); returns the number of lanes now in use, or a negative status. */
+int bev_set_lanes(bev_ctx_t *ctx, int n);
+
 #define BEV_MAX_KERNELS 16
 typedef struct bev_kernel_stat {
     const char *name;      /* kernel symbol as rocprofv3 prints it */

@@ -73,7 +73,7 @@ ABI_SYMBOLS = [
     "bev_process_batch", "bev_process_device_resident", "bev_synchronize",
     "bev_order_cloud", "bev_mark_ground", "bev_multi_bev", "bev_single_bev",
     "bev_float_bev", "bev_float_bev_size", "bev_project_xyzi",
-    "bev_profile_enable", "bev_profile_reset", "bev_profile_get",
+    "bev_set_lanes", "bev_profile_enable", "bev_profile_reset", "bev_profile_get",
     "bev_debug_get_cell_avg", "bev_debug_get_fast_path", "bev_debug_angle_predicate", "bev_abi_version",
 ]
 
@@ -126,6 +126,7 @@ def load_lib() -> C.CDLL:
     lib.bev_float_bev_size.argtypes = [C.c_float]
     lib.bev_float_bev_size.restype = sz
     lib.bev_project_xyzi.argtypes = [vp, i32, vp, u32, vp]
+    lib.bev_set_lanes.argtypes = [vp, i32]
     lib.bev_profile_enable.argtypes = [vp, i32]
     lib.bev_profile_reset.argtypes = [vp]
     lib.bev_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32]
@@ -260,6 +261,12 @@ class BevContext:
         return out
 
     # ---- measurement / test hooks ------------------------------------------
+    def set_lanes(self, n: int) -> int:
+        r = self.lib.bev_set_lanes(self._h, n)
+        if r < 0:
+            self._check(r, "bev_set_lanes")
+        return r
+
     def profile_enable(self, on=True):
         self._check(self.lib.bev_profile_enable(self._h, 1 if on else 0), "bev_profile_enable")
 

@@ -63,6 +63,7 @@ struct bev_ctx {
     /* per-lane sub-batch workspace; the aliases below are lane 0's */
     Lane lanes[kMaxLanes];
     int n_lanes = 1;
+    int n_lanes_active = 1; /* <= n_lanes; bev_set_lanes */
     bool fast_path = false; /* BEV_FAST=1 enables the (experimental) sorted-prefix fast path */
     hipEvent_t fork_ev = nullptr;
     hipEvent_t stagger_ev = nullptr; /* recorded on a lane after its bandwidth-bound kernels */
@@ -262,7 +263,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
      * host->device copies of the host-buffer entry points).  The device-resident entry point has nothing
      * on the main stream to wait for, so its lanes free-run from call to call and stay staggered. */
     const int n_sub = (n_frames + c->max_batch - 1) / c->max_batch;
-    const int lanes_used = std::min(c->n_lanes, n_sub);
+    const int lanes_used = std::min(c->n_lanes_active, n_sub);
     if (fork) {
         HIPCK(c, hipEventRecord(c->fork_ev, c->stream));
         for (int l = 0; l < lanes_used; ++l) HIPCK(c, hipStreamWaitEvent(c->lanes[l].st, c->fork_ev, 0));
@@ -335,7 +336,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         /* One-time stagger: a lane's FIRST sub-batch starts only after the previous lane has issued its
          * bandwidth-bound kernels (order scan + column walk), so that from then on one lane's latency-bound
          * per-frame kernels run beside the other lane's streaming kernels instead of in lock-step. */
-        if (c->n_lanes > 1 && !fork) {
+        if (lanes_used > 1 && !fork) {
             const int li = sub % lanes_used;
             HIPCK(c, hipEventRecord(c->stagger_ev, st));
             const int nxt = (li + 1) % lanes_used;
@@ -498,6 +499,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         const char *e = getenv("BEV_LANES");
         int nl = e ? atoi(e) : 2;
         c->n_lanes = std::max(1, std::min(kMaxLanes, nl));
+        c->n_lanes_active = c->n_lanes;
         const char *fp = getenv("BEV_FAST");
         c->fast_path = fp && atoi(fp) != 0;
     }
@@ -785,6 +787,16 @@ int bev_float_bev(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, float inte
     HIPCK(c, hipMemcpyAsync(out, grid, M * M * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BEV_OK;
+}
+
+int bev_set_lanes(bev_ctx_t *c, int n)
+{
+    if (!c || n < 1) return BEV_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    for (int l = 0; l < c->n_lanes; ++l) HIPCK(c, hipStreamSynchronize(c->lanes[l].st));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->n_lanes_active = std::min(n, c->n_lanes);
+    return c->n_lanes_active;
 }
 
 int bev_profile_enable(bev_ctx_t *c, int on)

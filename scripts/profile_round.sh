@@ -3,8 +3,9 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 TAG=${1:-r01}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-# 1. kernel trace + stats under the default bench command line (plus --no-cpu to keep it short)
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu > $OUT/bench_under_rocprof.log 2>&1
+# 1. kernel trace + stats of the bench command line with ONE lane (BEV_LANES=1): every launch runs back to back, like in
+#    bench.py's roofline pass, so AverageNs is comparable with roofline.avg_launch_ms
+BEV_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu > $OUT/bench_under_rocprof.log 2>&1
 # 2. plain bench (with the CPU baseline)
 timeout 900 python3 bench.py --steps 5 --warmup 2 > $OUT/bench.log 2>&1
 # 3. PMC passes, one counter group per run (no trace domains mixed in)
