@@ -357,6 +357,7 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     /* (sized 1 in the other modes: the general walk keeps its LDS under 1 KiB so that 7 of its workgroups
      * fit beside a 151 KiB cell-sum workgroup on one CU) */
     __shared__ uint32_t idx[2][kFast ? kStripThreads : 1]; /* row q -> idx[q & 1][pos] = input index + 1 of virtual column pos */
+    __shared__ Half rowpts[2][kFast ? kStripThreads : 1][2]; /* ... and the point itself (lo, hi halves) */
     constexpr int kMaxRowsLds = 128;           /* rows whose tile bounds are staged in LDS (else read from global) */
     __shared__ uint32_t bnd_lds[kFast ? kMaxRowsLds : 1][3]; /* per row: tile start, tile end, row start */
     const uint32_t M = kFast ? b.fast_len[f] : 0u;
@@ -371,17 +372,40 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     }
     const uint32_t *bits = kFast ? b.tail_bits + (size_t)f * g.bit_words : nullptr;
     const bool last_strip = strip == g.strips - 1;
+    /* override bitmap of this strip, staged once: per row the 10 words that cover its 256 virtual columns
+     * (plus, for the last strip, the word of the wrapped columns 0 and 1) */
+    constexpr int kBitWords = 10;
+    __shared__ uint32_t tbits[kFast ? kMaxRowsLds : 1][kBitWords + 1];
+    if (bnd_staged) {
+        for (int e = tid; e < N * (kBitWords + 1); e += kStripThreads) {
+            const int q = e / (kBitWords + 1), k = e - q * (kBitWords + 1);
+            uint32_t wv_ = 0u;
+            if (k < kBitWords) {
+                const int first = q * H + strip * kStripCols - 2;          /* may be negative for q = 0 */
+                const int wi = (first >= 0 ? first >> 5 : -1) + k;
+                if (wi >= 0 && wi < g.bit_words) wv_ = bits[wi];
+            } else {
+                wv_ = bits[(q * H) >> 5];                                   /* columns 0, 1 of the row */
+            }
+            tbits[q][k] = wv_;
+        }
+    }
     bool my_fail = false;
-    /* candidate of thread tid for row q: input index ci (< 0: none) and its slot cs */
-    struct Key { int ci; uint32_t cs; int cnt; bool wrap; };
-    auto load_key = [&](int q) -> Key {
-        Key k{-1, 0xffffffffu, 0, false};
+    /* Candidate of thread tid for row q: the input point at index ci (< 0: none), loaded WHOLE and fully
+     * coalesced (consecutive threads read consecutive input points: 8 KiB per row), then dropped into the LDS
+     * row buffer at the virtual column its row / col fields say. */
+    struct Cand { int ci; int cnt; bool wrap; uint32_t prev_slot; Half lo, hi; };
+    auto load_cand = [&](int q) -> Cand {
+        Cand k;
+        k.ci = -1; k.cnt = 0; k.wrap = false; k.prev_slot = 0xffffffffu;
+        k.lo = Half{{0, 0, 0, 0}};
+        k.hi = Half{{0, 0, 0, 0}};
         if (q >= N) return k;
         const uint32_t a = bnd_staged ? bnd_lds[q][0] : bnd[q * g.strips + strip];
         const uint32_t e = bnd_staged ? bnd_lds[q][1] : bnd[q * g.strips + strip + 1];
         const int cnt = (int)e - (int)a;
         k.cnt = cnt;
-        if (cnt < 0 || cnt > kStripCols) return k; /* flagged in place_key */
+        if (cnt < 0 || cnt > kStripCols) return k; /* flagged in place_cand */
         int ci = (int)a - 2 + tid;                 /* input indices fit 31 bits: bev_create caps max_points */
         if (last_strip && tid >= cnt + 2 && tid < cnt + 4) { /* right halo wraps to columns 0, 1 of the same row */
             ci = (int)(bnd_staged ? bnd_lds[q][2] : bnd[q * g.strips]) + (tid - (cnt + 2));
@@ -389,50 +413,89 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         }
         if (tid < cnt + 4 && ci >= 0 && ci < (int)M) {
             k.ci = ci;
-            k.cs = point_slot(fpts, (uint32_t)ci, N, H);
+            const Half *src = reinterpret_cast<const Half *>(fpts + ci);
+            k.lo = src[0];
+            k.hi = src[1];
+            /* a wave's first lane cannot get its left neighbour's slot by shuffle: fetch that key now */
+            if (lane == 0 && tid > 2 && ci > 0 && !k.wrap) k.prev_slot = point_slot(fpts, (uint32_t)ci - 1u, N, H);
         }
         return k;
     };
-    auto place_key = [&](int q, const Key &k) {
+    auto slot_of = [&](const Half &hi) -> uint32_t {
+        const uint32_t row = hi.w[1] & 0xffffu, col = hi.w[1] >> 16;
+        return (row < (uint32_t)N && col < (uint32_t)H) ? row * (uint32_t)H + col : 0xffffffffu;
+    };
+    auto place_cand = [&](int q, const Cand &k) {
         if (q >= N) return; /* workgroup-uniform */
+        const uint32_t cs = k.ci >= 0 ? slot_of(k.hi) : 0xffffffffu;
         /* slot of the candidate one thread to the left (the previous input point for main points) */
-        uint32_t cprev = __shfl_up(k.cs, 1);
-        if (lane == 0 && tid > 2 && k.ci > 0 && !k.wrap) cprev = point_slot(fpts, (uint32_t)k.ci - 1u, N, H);
+        uint32_t cprev = __shfl_up(cs, 1);
+        if (lane == 0) cprev = k.prev_slot;
         if (k.cnt < 0 || k.cnt > kStripCols) { my_fail = true; return; }
         if (k.ci < 0) return;
         const int base = q * H + strip * kStripCols - 2; /* flat slot of pos 0 (may be -2) */
         const bool main_pt = !k.wrap && tid >= 2 && tid < k.cnt + 2;
         int pos = -1;
-        if (k.cs != 0xffffffffu) {
+        if (cs != 0xffffffffu) {
             if (k.wrap) {
-                const int w = (int)k.cs - q * H; /* 0 or 1 expected */
+                const int w = (int)cs - q * H; /* 0 or 1 expected */
                 if (w >= 0 && w < 2) pos = H + w - (strip * kStripCols - 2);
-            } else if ((int)k.cs < (q + 1) * H) {
-                pos = (int)k.cs - base;
+            } else if ((int)cs < (q + 1) * H) {
+                pos = (int)cs - base;
             }
         }
         if (main_pt) {
-            /* verification: in the tile's own column range, strictly above the previous point */
+            /* verification: in the tile's own column range, strictly above the previous point.  With both
+             * true for every tile, [0, M) is strictly slot-sorted, so no two candidates share a position. */
             if (pos < 2 || pos >= 2 + kStripCols) { my_fail = true; return; }
-            if (tid > 2 && !(cprev != 0xffffffffu && cprev < k.cs)) { my_fail = true; return; }
+            if (tid > 2 && !(cprev != 0xffffffffu && cprev < cs)) { my_fail = true; return; }
         }
         if (pos >= 0 && pos < kStripThreads) {
-            const uint32_t old = atomicExch(&idx[q & 1][pos], (uint32_t)k.ci + 1u);
-            if (old != 0u) my_fail = true;
+            rowpts[q & 1][pos][0] = k.lo;
+            rowpts[q & 1][pos][1] = k.hi;
+            idx[q & 1][pos] = (uint32_t)k.ci + 1u;
         }
     };
     auto tail_word = [&](int q) -> uint32_t { /* override bitmap word of this thread's slot in row q */
         if (!provider || q >= N) return 0u;
         const int fl = q * H + vcol;
-        return fl >= 0 ? bits[fl >> 5] : 0u;
+        if (fl < 0) return 0u;
+        if (!bnd_staged) return bits[fl >> 5];
+        if (v >= H) return tbits[q][kBitWords];                             /* wrapped right halo */
+        const int first = q * H + strip * kStripCols - 2;
+        return tbits[q][(fl >> 5) - (first >= 0 ? first >> 5 : -1)];
     };
-    auto fast_winner = [&](int q, uint32_t word) -> uint32_t { /* after the barrier that follows place_key(q) */
-        uint32_t w = idx[q & 1][tid];
-        idx[q & 1][tid] = 0u;
-        if (!provider || q >= N) return 0u;
+    /* Tail overrides (a slot whose last writer sits in the tail [M, P)) are fetched ahead of time by the
+     * thread that owns the virtual column: the tail winner index three rows ahead, the point two rows ahead.
+     * Nearly every wave has some overridden lane in every row, so waiting for these loads where they are
+     * needed would stall every row. */
+    auto tail_bit = [&](int q) -> bool {
+        if (!provider || q >= N) return false;
         const int fl = q * H + vcol;
-        if (fl >= 0 && ((word >> (fl & 31)) & 1u)) w = fwin[fl]; /* a tail point owns this slot */
-        return w;
+        return fl >= 0 && ((tail_word(q) >> (fl & 31)) & 1u);
+    };
+    auto issue_tail_winner = [&](int q) -> uint32_t { return tail_bit(q) ? fwin[q * H + vcol] : 0u; };
+    auto issue_tail_point = [&](uint32_t w, Half &lo, Half &hi) {
+        if (w != 0u) {
+            const Half *src = reinterpret_cast<const Half *>(fpts + (w - 1u));
+            lo = src[0];
+            hi = src[1];
+        }
+    };
+    /* the point of this thread's virtual column in row q, after the barrier that follows place_cand(q) */
+    auto fast_point = [&](int q, uint32_t ovr_w, const Half &ovr_lo, const Half &ovr_hi, Half &lo, Half &hi) {
+        const uint32_t have = idx[q & 1][tid];
+        idx[q & 1][tid] = 0u;
+        lo = Half{{0, 0, 0, 0}};
+        hi = Half{{0, 0, 0, 0}};
+        if (!provider || q >= N) return;
+        if (ovr_w != 0u) { /* a tail point owns this slot (last writer wins) */
+            lo = ovr_lo;
+            hi = ovr_hi;
+        } else if (have != 0u) {
+            lo = rowpts[q & 1][tid][0];
+            hi = rowpts[q & 1][tid][1];
+        }
     };
     auto load_point = [&](uint32_t w, Half &lo, Half &hi) {
         lo = Half{{0, 0, 0, 0}};
@@ -448,23 +511,31 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     Half cur_lo, cur_hi, nxt_lo, nxt_hi;
     Half nx2_lo{{0, 0, 0, 0}}, nx2_hi{{0, 0, 0, 0}}; /* general/identity: point of row r+2 (two rows in flight) */
     uint32_t w_next = 0u, w_nx2 = 0u;                /* general/identity: winners of rows r+3 and r+4 */
-    /* fast: keys / bitmap words of rows r+3 and r+4 are in flight, like the points of rows r+1 and r+2 */
-    Key key_a{-1, 0xffffffffu, 0, false}, key_b{-1, 0xffffffffu, 0, false};
-    uint32_t word_a = 0u, word_b = 0u;
+    /* fast: candidates of rows r+1 and r+2 are in flight */
+    Cand cand_a, cand_b;
+    cand_a.ci = cand_b.ci = -1; cand_a.cnt = cand_b.cnt = 0; cand_a.wrap = cand_b.wrap = false;
+    cand_a.prev_slot = cand_b.prev_slot = 0xffffffffu;
+    cand_a.lo = cand_a.hi = cand_b.lo = cand_b.hi = Half{{0, 0, 0, 0}};
+    uint32_t ow_cur = 0u, ow_nxt = 0u, ow_far = 0u;   /* tail winners of rows r+1, r+2, r+3 (0: not overridden) */
+    Half oc_lo{{0, 0, 0, 0}}, oc_hi{{0, 0, 0, 0}}, on_lo{{0, 0, 0, 0}}, on_hi{{0, 0, 0, 0}}; /* their points: r+1, r+2 */
     if (kFast) {
         idx[0][tid] = 0u;
         idx[1][tid] = 0u;
+        __syncthreads(); /* also publishes bnd_lds / tbits */
+        const Cand c0 = load_cand(0);
+        cand_a = load_cand(1);
+        cand_b = load_cand(2);
+        const uint32_t ow0 = issue_tail_winner(0);
+        Half o0_lo{{0, 0, 0, 0}}, o0_hi{{0, 0, 0, 0}};
+        issue_tail_point(ow0, o0_lo, o0_hi);
+        ow_cur = issue_tail_winner(1);
+        issue_tail_point(ow_cur, oc_lo, oc_hi);
+        ow_nxt = issue_tail_winner(2);
+        issue_tail_point(ow_nxt, on_lo, on_hi);
+        ow_far = issue_tail_winner(3);
+        place_cand(0, c0);
         __syncthreads();
-        const Key k0 = load_key(0), k1 = load_key(1);
-        const uint32_t word0 = tail_word(0), word1 = tail_word(1);
-        key_a = load_key(2); word_a = tail_word(2);
-        key_b = load_key(3); word_b = tail_word(3);
-        place_key(0, k0);
-        place_key(1, k1);
-        __syncthreads();
-        load_point(fast_winner(0, word0), nxt_lo, nxt_hi);
-        load_point(fast_winner(1, word1), nx2_lo, nx2_hi);
-        __syncthreads(); /* every thread has read and cleared both buffers before row 2 is scattered */
+        fast_point(0, ow0, o0_lo, o0_hi, nxt_lo, nxt_hi);
     } else {
         load_point(load_winner(0), nxt_lo, nxt_hi);
         load_point(load_winner(1), nx2_lo, nx2_hi);
@@ -483,14 +554,10 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     for (int r = 0; r < N + 2; ++r) {
         cur_lo = nxt_lo;
         cur_hi = nxt_hi;
-        uint32_t word_cur = 0u;
         if (kFast) {
-            place_key(r + 2, key_a);      /* scatter row r+2's input indices into idx[r & 1] */
-            word_cur = word_a;
-            key_a = key_b;
-            word_a = word_b;
-            key_b = load_key(r + 4);      /* two rows ahead of its use */
-            word_b = tail_word(r + 4);
+            place_cand(r + 1, cand_a);    /* scatter row r+1's points into the LDS row buffer (r+1) & 1 */
+            cand_a = cand_b;
+            cand_b = load_cand(r + 3);    /* two rows ahead of its use */
         } else {
             /* points of rows r+1 and r+2 and winners of rows r+3 and r+4 are in flight while row r is handled */
             nxt_lo = nx2_lo;
@@ -505,10 +572,12 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
         if (lane == 0) wave_cnt[r & 1][wv] = (uint32_t)__popcll(m_ready);
         __syncthreads();
-        if (kFast) { /* row r+1 is already in flight; issue row r+2 */
-            nxt_lo = nx2_lo;
-            nxt_hi = nx2_hi;
-            load_point(fast_winner(r + 2, word_cur), nx2_lo, nx2_hi);
+        if (kFast) {
+            fast_point(r + 1, ow_cur, oc_lo, oc_hi, nxt_lo, nxt_hi); /* row r+1 straight from the LDS row buffer */
+            ow_cur = ow_nxt; oc_lo = on_lo; oc_hi = on_hi;           /* shift the override pipeline */
+            ow_nxt = ow_far;
+            issue_tail_point(ow_nxt, on_lo, on_hi);                  /* row r+3's point */
+            ow_far = issue_tail_winner(r + 4);
         }
 
         /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
