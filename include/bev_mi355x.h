@@ -175,11 +175,21 @@ size_t bev_float_bev_size(float interval); /* M for a given interval (0 if unsup
  *   BEV_PROJECT_OXFORD_HDL_32E  extractPointCloud, OxfordPointCloudSelect.cpp:172-218:
  *                               xyzi = x[n] y[n] z[n] intensity[n]; x and z are negated, row from the
  *                               elevation (0..31), col from the azimuth (0..1055)
- * out: n points with label = -2; t and padding are 0 (the reference leaves them uninitialised).
- * atan2f is evaluated on the device by a restatement of glibc's algorithm (bit-identical, csrc/bev_libm.h). */
+ *   BEV_PROJECT_KITTI_HDL_64E   extractPointCloud, KittiPointCloudSelect.cpp:186-243 (after the file is read):
+ *                               xyzi = n * (x, y, z, intensity); row = a counter of azimuth zero crossings (a new
+ *                               ring needs more than 2083 * 0.60f points on the current one), col from the azimuth
+ *                               (0..2082); out is the reference's STRUCTURED cloud of 64 * 2083 points, last
+ *                               writer per slot, real points with intensity = -1, empty slots all-zero.  Point 0
+ *                               is never stored (the reference's loop starts at 1).  n = 0 and NaN azimuths are
+ *                               undefined behaviour in the reference; here: all-zero cloud / point dropped.
+ * out: bev_project_out_points(kind, n) points (n, or 64 * 2083 for KITTI) with label = -2; t and padding are 0
+ * (the reference leaves them uninitialised).  atan2f is evaluated on the device by a restatement of glibc's
+ * algorithm (bit-identical, csrc/bev_libm.h). */
 #define BEV_PROJECT_MULRAN_OS1_64 0
 #define BEV_PROJECT_OXFORD_HDL_32E 1
+#define BEV_PROJECT_KITTI_HDL_64E 2
 int bev_project_xyzi(bev_ctx_t *ctx, int kind, const float *xyzi, uint32_t n, bev_point_t *out);
+size_t bev_project_out_points(int kind, uint32_t n); /* 0 for an unknown kind */
 
 /* ---- measurement ------------------------------------------------------- */
 /* Sub-batches of bev_process_* are dealt to up to BEV_LANES (default 2, max 4) streams so that kernels of

@@ -315,3 +315,61 @@ void oracle_project_oxford(const float *xyzi, size_t n, oracle_point_t *out)
         out[i] = p;
     }
 }
+
+/* KittiPointCloudSelect.cpp:186-243 (the part of extractPointCloud after the file has been read into `cloud`):
+ * the ring index is a counter of azimuth zero crossings, a new ring being accepted only after more than
+ * Horizon_SCAN * 0.60f points; N_SCAN = 64 and Horizon_SCAN = 2083 are file constants (:148-149).
+ * out: 64 * 2083 points, empty slots all-zero (value-initialised by resize, :207).
+ * Defined here where the reference is undefined: n == 0 (the reference reads azimuth_angle[0] of an empty
+ * vector) gives an all-zero cloud; a column still outside [0, Horizon_SCAN) after the single wrap at :229-233
+ * (only a NaN azimuth gets there; the reference then writes out of bounds) drops the point. */
+static float kitti_make_angle_semi_positive(float a) /* :137-146 */
+{
+    if (a >= 360.0f) return a - 360.0f;
+    else if (a < 0) return a + 360.0f;
+    else return a;
+}
+
+void oracle_project_kitti(const float *xyzi, size_t n, oracle_point_t *out)
+{
+    const int N_SCAN = 64, Horizon_SCAN = 2083; /* :148-149 */
+    memset(out, 0, (size_t)N_SCAN * Horizon_SCAN * sizeof *out); /* :206-207 */
+    if (n == 0) return;
+    float *azimuth_angle = (float *)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; ++i)  /* :190-193 */
+        azimuth_angle[i] = (float)((double)atan2f(xyzi[4 * i + 1], xyzi[4 * i]) / M_PI * 180.0f);
+    int32_t ring_idx = -1;          /* :195-203 */
+    if (azimuth_angle[0] > 0) ring_idx = 0;
+    int num_points_on_this_ring = 0; /* :210 */
+    for (size_t i = 1; i < n; ++i) { /* :212 */
+        if (azimuth_angle[i - 1] <= 0 && azimuth_angle[i] > 0) { /* :214-222 */
+            if (ring_idx == -1) {
+                ring_idx = 0;
+                num_points_on_this_ring = 0;
+            } else if (num_points_on_this_ring > Horizon_SCAN * 0.60f) {
+                ring_idx++;
+                num_points_on_this_ring = 0;
+            }
+        }
+        const float this_azimuth = kitti_make_angle_semi_positive(azimuth_angle[i]); /* :225 */
+        int col_idx = cvtt_f64_to_i32(round((double)this_azimuth / (360.0 / Horizon_SCAN))); /* :226 */
+        if (ring_idx >= 0 && ring_idx < N_SCAN) { /* :228 */
+            if (col_idx >= Horizon_SCAN) col_idx = col_idx - Horizon_SCAN; /* :229-233 */
+            else if (col_idx < 0) col_idx = col_idx + Horizon_SCAN;
+            if (col_idx >= 0 && col_idx < Horizon_SCAN) { /* see the header comment */
+                oracle_point_t p;
+                memset(&p, 0, sizeof p);
+                p.x = xyzi[4 * i];
+                p.y = xyzi[4 * i + 1];
+                p.z = xyzi[4 * i + 2];
+                p.row = (uint16_t)ring_idx;   /* :235 */
+                p.col = (uint16_t)col_idx;    /* :236 */
+                p.label = -2;                 /* :237 */
+                p.intensity = -1;             /* :238 */
+                out[(size_t)ring_idx * Horizon_SCAN + col_idx] = p; /* :240 */
+            }
+        }
+        num_points_on_this_ring++; /* :242 */
+    }
+    free(azimuth_angle);
+}

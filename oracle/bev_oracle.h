@@ -104,6 +104,10 @@ void oracle_float_bev(const oracle_point_t *cloud, size_t n, float interval,
  * Oxford (OxfordPointCloudSelect.cpp:172-218): xyzi = x[n] y[n] z[n] intensity[n] (four planes). */
 void oracle_project_mulran(const float *xyzi, size_t n, oracle_point_t *out);
 void oracle_project_oxford(const float *xyzi, size_t n, oracle_point_t *out);
+/* KITTI (KittiPointCloudSelect.cpp:186-243): xyzi interleaved like MulRan; the ring index is a counter of
+ * azimuth zero crossings.  out: the structured 64 * 2083 cloud (empty slots all-zero, real points get
+ * intensity = -1, label = -2). */
+void oracle_project_kitti(const float *xyzi, size_t n, oracle_point_t *out);
 
 #ifdef __cplusplus
 }

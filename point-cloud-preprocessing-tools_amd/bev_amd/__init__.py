@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "bev_create", "bev_destroy", "bev_strerror", "bev_last_error",
     "bev_process_batch", "bev_process_device_resident", "bev_synchronize",
     "bev_order_cloud", "bev_mark_ground", "bev_multi_bev", "bev_single_bev",
-    "bev_float_bev", "bev_float_bev_size", "bev_project_xyzi",
+    "bev_float_bev", "bev_float_bev_size", "bev_project_xyzi", "bev_project_out_points",
     "bev_set_lanes", "bev_profile_enable", "bev_profile_reset", "bev_profile_get",
     "bev_debug_get_cell_avg", "bev_debug_get_fast_path", "bev_debug_angle_predicate", "bev_abi_version",
 ]
@@ -126,6 +126,8 @@ def load_lib() -> C.CDLL:
     lib.bev_float_bev_size.argtypes = [C.c_float]
     lib.bev_float_bev_size.restype = sz
     lib.bev_project_xyzi.argtypes = [vp, i32, vp, u32, vp]
+    lib.bev_project_out_points.argtypes = [i32, u32]
+    lib.bev_project_out_points.restype = C.c_size_t
     lib.bev_set_lanes.argtypes = [vp, i32]
     lib.bev_profile_enable.argtypes = [vp, i32]
     lib.bev_profile_reset.argtypes = [vp]
@@ -252,11 +254,13 @@ class BevContext:
         return out
 
     def project_xyzi(self, kind: int, xyzi):
-        """kind 0: MulRan/Ouster (n, 4) interleaved; kind 1: Oxford (4, n) planes."""
+        """kind 0: MulRan/Ouster (n, 4) interleaved; kind 1: Oxford (4, n) planes; kind 2: KITTI (n, 4)
+        interleaved, returns the structured 64 * 2083 cloud."""
         xyzi = np.ascontiguousarray(xyzi, dtype=np.float32)
         n = xyzi.size // 4
-        out = np.empty(n, dtype=POINT_DTYPE)
-        self._check(self.lib.bev_project_xyzi(self._h, kind, _ptr(xyzi) if n else None, n, _ptr(out) if n else None),
+        n_out = int(self.lib.bev_project_out_points(kind, n))
+        out = np.empty(n_out, dtype=POINT_DTYPE)
+        self._check(self.lib.bev_project_xyzi(self._h, kind, _ptr(xyzi) if n else None, n, _ptr(out) if n_out else None),
                     "bev_project_xyzi")
         return out
 

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "bev_internal.h"
+#include "bev_libm.h"
 
 using namespace bevk;
 
@@ -90,6 +91,9 @@ struct bev_ctx {
     uint8_t *st_multi = nullptr, *st_single = nullptr;
     int8_t *st_gm = nullptr;
     bool staging_ready = false;
+    /* KITTI projection workspace, one allocation made on first use and grown on demand */
+    void *kitti_buf = nullptr;
+    size_t kitti_points = 0;
 
     /* profiling */
     bool prof_on = false;
@@ -563,7 +567,7 @@ void bev_destroy(bev_ctx_t *c)
     }
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->stagger_ev) (void)hipEventDestroy(c->stagger_ev);
-    void *dev[] = {c->st_in, c->st_ordered, c->st_multi, c->st_single, c->st_gm};
+    void *dev[] = {c->st_in, c->st_ordered, c->st_multi, c->st_single, c->st_gm, c->kitti_buf};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     for (int k = 0; k < kDescRing; ++k) {
@@ -735,25 +739,81 @@ int bev_single_bev(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, uint8_t *
     return raster_cloud(c, cloud, n, nullptr, single_out);
 }
 
+size_t bev_project_out_points(int kind, uint32_t n)
+{
+    switch (kind) {
+    case BEV_PROJECT_MULRAN_OS1_64:
+    case BEV_PROJECT_OXFORD_HDL_32E: return n;
+    case BEV_PROJECT_KITTI_HDL_64E: return (size_t)bevx::kKittiRows * bevx::kKittiCols;
+    default: return 0;
+    }
+}
+
+namespace {
+/* carve the KITTI workspace out of one buffer (256-byte aligned pieces) */
+int kitti_workspace(bev_ctx *c, uint32_t n, KittiWork &w)
+{
+    const size_t blocks = ((size_t)n + bevx::kKittiBlock - 1) / bevx::kKittiBlock;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_col = up(sizeof(KittiHeader)), o_cnt = o_col + up((size_t)n * 4), o_pos = o_cnt + up(blocks * 4),
+                 o_win = o_pos + up(blocks * bevx::kKittiListCap * 4),
+                 total = o_win + up((size_t)bevx::kKittiRows * bevx::kKittiCols * 4);
+    if (n > c->kitti_points || !c->kitti_buf) {
+        if (c->kitti_buf) HIPCK(c, hipFree(c->kitti_buf));
+        c->kitti_buf = nullptr;
+        c->kitti_points = 0;
+        hipError_t e = hipMalloc(&c->kitti_buf, total);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            c->kitti_buf = nullptr;
+            return BEV_ERR_OOM;
+        }
+        HIPCK(c, e);
+        c->kitti_points = n;
+    }
+    char *base = static_cast<char *>(c->kitti_buf);
+    w.hdr = reinterpret_cast<KittiHeader *>(base);
+    w.col = reinterpret_cast<int32_t *>(base + o_col);
+    w.cnt = reinterpret_cast<uint32_t *>(base + o_cnt);
+    w.pos = reinterpret_cast<uint32_t *>(base + o_pos);
+    w.winner = reinterpret_cast<uint32_t *>(base + o_win);
+    return BEV_OK;
+}
+} // namespace
+
 int bev_project_xyzi(bev_ctx_t *c, int kind, const float *xyzi, uint32_t n, bev_point_t *out)
 {
-    if (!c || (n && (!xyzi || !out))) return BEV_ERR_INVALID_ARG;
-    if (kind != BEV_PROJECT_MULRAN_OS1_64 && kind != BEV_PROJECT_OXFORD_HDL_32E) return BEV_ERR_INVALID_ARG;
+    const size_t n_out = bev_project_out_points(kind, n);
+    if (!c || (n && !xyzi) || (n_out && !out)) return BEV_ERR_INVALID_ARG;
+    if (kind != BEV_PROJECT_MULRAN_OS1_64 && kind != BEV_PROJECT_OXFORD_HDL_32E && kind != BEV_PROJECT_KITTI_HDL_64E)
+        return BEV_ERR_INVALID_ARG;
     if ((size_t)n > std::max(c->max_points, (size_t)c->geo.S)) return BEV_ERR_TOO_LARGE;
-    if (n == 0) return BEV_OK;
+    if (n_out == 0) return BEV_OK;
     HIPCK(c, hipSetDevice(c->device));
     int rc = ensure_staging(c);
     if (rc != BEV_OK) return rc;
     /* raw floats are staged in the ordered-cloud staging buffer (16 B per point fit its 32 B per slot) */
     float *d_raw = reinterpret_cast<float *>(c->st_ordered);
     if ((size_t)n * 16 > (size_t)c->max_batch * c->geo.S * sizeof(bev_point_t)) return BEV_ERR_TOO_LARGE;
-    HIPCK(c, hipMemcpyAsync(d_raw, xyzi, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-    {
+    if (n_out > c->st_in_elems) return BEV_ERR_TOO_LARGE;
+    if (n) HIPCK(c, hipMemcpyAsync(d_raw, xyzi, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    if (kind == BEV_PROJECT_KITTI_HDL_64E) {
+        if (n == 0) { /* defined here, undefined in the reference: an empty file gives the all-zero structured cloud */
+            HIPCK(c, hipMemsetAsync(c->st_in, 0, n_out * sizeof(bev_point_t), c->stream));
+        } else {
+            KittiWork w{};
+            rc = kitti_workspace(c, n, w);
+            if (rc != BEV_OK) return rc;
+            HIPCK(c, hipMemsetAsync(w.winner, 0, n_out * sizeof(uint32_t), c->stream));
+            ProfScope ps(c, K_PROJECT, 1);
+            launch_project_kitti(d_raw, n, w, c->st_in, c->stream);
+        }
+    } else {
         ProfScope ps(c, K_PROJECT, 1);
         launch_project(kind, d_raw, n, c->st_in, c->stream);
     }
     HIPCK(c, hipGetLastError());
-    HIPCK(c, hipMemcpyAsync(out, c->st_in, (size_t)n * sizeof(bev_point_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(out, c->st_in, n_out * sizeof(bev_point_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BEV_OK;
 }

@@ -119,6 +119,21 @@ void launch_cloud_codes(const Geometry &g, const bev_point_t *cloud, uint32_t n,
 void launch_float_bev(const bev_point_t *cloud, uint32_t n, float interval, int M, bool skip_label0, float *grid,
                       hipStream_t st);
 void launch_project(int kind, const float *xyzi, uint32_t n, bev_point_t *out, hipStream_t st);
+/* KITTI projection workspace (device): header with the chain of accepted crossings, per-point column,
+ * per-block crossing lists, winner table of the 64 x 2083 structured cloud */
+struct KittiHeader {
+    int32_t ring0;
+    uint32_t n_links;
+    uint32_t link[68];
+};
+struct KittiWork {
+    KittiHeader *hdr;
+    int32_t *col;     /* [n] */
+    uint32_t *cnt;    /* [ceil(n / 256)] */
+    uint32_t *pos;    /* [ceil(n / 256)][128] */
+    uint32_t *winner; /* [64 * 2083] */
+};
+void launch_project_kitti(const float *xyzi, uint32_t n, const KittiWork &w, bev_point_t *out, hipStream_t st);
 void launch_angle_debug(const float *dx, const float *dy, const float *dz, uint8_t *out, size_t n, hipStream_t st);
 /* opt in to > 64 KiB of dynamic LDS for the two kernels that need it */
 hipError_t configure_kernels(const Geometry &g);

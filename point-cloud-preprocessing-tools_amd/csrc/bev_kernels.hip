@@ -1106,6 +1106,109 @@ __global__ __launch_bounds__(256) void k_project(int kind, const float *__restri
     dst[1] = hi;
 }
 
+
+/* ---- KITTI projection (see bev_libm.h): crossings -> chain of accepted crossings -> rings -> structured cloud ---- */
+/* per point: azimuth, column, crossing flag; per block of 256 points: the ascending list of crossing positions */
+__global__ __launch_bounds__(kKittiBlock) void k_kitti_crossings(const float *__restrict__ xyzi, uint32_t n,
+                                                                 int32_t *__restrict__ col, uint32_t *__restrict__ cnt,
+                                                                 uint32_t *__restrict__ pos, KittiHeader *__restrict__ hdr)
+{
+    __shared__ float az[kKittiBlock + 1];
+    __shared__ uint32_t wave_base[kKittiBlock / 64 + 1];
+    const uint32_t tid = threadIdx.x, i = blockIdx.x * (uint32_t)kKittiBlock + tid;
+    float a = 0.0f;
+    if (i < n) {
+        const float4 v = reinterpret_cast<const float4 *>(xyzi)[i];
+        a = kitti_azimuth(v.x, v.y);
+        col[i] = kitti_col(a);
+        if (i == 0) hdr->ring0 = a > 0.0f ? 0 : -1; /* :195-203 */
+    }
+    az[tid + 1] = a;
+    if (tid == 0 && i >= 1 && i < n) {
+        const float4 v = reinterpret_cast<const float4 *>(xyzi)[i - 1];
+        az[0] = kitti_azimuth(v.x, v.y);
+    }
+    __syncthreads();
+    const bool flag = i >= 1 && i < n && kitti_crossing(az[tid], az[tid + 1]);
+    const uint64_t m = __ballot(flag);
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    if (lane == 0) wave_base[wave + 1] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (tid == 0) {
+        wave_base[0] = 0;
+        for (int w = 0; w < kKittiBlock / 64; ++w) wave_base[w + 1] += wave_base[w];
+        cnt[blockIdx.x] = wave_base[kKittiBlock / 64];
+    }
+    __syncthreads();
+    if (flag) pos[(size_t)blockIdx.x * kKittiListCap + wave_base[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+/* one wave walks the chain of accepted crossings */
+__global__ __launch_bounds__(64) void k_kitti_chain(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ pos,
+                                                    uint32_t n, uint32_t ring_min, KittiHeader *__restrict__ hdr)
+{
+    const uint32_t lane = threadIdx.x, nblocks = (n + kKittiBlock - 1u) / kKittiBlock;
+    int ring = hdr->ring0;
+    uint32_t last = 1, links = 0; /* count == i - last; before any crossing count == i - 1 (:210-212) */
+    while (ring < kKittiRows && links < (uint32_t)kKittiMaxLinks) {
+        const uint64_t target = ring == -1 ? 1ull : (uint64_t)last + ring_min;
+        if (target >= n) break;
+        uint32_t found = 0; /* crossings are at positions >= 1 */
+        const uint32_t b = (uint32_t)(target / kKittiBlock), c = cnt[b];
+        for (uint32_t k0 = 0; k0 < c && !found; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint32_t p = k < c ? pos[(size_t)b * kKittiListCap + k] : 0u;
+            const uint64_t hit = __ballot(k < c && p >= target);
+            if (hit) found = __shfl(p, __ffsll((long long)hit) - 1);
+        }
+        for (uint32_t b0 = b + 1; b0 < nblocks && !found; b0 += 64) {
+            const uint32_t bb = b0 + lane;
+            const uint64_t hit = __ballot(bb < nblocks && cnt[bb] > 0u);
+            if (hit) found = pos[(size_t)(b0 + (uint32_t)__ffsll((long long)hit) - 1u) * kKittiListCap];
+        }
+        if (!found) break;
+        ring = ring == -1 ? 0 : ring + 1;
+        last = found;
+        if (lane == 0) hdr->link[links] = found;
+        ++links;
+    }
+    if (lane == 0) hdr->n_links = links;
+}
+
+/* ring of every point, then last-writer-wins on its slot (:240) */
+__global__ __launch_bounds__(256) void k_kitti_assign(const int32_t *__restrict__ col, uint32_t n,
+                                                      const KittiHeader *__restrict__ hdr, uint32_t *__restrict__ winner)
+{
+    __shared__ uint32_t link[kKittiMaxLinks];
+    const uint32_t n_links = hdr->n_links;
+    if (threadIdx.x < n_links) link[threadIdx.x] = hdr->link[threadIdx.x];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < 1u || i >= n) return; /* the loop at :212 starts at 1 */
+    const int ring = kitti_ring_of(i, hdr->ring0, link, n_links), c = col[i];
+    if (ring >= 0 && ring < kKittiRows && c >= 0) atomicMax(&winner[(uint32_t)ring * kKittiCols + (uint32_t)c], i + 1u);
+}
+
+/* the structured cloud: winners with intensity = -1, label = -2 (:235-238), empty slots all-zero (:207) */
+__global__ __launch_bounds__(256) void k_kitti_gather(const float *__restrict__ xyzi, const uint32_t *__restrict__ winner,
+                                                      bev_point_t *__restrict__ out)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= (uint32_t)(kKittiRows * kKittiCols)) return;
+    Half lo{{0, 0, 0, 0}}, hi{{0, 0, 0, 0}};
+    const uint32_t w = winner[s];
+    if (w != 0u) {
+        const float4 v = reinterpret_cast<const float4 *>(xyzi)[w - 1u];
+        lo.w[0] = __float_as_uint(v.x); lo.w[1] = __float_as_uint(v.y); lo.w[2] = __float_as_uint(v.z);
+        hi.w[0] = __float_as_uint(-1.0f);
+        hi.w[1] = (s / (uint32_t)kKittiCols) | ((s % (uint32_t)kKittiCols) << 16);
+        hi.w[3] = (uint32_t)(uint16_t)(int16_t)-2;
+    }
+    Half *dst = reinterpret_cast<Half *>(out + s);
+    dst[0] = lo;
+    dst[1] = hi;
+}
+
 /* test hook: the phase-A angle predicate on raw difference vectors */
 __global__ __launch_bounds__(256) void k_angle_debug(const float *dx, const float *dy, const float *dz,
                                                      uint8_t *out, size_t n)
@@ -1207,6 +1310,15 @@ void launch_project(int kind, const float *xyzi, uint32_t n, bev_point_t *out, h
 {
     if (n == 0) return;
     hipLaunchKernelGGL(k_project, dim3((n + 255u) / 256u), dim3(256), 0, st, kind, xyzi, n, out);
+}
+void launch_project_kitti(const float *xyzi, uint32_t n, const KittiWork &w, bev_point_t *out, hipStream_t st)
+{
+    /* n >= 1; w.winner zeroed by the caller on the same stream */
+    const unsigned blocks = (n + kKittiBlock - 1u) / kKittiBlock;
+    hipLaunchKernelGGL(k_kitti_crossings, dim3(blocks), dim3(kKittiBlock), 0, st, xyzi, n, w.col, w.cnt, w.pos, w.hdr);
+    hipLaunchKernelGGL(k_kitti_chain, dim3(1), dim3(64), 0, st, w.cnt, w.pos, n, kitti_ring_min(), w.hdr);
+    hipLaunchKernelGGL(k_kitti_assign, dim3((n + 255u) / 256u), dim3(256), 0, st, w.col, n, w.hdr, w.winner);
+    hipLaunchKernelGGL(k_kitti_gather, dim3((kKittiRows * kKittiCols + 255) / 256), dim3(256), 0, st, xyzi, w.winner, out);
 }
 void launch_angle_debug(const float *dx, const float *dy, const float *dz, uint8_t *out, size_t n, hipStream_t st)
 {

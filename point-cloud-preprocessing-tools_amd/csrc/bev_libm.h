@@ -127,5 +127,56 @@ BEVX_HD void project_oxford(float x, float y, float z, uint16_t &row, uint16_t &
     col = c;
 }
 
+/* ---------------------------------------------------------------------------
+ * KITTI (KittiPointCloudSelect.cpp:186-243): the row is a counter of azimuth zero crossings — a sequential
+ * state machine in the reference.  Pieces shared by the kernels (bev_kernels.hip, k_kitti_*) and their host
+ * mirror (tests/hostcheck):
+ *   crossing at i (i >= 1)   az[i-1] <= 0 && az[i] > 0                                        (:214)
+ *   state (ring, count)      a crossing takes ring -1 -> 0, or ring -> ring + 1 when count > Horizon_SCAN * 0.60f,
+ *                            and zeroes count in both cases; every point then adds one to count  (:215-222, :242)
+ * Since count = i - (position of the last accepted crossing), the accepted crossings form a chain: the next one
+ * is the first crossing at a position >= last + kitti_ring_min() (or the first crossing at all while ring == -1).
+ * The chain has at most 65 links before ring reaches N_SCAN and everything later is dropped, so it is walked by
+ * one wave over per-block crossing lists, and each point finds its ring by counting the links at or before it.
+ * ------------------------------------------------------------------------- */
+constexpr int kKittiRows = 64;    /* N_SCAN, KittiPointCloudSelect.cpp:148 */
+constexpr int kKittiCols = 2083;  /* Horizon_SCAN, :149 */
+constexpr int kKittiBlock = 256;  /* points per crossing list */
+constexpr int kKittiListCap = kKittiBlock / 2; /* two consecutive positions cannot both be crossings */
+constexpr int kKittiMaxLinks = kKittiRows + 2;
+
+BEVX_HD float kitti_azimuth(float x, float y) { return degrees_of(fd_atan2f(y, x)); } /* :192 */
+BEVX_HD bool kitti_crossing(float az_prev, float az) { return az_prev <= 0.0f && az > 0.0f; } /* :214 */
+BEVX_HD bool kitti_ring_full(uint32_t count) { return (float)(int)count > (float)kKittiCols * 0.60f; } /* :218 */
+/* smallest count that lets a crossing start a new ring */
+inline uint32_t kitti_ring_min()
+{
+    uint32_t m = 0;
+    while (!kitti_ring_full(m)) ++m;
+    return m;
+}
+/* :225-233; -1 where the reference would index outside the row (NaN azimuth only) */
+BEVX_HD int kitti_col(float az)
+{
+    float a = az;                       /* makeAngleSemiPositive, :137-146 */
+    if (a >= 360.0f) a = a - 360.0f;
+    else if (a < 0.0f) a = a + 360.0f;
+    int c = cvtt_f64(round((double)a / (360.0 / kKittiCols)));
+    if (c >= kKittiCols) c -= kKittiCols;
+    else if (c < 0) c += kKittiCols;
+    return (c >= 0 && c < kKittiCols) ? c : -1;
+}
+/* ring of point i given ring0 (0 or -1) and the ascending positions of the accepted crossings */
+BEVX_HD int kitti_ring_of(uint32_t i, int ring0, const uint32_t *links, uint32_t n_links)
+{
+    uint32_t lo = 0, hi = n_links; /* number of links <= i */
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (links[mid] <= i) lo = mid + 1;
+        else hi = mid;
+    }
+    return ring0 + (int)lo;
+}
+
 } /* namespace bevx */
 #endif

@@ -8,6 +8,7 @@
  * test-suite compares this composition with the sequential oracle, so a wrong
  * closed form is caught without a GPU.
  */
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -221,6 +222,68 @@ void hc_project(int kind, const float *xyzi, uint32_t n, bev_point_t *out)
         out[k] = p;
     }
 }
+
+
+/* KITTI projection decomposed like the kernels k_kitti_* (crossing lists per block of 256 points, chain of
+ * accepted crossings, ring by counting links, max-index winner per slot).  out: 64 * 2083 points. */
+void hc_project_kitti(const float *xyzi, uint32_t n, bev_point_t *out)
+{
+    const size_t S = (size_t)kKittiRows * kKittiCols;
+    memset(out, 0, S * sizeof *out);
+    if (n == 0) return;
+    const uint32_t nblocks = (n + kKittiBlock - 1u) / kKittiBlock;
+    std::vector<float> az(n);
+    std::vector<int32_t> col(n);
+    std::vector<uint32_t> cnt(nblocks, 0), pos((size_t)nblocks * kKittiListCap);
+    for (uint32_t i = 0; i < n; ++i) {
+        az[i] = kitti_azimuth(xyzi[4 * (size_t)i], xyzi[4 * (size_t)i + 1]);
+        col[i] = kitti_col(az[i]);
+        if (i >= 1 && kitti_crossing(az[i - 1], az[i])) {
+            const uint32_t b = i / kKittiBlock;
+            pos[(size_t)b * kKittiListCap + cnt[b]++] = i;
+        }
+    }
+    const int ring0 = az[0] > 0.0f ? 0 : -1;
+    const uint32_t ring_min = kitti_ring_min();
+    uint32_t link[kKittiMaxLinks], links = 0, last = 1;
+    int ring = ring0;
+    while (ring < kKittiRows && links < (uint32_t)kKittiMaxLinks) {
+        const uint64_t target = ring == -1 ? 1ull : (uint64_t)last + ring_min;
+        if (target >= n) break;
+        uint32_t found = 0;
+        const uint32_t b = (uint32_t)(target / kKittiBlock);
+        for (uint32_t k = 0; k < cnt[b] && !found; ++k)
+            if (pos[(size_t)b * kKittiListCap + k] >= target) found = pos[(size_t)b * kKittiListCap + k];
+        for (uint32_t bb = b + 1; bb < nblocks && !found; ++bb)
+            if (cnt[bb] > 0) found = pos[(size_t)bb * kKittiListCap];
+        if (!found) break;
+        ring = ring == -1 ? 0 : ring + 1;
+        last = found;
+        link[links++] = found;
+    }
+    std::vector<uint32_t> winner(S, 0);
+    for (uint32_t i = 1; i < n; ++i) {
+        const int r = kitti_ring_of(i, ring0, link, links);
+        if (r >= 0 && r < kKittiRows && col[i] >= 0) {
+            uint32_t &w = winner[(size_t)r * kKittiCols + col[i]];
+            w = std::max(w, i + 1u);
+        }
+    }
+    for (size_t s2 = 0; s2 < S; ++s2) {
+        if (!winner[s2]) continue;
+        const size_t i = winner[s2] - 1u;
+        bev_point_t p;
+        memset(&p, 0, sizeof p);
+        p.x = xyzi[4 * i]; p.y = xyzi[4 * i + 1]; p.z = xyzi[4 * i + 2];
+        p.intensity = -1.0f;
+        p.row = (uint16_t)(s2 / kKittiCols);
+        p.col = (uint16_t)(s2 % kKittiCols);
+        p.label = -2;
+        out[s2] = p;
+    }
+}
+
+void hc_kitti_ring_min(uint32_t *out) { out[0] = kitti_ring_min(); }
 
 /* Whole frame, composed like the kernels. gm_phase_a / gm_final / avg may be NULL. */
 void hc_process_frame(const bev_params_t *p, const bev_point_t *in, uint32_t n_in, bev_point_t *ordered,

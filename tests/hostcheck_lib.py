@@ -29,6 +29,10 @@ def lib():
         l.hc_libm_vs_host.restype = None
         l.hc_project.argtypes = [C.c_int, vp, C.c_uint32, vp]
         l.hc_project.restype = None
+        l.hc_project_kitti.argtypes = [vp, C.c_uint32, vp]
+        l.hc_project_kitti.restype = None
+        l.hc_kitti_ring_min.argtypes = [vp]
+        l.hc_kitti_ring_min.restype = None
         l.hc_exhaustive_exact_forms.argtypes = [vp]
         l.hc_exhaustive_exact_forms.restype = None
         l.hc_derive_angle_threshold.argtypes = [vp]
@@ -65,6 +69,10 @@ def process_frame(p: BevParams, pts):
 def project(kind: int, xyzi):
     xyzi = np.ascontiguousarray(xyzi, np.float32)
     n = xyzi.size // 4
+    if kind == 2:
+        out = np.empty(64 * 2083, POINT_DTYPE)
+        lib().hc_project_kitti(xyzi.ctypes.data, n, out.ctypes.data)
+        return out
     out = np.empty(n, POINT_DTYPE)
     lib().hc_project(kind, xyzi.ctypes.data, n, out.ctypes.data)
     return out

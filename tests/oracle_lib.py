@@ -45,6 +45,8 @@ def lib():
         l.oracle_project_mulran.restype = None
         l.oracle_project_oxford.argtypes = [vp, sz, vp]
         l.oracle_project_oxford.restype = None
+        l.oracle_project_kitti.argtypes = [vp, sz, vp]
+        l.oracle_project_kitti.restype = None
         _lib = l
     return _lib
 
@@ -119,6 +121,7 @@ def float_bev(cloud: np.ndarray, interval: float = 1.0, skip_label0: bool = True
 def project(kind: int, xyzi: np.ndarray) -> np.ndarray:
     xyzi = np.ascontiguousarray(xyzi, dtype=np.float32)
     n = xyzi.size // 4
-    out = np.empty(n, dtype=POINT_DTYPE)
-    (lib().oracle_project_mulran if kind == 0 else lib().oracle_project_oxford)(xyzi.ctypes.data, n, out.ctypes.data)
+    out = np.empty(64 * 2083 if kind == 2 else n, dtype=POINT_DTYPE)
+    (lib().oracle_project_mulran, lib().oracle_project_oxford, lib().oracle_project_kitti)[kind](
+        xyzi.ctypes.data, n, out.ctypes.data)
     return out

@@ -212,3 +212,28 @@ def test_projection_matches_oracle(ctxs, kind):
     o_ord, o_gm, o_multi, o_single = orc.process_frame(sp, cloud)
     assert ordered[0].tobytes() == o_ord.tobytes() and np.array_equal(gm[0], o_gm)
     assert np.array_equal(multi[0], o_multi) and np.array_equal(single[0], o_single)
+
+
+def test_kitti_projection_matches_oracle(ctxs):
+    """SURVEY §8(f) N3, KITTI: ring index = counter of azimuth zero crossings (a sequential loop in the reference)."""
+    from projection_data import KITTI_VARIANTS, kitti_returns
+
+    p, ctx = ctxs("HDL_64E", 2, 600000)
+    sp = orc.sensor_from_params(p)
+    for variant in KITTI_VARIANTS:
+        for seed in (0, 1):
+            xyzi = kitti_returns(seed, variant)
+            got, want = ctx.project_xyzi(2, xyzi), orc.project(2, xyzi)
+            assert got.shape == (64 * 2083,)
+            assert got.tobytes() == want.tobytes(), (variant, seed)
+    xyzi = kitti_returns(3, "noisy_seam")
+    for n in (0, 1, 2, 255, 256, 257, 1250, 1251, 5000):
+        assert ctx.project_xyzi(2, xyzi[:n]).tobytes() == orc.project(2, xyzi[:n]).tobytes(), n
+    big = np.concatenate([kitti_returns(s, "sweep") for s in range(4)])   # 480 k returns: rings run out after 64
+    assert ctx.project_xyzi(2, big).tobytes() == orc.project(2, big).tobytes()
+    # the structured cloud feeds the hot path like any selector output (empty slots are all-zero points at slot 0)
+    cloud = ctx.project_xyzi(2, kitti_returns(9, "sweep"))
+    ordered, multi, single, gm = ctx.process_batch([cloud], want_ground_mat=True)
+    o_ord, o_gm, o_multi, o_single = orc.process_frame(sp, cloud)
+    assert ordered[0].tobytes() == o_ord.tobytes() and np.array_equal(gm[0], o_gm)
+    assert np.array_equal(multi[0], o_multi) and np.array_equal(single[0], o_single)
