@@ -14,7 +14,8 @@ import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent.parent
 REPO_DIR = PKG_DIR.parent
-LIB_PATH = PKG_DIR / "csrc" / "libbev_mi355x.so"
+# BEV_AMD_LIB: developer override (e.g. the `make clk` build with in-kernel phase clocks); never a fallback
+LIB_PATH = Path(os.environ["BEV_AMD_LIB"]) if os.environ.get("BEV_AMD_LIB") else PKG_DIR / "csrc" / "libbev_mi355x.so"
 SYNTH_PATH = PKG_DIR / "synth" / "libbev_synth.so"
 
 # pcl::PointXYZIRCT in memory (reference BatchMultiBevGen.h:43-54), 32 bytes

@@ -37,6 +37,7 @@ constexpr int kMaxLanes = 4;
 struct Lane {
     hipStream_t st = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t front_done = nullptr, back_done = nullptr; /* staged mode: workspace hand-over between the two stages */
     uint32_t *winner = nullptr;
     uint32_t *codes = nullptr;
     uint16_t *cand_cell = nullptr;
@@ -65,6 +66,7 @@ struct bev_ctx {
     Lane lanes[kMaxLanes];
     int n_lanes = 1;
     int n_lanes_active = 1; /* <= n_lanes; bev_set_lanes */
+    bool staged = true;     /* two-stage pipeline, see run_pipeline; BEV_STAGED=0 falls back to free-running lanes */
     bool fast_path = false; /* BEV_FAST=1 enables the (experimental) sorted-prefix fast path */
     hipEvent_t fork_ev = nullptr;
     hipEvent_t stagger_ev = nullptr; /* recorded on a lane after its bandwidth-bound kernels */
@@ -279,7 +281,12 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
     for (int f0 = 0; f0 < n_frames; f0 += c->max_batch, ++sub) {
         const int nb = std::min(c->max_batch, n_frames - f0);
         Lane &ln = c->lanes[sub % lanes_used];
-        hipStream_t st = ln.st;
+        /* staged mode: lanes are only workspace sets; the bandwidth-bound front (order scan + column walk) of
+         * every sub-batch runs on one stream, the latency-bound back (cell sums, resolve, rasters) on another,
+         * higher-priority one, so that exactly one of each kind is in flight */
+        const bool staged = c->staged && lanes_used >= 2 && !identity;
+        hipStream_t st = staged ? c->lanes[1].st : ln.st;
+        if (staged) HIPCK(c, hipStreamWaitEvent(st, ln.back_done, 0)); /* the set's previous tenant has left */
         BatchPtrs b{};
         b.pts = identity ? d_pts + (size_t)f0 * S : d_pts;
         b.frames = identity ? nullptr : c->d_desc[ds] + f0;
@@ -340,7 +347,12 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         /* One-time stagger: a lane's FIRST sub-batch starts only after the previous lane has issued its
          * bandwidth-bound kernels (order scan + column walk), so that from then on one lane's latency-bound
          * per-frame kernels run beside the other lane's streaming kernels instead of in lock-step. */
-        if (lanes_used > 1 && !fork) {
+        if (staged) {
+            HIPCK(c, hipEventRecord(ln.front_done, st));
+            st = c->lanes[0].st;
+            HIPCK(c, hipStreamWaitEvent(st, ln.front_done, 0));
+        }
+        if (lanes_used > 1 && !fork && !staged) {
             const int li = sub % lanes_used;
             HIPCK(c, hipEventRecord(c->stagger_ev, st));
             const int nxt = (li + 1) % lanes_used;
@@ -366,6 +378,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             launch_bev_raster(g, ln.codes, S, (uint32_t)S, b.multi, b.single, d_multi != nullptr,
                               d_single != nullptr, nb, st);
         }
+        if (staged) HIPCK(c, hipEventRecord(ln.back_done, st));
         c->last_sub_frames = nb;
         c->last_avg = ln.avg;
         c->last_fast_len = ln.fast_len;
@@ -506,6 +519,8 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         c->n_lanes_active = c->n_lanes;
         const char *fp = getenv("BEV_FAST");
         c->fast_path = fp && atoi(fp) != 0;
+        const char *sg = getenv("BEV_STAGED");
+        c->staged = (!sg || atoi(sg) != 0) && c->n_lanes >= 2;
     }
     CK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&c->stagger_ev, hipEventDisableTiming));
@@ -521,6 +536,8 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         if (prio > prio_least) prio = prio_least;
         CK(hipStreamCreateWithPriority(&ln.st, hipStreamNonBlocking, prio));
         CK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&ln.front_done, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&ln.back_done, hipEventDisableTiming));
         CK(hipMalloc((void **)&ln.winner, nb * S * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.codes, c->codes_elems * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.cand_cell, nb * (size_t)c->geo.segs * kSeg * sizeof(uint16_t)));
@@ -563,6 +580,8 @@ void bev_destroy(bev_ctx_t *c)
         for (void *p : ws)
             if (p) (void)hipFree(p);
         if (ln.done) (void)hipEventDestroy(ln.done);
+        if (ln.front_done) (void)hipEventDestroy(ln.front_done);
+        if (ln.back_done) (void)hipEventDestroy(ln.back_done);
         if (ln.st) (void)hipStreamDestroy(ln.st);
     }
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);

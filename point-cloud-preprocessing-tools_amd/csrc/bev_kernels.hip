@@ -55,6 +55,7 @@ static inline int xcd_grid(int nf, int tiles) { return 8 * ((nf + 7) / 8) * tile
 /* getOrderedCloud, BatchMultiBevGen.cpp:102-116: bounds test + slot index;
  * "last point in input order wins" == max input index per slot.            */
 constexpr int kScanPerThread = 4;
+constexpr int kScanIdxBits = 10; /* 256 * kScanPerThread = 1024 points per block */
 constexpr int kScanRowBins = 128; /* rows the LDS regrouping below can bin (more rows: plain path) */
 __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restrict__ pts,
                                                     const FrameDesc *__restrict__ frames,
@@ -94,12 +95,15 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
     }
     __shared__ uint32_t any_spread;
     __shared__ uint32_t row_fill[kScanRowBins];
-    __shared__ uint2 pairs[256 * kScanPerThread]; /* (slot, index + 1) regrouped by row */
+    /* (slot << kScanIdxBits | index within the block) regrouped by row; 4 B per point, not 8: LDS is what decides how many of these
+     * blocks fit on a CU beside a k_cell_sums / k_bev_raster workgroup of another sub-batch */
+    __shared__ uint32_t pairs[256 * kScanPerThread];
+    static_assert(256 * kScanPerThread == (1 << kScanIdxBits), "bits of block-local index");
     if (threadIdx.x == 0) any_spread = 0u;
     __syncthreads();
     if (spread && (threadIdx.x & 63) == 0) any_spread = 1u;
     __syncthreads();
-    if (any_spread == 0u || N > kScanRowBins) {
+    if (any_spread == 0u || N > kScanRowBins || S > (1 << (32 - kScanIdxBits))) {
         /* coalesced already (or too many rows to bin): one atomicMax per point, in input order */
 #pragma unroll
         for (int k = 0; k < kScanPerThread; ++k)
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
      * columns instead of 64 different rows — scattered device atomics run ~15x slower than contiguous ones. */
     for (int r = threadIdx.x; r < kScanRowBins; r += 256) row_fill[r] = 0u;
 #pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k) pairs[threadIdx.x + 256u * k] = make_uint2(0u, 0u); /* y == 0: empty */
+    for (int k = 0; k < kScanPerThread; ++k) pairs[threadIdx.x + 256u * k] = 0xffffffffu; /* empty */
     __syncthreads();
     uint32_t rank[kScanPerThread];
 #pragma unroll
@@ -134,13 +138,13 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k)
         if (slot[k] != 0xffffffffu)
-            pairs[row_fill[slot[k] / (uint32_t)H] + rank[k]] = make_uint2(slot[k], base + 256u * k + 1u);
+            pairs[row_fill[slot[k] / (uint32_t)H] + rank[k]] = (slot[k] << kScanIdxBits) | (threadIdx.x + 256u * k);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k) {
         const uint32_t j = threadIdx.x + 256u * k;
-        const uint2 pr = pairs[j];
-        if (pr.y != 0u) atomicMax(&fw[pr.x], pr.y);
+        const uint32_t pr = pairs[j];
+        if (pr != 0xffffffffu) atomicMax(&fw[pr >> kScanIdxBits], blockIdx.x * (256u * kScanPerThread) + (pr & ((1u << kScanIdxBits) - 1u)) + 1u);
     }
 }
 
@@ -685,7 +689,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_only(BatchPtrs b, Geo
 /* markGroundPoints phase B + divide, BatchMultiBevGen.cpp:187-210.
  * One workgroup (8 waves) per frame.
  *   LDS: hist[8][3750] u32 (later reused as the z staging chunk) | cell_start |
- *        cell_total | per-wave tile counts | scan scratch
+ *        per-wave tile counts | scan scratch
  *   pass 1  wave w owns a contiguous range of tiles (slot order) and counts its
  *           candidates per cell (LDS atomics; order-free, so loads are issued
  *           several slices at a time).
@@ -706,21 +710,30 @@ constexpr int kMaxSegsPerWave = kMaxSegs / kSumWaves + 1;
 
 size_t cell_sums_lds_bytes()
 {
-    return sizeof(uint32_t) * ((size_t)kSumWaves * kCells + 2 * kCells + (size_t)kSumWaves * kMaxSegsPerWave + 16);
+    return sizeof(uint32_t) * ((size_t)kSumWaves * kCells + (kCells + 1) + (size_t)kSumWaves * kMaxSegsPerWave + 16);
 }
 
+/* developer aid (make clk): phase durations of one workgroup of k_cell_sums, in 10 ns ticks */
+#ifdef BEV_CS_CLOCK
+#define CS_CLK(i) cs_clk[i] = wall_clock64()
+#else
+#define CS_CLK(i)
+#endif
 __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry g)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *hist = lds;                         /* [kSumWaves][kCells] */
-    uint32_t *cell_start = hist + kSumWaves * kCells;
-    uint32_t *cell_total = cell_start + kCells;
-    uint32_t *tile_cnt = cell_total + kCells;     /* [kSumWaves][kMaxSegsPerWave] */
+    uint32_t *cell_start = hist + kSumWaves * kCells; /* [kCells + 1], the last entry is the candidate count */
+    uint32_t *tile_cnt = cell_start + kCells + 1;    /* [kSumWaves][kMaxSegsPerWave] */
     uint32_t *wave_sum = tile_cnt + kSumWaves * kMaxSegsPerWave; /* [kSumWaves] */
 
     const int f = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int T = g.segs;
+#ifdef BEV_CS_CLOCK
+    long long cs_clk[8];
+#endif
+    CS_CLK(0);
     const uint16_t *ccell = b.cand_cell + (size_t)f * T * kSeg;
     const float *cz = b.cand_z + (size_t)f * T * kSeg;
     const uint32_t *ncand = b.ncand + (size_t)f * T;
@@ -733,29 +746,32 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     __syncthreads();
 
     uint32_t *myhist = hist + wv * kCells;
+    CS_CLK(1);
 
-    /* pass 1: order-free histogram of this wave's range; a segment holds at most kSeg = 4 x 64
-     * candidates, all four (predicated) loads of the NEXT segment are issued before the LDS
-     * atomics of the current one */
+    /* pass 1: order-free histogram of this wave's range.  The workgroup is alone on its CU (LDS) with two waves per
+     * SIMD, and it usually runs beside another sub-batch's streaming kernels, where a memory round trip takes
+     * several microseconds: the candidate loads are therefore requested kBatch1 segments (of at most kSeg = 4 x 64
+     * candidates) at a time, not one. */
     constexpr int kSl = kSeg / 64;
-    {
-        uint32_t cc[kSl], nc[kSl];
-        int n = (t0 < t1) ? (int)mycnt[0] : 0;
+    constexpr int kBatch1 = 8;
+    for (int tb = t0; tb < t1; tb += kBatch1) {
+        uint32_t cc[kBatch1][kSl];
 #pragma unroll
-        for (int k = 0; k < kSl; ++k) cc[k] = (lane + 64 * k < n) ? (uint32_t)ccell[(size_t)t0 * kSeg + lane + 64 * k] : 0xffffu;
-        for (int t = t0; t < t1; ++t) {
-            const int nn = (t + 1 < t1) ? (int)mycnt[t + 1 - t0] : 0;
-#pragma unroll
-            for (int k = 0; k < kSl; ++k)
-                nc[k] = (lane + 64 * k < nn) ? (uint32_t)ccell[(size_t)(t + 1) * kSeg + lane + 64 * k] : 0xffffu;
+        for (int j = 0; j < kBatch1; ++j) {
+            const int t = tb + j;
+            const int n = t < t1 ? (int)mycnt[t - t0] : 0;
 #pragma unroll
             for (int k = 0; k < kSl; ++k)
-                if (cc[k] != 0xffffu) atomicAdd(&myhist[cc[k]], 1u);
-#pragma unroll
-            for (int k = 0; k < kSl; ++k) cc[k] = nc[k];
+                cc[j][k] = (lane + 64 * k < n) ? (uint32_t)ccell[(size_t)t * kSeg + lane + 64 * k] : 0xffffu;
         }
+#pragma unroll
+        for (int j = 0; j < kBatch1; ++j)
+#pragma unroll
+            for (int k = 0; k < kSl; ++k)
+                if (cc[j][k] != 0xffffu) atomicAdd(&myhist[cc[j][k]], 1u);
     }
     __syncthreads();
+    CS_CLK(2);
 
     /* per-cell totals, hist -> wave offsets inside the cell's run */
     for (int c = tid; c < kCells; c += kSumThreads) {
@@ -766,11 +782,11 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
             hist[w * kCells + c] = tot;
             tot += v;
         }
-        cell_total[c] = tot;
+        cell_start[c] = tot; /* the cell's total until the scan below turns it into its start */
     }
     __syncthreads();
 
-    /* exclusive scan of cell_total: thread owns kCellsPerThread consecutive cells */
+    /* exclusive scan of the totals: thread owns kCellsPerThread consecutive cells (reads and rewrites only those) */
     {
         const int c0 = tid * kCellsPerThread;
         uint32_t loc[kCellsPerThread];
@@ -778,7 +794,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
 #pragma unroll
         for (int k = 0; k < kCellsPerThread; ++k) {
             const int c = c0 + k;
-            loc[k] = (c < kCells) ? cell_total[c] : 0u;
+            loc[k] = (c < kCells) ? cell_start[c] : 0u;
             s += loc[k];
         }
         uint32_t incl = s;
@@ -797,38 +813,40 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
             const int c = c0 + k;
             if (c < kCells) cell_start[c] = run;
             run += loc[k];
+            if (c == kCells - 1) cell_start[kCells] = run;
         }
     }
     __syncthreads();
 
-    /* pass 2: stable placement.  Segments are walked IN ORDER; the (cell, z) pairs of the next
-     * segment are in flight while the up to four 64-slices of the current one are ranked. */
-    {
-        uint32_t cc[kSl], nc[kSl];
-        float zz[kSl], nz[kSl];
-        int n = (t0 < t1) ? (int)mycnt[0] : 0;
+    CS_CLK(3);
+    /* pass 2: stable placement.  Segments are walked IN ORDER, kBatch2 at a time: all (cell, z) pairs of a batch
+     * are requested first, then its 64-slices are ranked one after the other. */
+    constexpr int kBatch2 = 4;
+    for (int tb = t0; tb < t1; tb += kBatch2) {
+        uint32_t cc[kBatch2][kSl];
+        float zz[kBatch2][kSl];
+        int nn[kBatch2];
 #pragma unroll
-        for (int k = 0; k < kSl; ++k) {
-            const bool ok = lane + 64 * k < n;
-            cc[k] = ok ? (uint32_t)ccell[(size_t)t0 * kSeg + lane + 64 * k] : 0xfffu;
-            zz[k] = ok ? cz[(size_t)t0 * kSeg + lane + 64 * k] : 0.f;
-        }
-        for (int t = t0; t < t1; ++t) {
-            const int nn = (t + 1 < t1) ? (int)mycnt[t + 1 - t0] : 0;
+        for (int j = 0; j < kBatch2; ++j) {
+            const int t = tb + j;
+            nn[j] = t < t1 ? (int)mycnt[t - t0] : 0;
 #pragma unroll
             for (int k = 0; k < kSl; ++k) {
-                const bool ok = lane + 64 * k < nn;
-                nc[k] = ok ? (uint32_t)ccell[(size_t)(t + 1) * kSeg + lane + 64 * k] : 0xfffu;
-                nz[k] = ok ? cz[(size_t)(t + 1) * kSeg + lane + 64 * k] : 0.f;
+                const bool ok = lane + 64 * k < nn[j];
+                cc[j][k] = ok ? (uint32_t)ccell[(size_t)t * kSeg + lane + 64 * k] : 0xfffu;
+                zz[j][k] = ok ? cz[(size_t)t * kSeg + lane + 64 * k] : 0.f;
             }
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch2; ++j) {
 #pragma unroll
             for (int k = 0; k < kSl; ++k) {
-                if (64 * k >= n) break; /* wave-uniform */
-                const bool valid = lane + 64 * k < n;
+                if (64 * k >= nn[j]) break; /* wave-uniform */
+                const bool valid = lane + 64 * k < nn[j];
                 /* lanes holding the same cell find each other with one ballot per key bit (12 bits
                  * cover 3750 cells; 0xfff is not a cell): constant work however many distinct cells
                  * the 64 candidates have */
-                const uint32_t cell = cc[k];
+                const uint32_t cell = cc[j][k];
                 unsigned long long peers = __ballot(valid);
 #pragma unroll
                 for (int bit = 0; bit < 12; ++bit) {
@@ -839,19 +857,17 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
                 const unsigned long long lower = peers & ((1ull << lane) - 1ull);
                 if (valid) {
                     const uint32_t pos = cell_start[cell] + myhist[cell] + (uint32_t)__popcll(lower);
-                    zs[pos] = zz[k];
+                    zs[pos] = zz[j][k];
                 }
                 /* the lowest lane of each peer group advances the wave's cursor for that cell; every
                  * read above is issued before this write (same wave, program order) */
                 if (valid && lower == 0ull) myhist[cell] += (uint32_t)__popcll(peers);
             }
-            n = nn;
-#pragma unroll
-            for (int k = 0; k < kSl; ++k) { cc[k] = nc[k]; zz[k] = nz[k]; }
         }
     }
     __threadfence_block();
     __syncthreads();
+    CS_CLK(4);
 
     /* pass 3: in-order float accumulation; thread owns cells tid + 512*j */
     float sum[kCellsPerThread], cnt[kCellsPerThread];
@@ -860,7 +876,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
         sum[j] = 0.0f;   /* :133-134 */
         cnt[j] = 0.01f;  /* :135-136 */
     }
-    const int n_total = (int)(cell_start[kCells - 1] + cell_total[kCells - 1]);
+    const int n_total = (int)cell_start[kCells];
     float *zchunk = reinterpret_cast<float *>(hist);
     for (int chunk0 = 0; chunk0 < n_total; chunk0 += kChunk) {
         const int cn = min(kChunk, n_total - chunk0);
@@ -872,7 +888,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
             if (c < kCells) {
                 const int st = (int)cell_start[c];
                 const int a = max(st, chunk0) - chunk0;
-                const int e = min(st + (int)cell_total[c], chunk0 + cn) - chunk0;
+                const int e = min((int)cell_start[c + 1], chunk0 + cn) - chunk0;
                 float sj = sum[j], cj = cnt[j];
                 int i = a;
                 for (; i + 4 <= e; i += 4) {
@@ -890,6 +906,13 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
         }
         __syncthreads();
     }
+    CS_CLK(5);
+#ifdef BEV_CS_CLOCK
+    if (tid == 0 && f == 100)
+        printf("cell_sums f=%d: init %lld pass1 %lld scan %lld pass2 %lld pass3 %lld (x10 ns), %d candidates\n", f,
+               cs_clk[1] - cs_clk[0], cs_clk[2] - cs_clk[1], cs_clk[3] - cs_clk[2], cs_clk[4] - cs_clk[3],
+               cs_clk[5] - cs_clk[4], n_total);
+#endif
     float *avg = b.avg + (size_t)f * kCells;
 #pragma unroll
     for (int j = 0; j < kCellsPerThread; ++j) {

@@ -1,11 +1,1 @@
-cd $GRAFT_REPO_ROOT
-F=point-cloud-preprocessing-tools_amd/csrc/bev_kernels.hip
-run() { make -C point-cloud-preprocessing-tools_amd 2>&1 | grep -E "error" ; for lanes in 1 2; do BEV_LANES=$lanes timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu 2>/dev/null | tail -1 > /tmp/b.json; python - <<PY
-import json
-d=json.loads(open("/tmp/b.json").read()); print("$1 lanes $lanes", round(d["value"]), [(k["name"][2:8], round(k["avg_launch_ms"]*1e3/ (1000/ (k["launches"]/6)),2)) for k in d["kernels"]])
-PY
-done
-}
-run regroup
-# disable the regroup path: never "spread"
-sed -i 's/            spread = spread || d > 4u \* (uint32_t)H;/            spread = spread || (d > 4u * (uint32_t)H \&\& N < 0);/' $F; run regroup_disabled
+BEV_LANES=1 timeout 300 python bench.py --steps 1 --warmup 0 --no-cpu --no-profile 2>&1 | grep "^cs \|^p2" | head -24
