@@ -141,6 +141,13 @@ int bev_process_device_resident(bev_ctx_t *ctx, int n_frames,
                                 int8_t *d_ground_mat);
 int bev_synchronize(bev_ctx_t *ctx);
 
+/* Page-locked host memory for the buffers handed to bev_process_batch (optional): copies from / to such memory
+ * are DMA transfers without intermediate staging by the runtime.  Any host memory works (on the MI355X boxes
+ * measured, pageable buffers reached 6.3 k frames/s and page-locked ones 6.5 k: the link, not the staging, is
+ * the limit).  hipHostMalloc / hipHostFree. */
+int bev_host_alloc(void **out, size_t bytes);
+int bev_host_free(void *p);
+
 /* ---- per-function entry points (host buffers, one cloud) ---------------
  * These let the reference-named C++ free functions be re-implemented as thin
  * callers, one ABI call each. */
@@ -213,9 +220,10 @@ int bev_profile_reset(bev_ctx_t *ctx);
 int bev_profile_get(bev_ctx_t *ctx, bev_kernel_stat_t *out, int cap);
 
 /* ---- test hooks (used by tests/ only; not part of the reference surface) - */
-/* Per-cell average ground heights of the LAST frame range processed:
- * copies n_frames * 3750 floats (ground_grid_avg_heights after
- * BatchMultiBevGen.cpp:210). */
+/* Per-cell average ground heights of the LAST sub-batch processed (bev_process_batch works in chunks of
+ * max(1, max_batch / 2) frames, bev_process_device_resident in sub-batches of max_batch): copies
+ * n_frames * 3750 floats (ground_grid_avg_heights after BatchMultiBevGen.cpp:210), first_frame counted
+ * from the start of that sub-batch. */
 int bev_debug_get_cell_avg(bev_ctx_t *ctx, int first_frame, int n_frames, float *out);
 /* Sorted-prefix fast path of the LAST sub-batch processed: per frame, the prefix length M
  * that was tried and whether verification failed (frame redone by the general path). */

@@ -73,7 +73,7 @@ ABI_SYMBOLS = [
     "bev_create", "bev_destroy", "bev_strerror", "bev_last_error",
     "bev_process_batch", "bev_process_device_resident", "bev_synchronize",
     "bev_order_cloud", "bev_mark_ground", "bev_multi_bev", "bev_single_bev",
-    "bev_float_bev", "bev_float_bev_size", "bev_project_xyzi", "bev_project_out_points",
+    "bev_float_bev", "bev_float_bev_size", "bev_project_xyzi", "bev_project_out_points", "bev_host_alloc", "bev_host_free",
     "bev_set_lanes", "bev_profile_enable", "bev_profile_reset", "bev_profile_get",
     "bev_debug_get_cell_avg", "bev_debug_get_fast_path", "bev_debug_angle_predicate", "bev_abi_version",
 ]
@@ -127,6 +127,8 @@ def load_lib() -> C.CDLL:
     lib.bev_float_bev_size.argtypes = [C.c_float]
     lib.bev_float_bev_size.restype = sz
     lib.bev_project_xyzi.argtypes = [vp, i32, vp, u32, vp]
+    lib.bev_host_alloc.argtypes = [C.POINTER(vp), sz]
+    lib.bev_host_free.argtypes = [vp]
     lib.bev_project_out_points.argtypes = [i32, u32]
     lib.bev_project_out_points.restype = C.c_size_t
     lib.bev_set_lanes.argtypes = [vp, i32]
@@ -309,6 +311,18 @@ class BevContext:
         self._check(self.lib.bev_debug_angle_predicate(self._h, _ptr(dx), _ptr(dy), _ptr(dz), _ptr(out), dx.shape[0]),
                     "bev_debug_angle_predicate")
         return out
+
+
+def host_alloc(shape, dtype) -> np.ndarray:
+    """A numpy array in page-locked host memory (bev_host_alloc); the memory is never returned to the system —
+    meant for long-lived I/O buffers of a driver script."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    rc = load_lib().bev_host_alloc(C.byref(p), n)
+    if rc != 0 or not p.value:
+        raise BevError(f"bev_host_alloc({n}) failed: status {rc}")
+    buf = (C.c_char * n).from_address(p.value)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
 def algorithmic_bytes_per_frame(params: BevParams, n_points: float) -> float:

@@ -6,6 +6,10 @@
  * HIP cannot give us a device, bev_create() fails.
  */
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -93,6 +97,8 @@ struct bev_ctx {
     uint8_t *st_multi = nullptr, *st_single = nullptr;
     int8_t *st_gm = nullptr;
     bool staging_ready = false;
+    hipStream_t dl_stream = nullptr;             /* device -> host copies of bev_process_batch (own host thread) */
+    hipEvent_t out_ready[2] = {nullptr, nullptr}; /* per half of the output staging: its chunk has been computed */
     /* KITTI projection workspace, one allocation made on first use and grown on demand */
     void *kitti_buf = nullptr;
     size_t kitti_points = 0;
@@ -408,6 +414,8 @@ int ensure_staging(bev_ctx *c)
     HIPCK(c, hipMalloc((void **)&c->st_multi, (size_t)c->max_batch * c->multi_bytes));
     HIPCK(c, hipMalloc((void **)&c->st_single, (size_t)c->max_batch * c->single_bytes));
     HIPCK(c, hipMalloc((void **)&c->st_gm, (size_t)c->max_batch * S));
+    HIPCK(c, hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
+    for (auto &e : c->out_ready) HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->staging_ready = true;
     return BEV_OK;
 }
@@ -586,6 +594,9 @@ void bev_destroy(bev_ctx_t *c)
     }
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->stagger_ev) (void)hipEventDestroy(c->stagger_ev);
+    if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
+    for (auto e : c->out_ready)
+        if (e) (void)hipEventDestroy(e);
     void *dev[] = {c->st_in, c->st_ordered, c->st_multi, c->st_single, c->st_gm, c->kitti_buf};
     for (void *p : dev)
         if (p) (void)hipFree(p);
@@ -620,51 +631,162 @@ int bev_process_device_resident(bev_ctx_t *c, int n_frames, const bev_point_t *d
                         /*fork=*/false);
 }
 
+namespace {
+/* Device -> host side of bev_process_batch.  Copies into pageable host memory block the calling thread, so the
+ * downloads of chunk k run on their own thread and stream while the main thread uploads and launches chunk k + 1:
+ * PCIe is used in both directions at once. */
+struct Downloader {
+    struct Task { int f0, nb, half; };
+    bev_ctx *c;
+    bev_point_t *const *ordered_out;
+    uint8_t *const *multi_out;
+    uint8_t *const *single_out;
+    int8_t *const *gm_out;
+    int half_frames;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Task> queue;
+    bool closing = false;
+    int finished = 0; /* chunks whose outputs are in the caller's buffers */
+    hipError_t err = hipSuccess;
+    std::thread th;
+
+    void run()
+    {
+        (void)hipSetDevice(c->device);
+        const size_t S = (size_t)c->geo.S;
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return closing || !queue.empty(); });
+                if (queue.empty()) return;
+                t = queue.front();
+                queue.pop_front();
+            }
+            hipError_t e = hipStreamWaitEvent(c->dl_stream, c->out_ready[t.half], 0);
+            const size_t base = (size_t)t.half * half_frames;
+            auto copy = [&](void *dst, const void *src, size_t n) {
+                if (e == hipSuccess && dst) e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->dl_stream);
+            };
+            for (int f = 0; f < t.nb; ++f) {
+                const int g = t.f0 + f;
+                copy(ordered_out[g], c->st_ordered + (base + f) * S, S * sizeof(bev_point_t));
+                if (multi_out) copy(multi_out[g], c->st_multi + (base + f) * c->multi_bytes, c->multi_bytes);
+                if (single_out) copy(single_out[g], c->st_single + (base + f) * c->single_bytes, c->single_bytes);
+                if (gm_out) copy(gm_out[g], c->st_gm + (base + f) * S, S);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(c->dl_stream);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (e != hipSuccess && err == hipSuccess) err = e;
+                ++finished;
+            }
+            cv.notify_all();
+        }
+    }
+    void push(Task t)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            queue.push_back(t);
+        }
+        cv.notify_all();
+    }
+    void wait_finished(int n)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return finished >= n; });
+    }
+    void close()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            closing = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+} // namespace
+
 int bev_process_batch(bev_ctx_t *c, int n_frames, const bev_point_t *const *pts, const uint32_t *n_pts,
                       bev_point_t *const *ordered_out, uint8_t *const *multi_out, uint8_t *const *single_out,
                       int8_t *const *ground_mat_out)
 {
     if (!c || n_frames < 0 || (n_frames > 0 && (!pts || !n_pts || !ordered_out))) return BEV_ERR_INVALID_ARG;
+    for (int f = 0; f < n_frames; ++f) {
+        if (n_pts[f] > c->max_points) return BEV_ERR_TOO_LARGE;
+        if (n_pts[f] && !pts[f]) return BEV_ERR_INVALID_ARG;
+    }
+    if (n_frames == 0) return BEV_OK;
     HIPCK(c, hipSetDevice(c->device));
     int rc = ensure_staging(c);
     if (rc != BEV_OK) return rc;
     const size_t S = (size_t)c->geo.S;
+    /* the output staging is used as two halves: chunk k is computed into half k % 2 while half (k - 1) % 2 drains */
+    const int halves = c->max_batch >= 2 ? 2 : 1;
+    const int chunk = c->max_batch / halves;
+    bool any_gm = false;
+    for (int f = 0; f < n_frames && ground_mat_out; ++f) any_gm = any_gm || ground_mat_out[f] != nullptr;
+
+    Downloader dl{c, ordered_out, multi_out, single_out, any_gm ? ground_mat_out : nullptr, chunk};
+    dl.th = std::thread([&dl] { dl.run(); });
     std::vector<uint64_t> off;
-    for (int f0 = 0; f0 < n_frames; f0 += c->max_batch) {
-        const int nb = std::min(c->max_batch, n_frames - f0);
+    int k = 0;
+    rc = BEV_OK;
+    for (int f0 = 0; f0 < n_frames && rc == BEV_OK; f0 += chunk, ++k) {
+        const int nb = std::min(chunk, n_frames - f0), half = k % halves;
         off.assign((size_t)nb + 1, 0);
-        bool any_gm = false;
-        for (int f = 0; f < nb; ++f) {
+        hipError_t e = hipSuccess;
+        for (int f = 0; f < nb && e == hipSuccess; ++f) { /* the input staging is free again: stream order */
             const uint32_t n = n_pts[f0 + f];
-            if (n > c->max_points) return BEV_ERR_TOO_LARGE;
-            if (n && !pts[f0 + f]) return BEV_ERR_INVALID_ARG;
             off[f + 1] = off[f] + n;
             if (n)
-                HIPCK(c, hipMemcpyAsync(c->st_in + off[f], pts[f0 + f], (size_t)n * sizeof(bev_point_t),
-                                        hipMemcpyHostToDevice, c->stream));
-            if (ground_mat_out && ground_mat_out[f0 + f]) any_gm = true;
+                e = hipMemcpyAsync(c->st_in + off[f], pts[f0 + f], (size_t)n * sizeof(bev_point_t), hipMemcpyHostToDevice,
+                                   c->stream);
         }
-        rc = run_pipeline(c, nb, c->st_in, off.data(), false, c->st_ordered, multi_out ? c->st_multi : nullptr,
-                          single_out ? c->st_single : nullptr, any_gm ? c->st_gm : nullptr);
-        if (rc != BEV_OK) return rc;
-        for (int f = 0; f < nb; ++f) {
-            if (ordered_out[f0 + f])
-                HIPCK(c, hipMemcpyAsync(ordered_out[f0 + f], c->st_ordered + (size_t)f * S, S * sizeof(bev_point_t),
-                                        hipMemcpyDeviceToHost, c->stream));
-            if (multi_out && multi_out[f0 + f])
-                HIPCK(c, hipMemcpyAsync(multi_out[f0 + f], c->st_multi + (size_t)f * c->multi_bytes, c->multi_bytes,
-                                        hipMemcpyDeviceToHost, c->stream));
-            if (single_out && single_out[f0 + f])
-                HIPCK(c, hipMemcpyAsync(single_out[f0 + f], c->st_single + (size_t)f * c->single_bytes,
-                                        c->single_bytes, hipMemcpyDeviceToHost, c->stream));
-            if (ground_mat_out && ground_mat_out[f0 + f])
-                HIPCK(c, hipMemcpyAsync(ground_mat_out[f0 + f], c->st_gm + (size_t)f * S, S, hipMemcpyDeviceToHost,
-                                        c->stream));
+        if (e != hipSuccess) {
+            rc = hip_fail(c, e, "hipMemcpyAsync (host -> device staging)", __LINE__);
+            break;
         }
-        /* staging is reused by the next sub-batch */
-        HIPCK(c, hipStreamSynchronize(c->stream));
+        dl.wait_finished(k + 1 - halves); /* this half's previous tenant has reached the caller's buffers */
+        const size_t base = (size_t)half * chunk;
+        rc = run_pipeline(c, nb, c->st_in, off.data(), false, c->st_ordered + base * S,
+                          multi_out ? c->st_multi + base * c->multi_bytes : nullptr,
+                          single_out ? c->st_single + base * c->single_bytes : nullptr, any_gm ? c->st_gm + base * S : nullptr);
+        if (rc != BEV_OK) break;
+        e = hipEventRecord(c->out_ready[half], c->stream);
+        if (e != hipSuccess) {
+            rc = hip_fail(c, e, "hipEventRecord", __LINE__);
+            break;
+        }
+        dl.push({f0, nb, half});
+    }
+    dl.close(); /* drains the queue first */
+    if (rc == BEV_OK && dl.err != hipSuccess) rc = hip_fail(c, dl.err, "device -> host copy", __LINE__);
+    if (rc != BEV_OK) (void)hipDeviceSynchronize();
+    return rc;
+}
+
+int bev_host_alloc(void **out, size_t bytes)
+{
+    if (!out) return BEV_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (bytes == 0) return BEV_OK;
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return e == hipErrorOutOfMemory ? BEV_ERR_OOM : BEV_ERR_HIP;
     }
     return BEV_OK;
+}
+
+int bev_host_free(void *p)
+{
+    if (!p) return BEV_OK;
+    return hipHostFree(p) == hipSuccess ? BEV_OK : BEV_ERR_HIP;
 }
 
 int bev_order_cloud(bev_ctx_t *c, const bev_point_t *pts, uint32_t n_pts, bev_point_t *ordered_out)

@@ -23,7 +23,7 @@ def fast_ctx():
     def get(sensor):
         if sensor not in made:
             p = bev_amd.params_for_sensor(sensor)
-            made[sensor] = (p, bev_amd.BevContext(p, device=0, max_batch=8, max_points=800000))
+            made[sensor] = (p, bev_amd.BevContext(p, device=0, max_batch=16, max_points=800000))  # host-buffer calls run in chunks of max_batch / 2
         return made[sensor]
 
     yield get

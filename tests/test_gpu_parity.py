@@ -40,9 +40,9 @@ def _oracle(p, pts):
 
 def _check_batch(p, ctx, frames):
     ordered, multi, single, gm = ctx.process_batch(frames, want_ground_mat=True)
-    navg = min(len(frames), ctx.max_batch)
-    # averages of the LAST sub-batch only
-    first = ((len(frames) - 1) // ctx.max_batch) * ctx.max_batch if frames else 0
+    # the debug hook exposes the averages of the LAST chunk only (host-buffer calls run in chunks of max_batch / 2)
+    chunk = max(1, ctx.max_batch // 2)
+    first = ((len(frames) - 1) // chunk) * chunk if frames else 0
     avg = ctx.cell_avg(0, len(frames) - first) if frames else None
     for i, pts in enumerate(frames):
         o_ord, o_gm, o_multi, o_single, o_avg = _oracle(p, pts)
