@@ -203,7 +203,7 @@ def main() -> int:
             "kernel": dom["name"], "frames_per_launch": per_launch_frames,
             "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": avg_ms,
             "note": "kernel durations from a one-lane pass of the same steps right after the timed region (back-to-back launches); "
-                    "the timed region itself runs two overlapping sub-batch lanes",
+                    "the timed region itself runs the two-stage pipeline (front of sub-batch k+1 beside the back of sub-batch k)",
             "pipeline": {"bytes_per_frame": b_frame, "achieved": pipe_achieved, "frac": pipe_achieved / HBM_PEAK_GBPS,
                          "definition": "algorithmic bytes of the whole hot path / wall time of the timed region, this GPU"},
         }

@@ -199,9 +199,10 @@ int bev_project_xyzi(bev_ctx_t *ctx, int kind, const float *xyzi, uint32_t n, be
 size_t bev_project_out_points(int kind, uint32_t n); /* 0 for an unknown kind */
 
 /* ---- measurement ------------------------------------------------------- */
-/* Sub-batches of bev_process_* are dealt to up to BEV_LANES (default 2, max 4) streams so that kernels of
- * consecutive sub-batches overlap.  bev_set_lanes(ctx, 1) makes them run back to back (clean per-kernel
- * durations for profiling); returns the number of lanes now in use, or a negative status. */
+/* Sub-batches of bev_process_device_resident run as a two-stage pipeline over BEV_LANES (default 2, max 4)
+ * workspace sets, so that the streaming kernels of sub-batch k + 1 overlap the per-frame kernels of sub-batch k
+ * (env BEV_STAGED=0: each lane runs whole sub-batches instead).  bev_set_lanes(ctx, 1) makes everything run back
+ * to back (clean per-kernel durations for profiling); returns the number of lanes now in use, or a negative status. */
 int bev_set_lanes(bev_ctx_t *ctx, int n);
 
 #define BEV_MAX_KERNELS 16

@@ -1,0 +1,69 @@
+"""Turn a scripts/profile_round.sh result directory (gpurun_out/<tag>/) into the files kept under profiles/:
+   <prefix>_kernel_stats.csv          rocprofv3 --kernel-trace --stats summary (one lane)
+   <prefix>_bench_under_rocprof.json  bench.py line of that profiled run
+   <prefix>_bench.json                bench.py line of the unprofiled default run (with the CPU baseline)
+   <prefix>_pmc_traffic.json          per-kernel HBM bytes from the PMC passes (gfx950 corrections applied)
+usage: python scripts/make_profiles.py gpurun_out/<tag> profiles/<prefix>"""
+import collections, csv, glob, json, os, shutil, sys
+
+src, prefix = sys.argv[1], sys.argv[2]
+
+
+def last_json_line(path):
+    for line in reversed(open(path).read().splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            return json.loads(line)
+    raise SystemExit(f"no JSON line in {path}")
+
+
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], prefix + "_kernel_stats.csv")
+for name, out in (("bench_under_rocprof.log", "_bench_under_rocprof.json"), ("bench.log", "_bench.json")):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        json.dump(last_json_line(p), open(prefix + out, "w"), indent=1)
+
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bevk::", "")
+        if not k.startswith("k_") and "fillBuffer" not in k:
+            continue
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k][r["Counter_Name"]] += 1
+frames = 256
+out = {"source": "rocprofv3 --pmc (one counter group per run), bench.py --frames 256 --sub-batch 256, BEV_LANES=1; "
+                 "per-launch means",
+       "frames_per_launch": frames,
+       "corrections": "FETCH_SIZE is reported in KiB and counts 128-B requests as 64 B on gfx950 (MI355X_MICROARCH.md, "
+                      "HBM): hbm_read_bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE KiB is exact",
+       "kernels": {}}
+total = 0.0
+for k in sorted(agg):
+    m = {c: agg[k][c] / cnt[k][c] for c in agg[k]}
+    e = {}
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        e["hbm_read_bytes_per_launch"] = 2 * m["FETCH_SIZE"] * 1024
+        e["hbm_write_bytes_per_launch"] = m["WRITE_SIZE"] * 1024
+        e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+        e["hbm_bytes_per_frame"] = e["hbm_bytes_per_launch"] / frames
+        e["FETCH_SIZE_KiB_raw"], e["WRITE_SIZE_KiB"] = m["FETCH_SIZE"], m["WRITE_SIZE"]
+        total += e["hbm_bytes_per_frame"]
+    if "TCC_EA0_RDREQ_sum" in m:
+        e["TCC_EA0_RDREQ"], e["TCC_EA0_WRREQ"] = m["TCC_EA0_RDREQ_sum"], m.get("TCC_EA0_WRREQ_sum")
+    if "TCC_HIT_sum" in m and m["TCC_HIT_sum"] + m.get("TCC_MISS_sum", 0) > 0:
+        e["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+    if "SQ_WAIT_ANY" in m and m.get("SQ_WAVE_CYCLES"):
+        e["SQ_WAIT_ANY_over_WAVE_CYCLES"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
+    for a, b in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_INSTS_VMEM_RD", "vmem_rd_insts"), ("SQ_INSTS_VMEM_WR", "vmem_wr_insts"),
+                 ("SQ_INSTS_LDS", "lds_insts")):
+        if a in m:
+            e[b] = m[a]
+    out["kernels"][k] = e
+out["hbm_bytes_per_frame_all_kernels"] = total
+if agg:
+    json.dump(out, open(prefix + "_pmc_traffic.json", "w"), indent=1)
+print("wrote", sorted(glob.glob(prefix + "_*")), "total HBM bytes per frame:", round(total))
