@@ -5,10 +5,11 @@
  * that runs once per dataset; no GPU involved.
  *
  * Without Eigen / nanoflann: 3x3 matrices are plain arrays and the k-NN searches
- * are exhaustive scans using nanoflann's L2 evaluation order for 3-D points
- * (((dx*dx) + dy*dy) + dz*dz in float), so distances are bit-identical; only the
- * choice between two EXACTLY equidistant major frames could differ from a
- * KD-tree traversal.
+ * restate nanoflann 1.3.2's KD-tree for 3-D float points (split rule, partition,
+ * traversal, result-set insertion; distances ((dx*dx) + dy*dy) + dz*dz in float),
+ * so that even the choice between exactly equidistant major frames is the
+ * reference's.  Checked against the reference's own nanoflann.hpp in
+ * tests/test_label_step_cpu.py.
  */
 #ifndef BEV_HOST_LABELSTEP_H
 #define BEV_HOST_LABELSTEP_H
@@ -35,5 +36,9 @@ std::vector<int32_t> selectMajorFrames(std::vector<Pose6f> &keyframe_pose);     
 std::vector<LabelType> getKeyFrameLabel(std::vector<Pose6f> &key_frame_poses,
                                         std::vector<int32_t> &major_frame_indeices);             /* :575-636 */
 bool saveLabels(std::vector<LabelType> key_frame_labels, std::string label_filename);              /* :645-661 */
+
+/* the k-NN both functions above use (KD-tree over 3-D positions, see LabelStep.cpp); exposed for the tests */
+void nearestPositions(const std::vector<std::vector<float>> &positions, const std::vector<float> &query, size_t k,
+                      std::vector<size_t> &indices, std::vector<float> &dists_sqr);
 
 #endif

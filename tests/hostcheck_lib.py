@@ -33,6 +33,10 @@ def lib():
         l.hc_project_kitti.restype = None
         l.hc_kitti_ring_min.argtypes = [vp]
         l.hc_kitti_ring_min.restype = None
+        l.hc_select_major_frames.argtypes = [vp, C.c_uint32, vp]
+        l.hc_select_major_frames.restype = C.c_uint32
+        l.hc_keyframe_labels.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp]
+        l.hc_keyframe_labels.restype = None
         l.hc_exhaustive_exact_forms.argtypes = [vp]
         l.hc_exhaustive_exact_forms.restype = None
         l.hc_derive_angle_threshold.argtypes = [vp]
@@ -75,4 +79,19 @@ def project(kind: int, xyzi):
         return out
     out = np.empty(n, POINT_DTYPE)
     lib().hc_project(kind, xyzi.ctypes.data, n, out.ctypes.data)
+    return out
+
+
+def select_major_frames(xyz):
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    out = np.empty(len(xyz), np.int32)
+    m = lib().hc_select_major_frames(xyz.ctypes.data, len(xyz), out.ctypes.data)
+    return out[:m].copy()
+
+
+def keyframe_labels(xyz, major):
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    major = np.ascontiguousarray(major, np.int32)
+    out = np.empty((len(xyz), len(major)), np.float32)
+    lib().hc_keyframe_labels(xyz.ctypes.data, len(xyz), major.ctypes.data, len(major), out.ctypes.data)
     return out
