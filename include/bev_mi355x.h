@@ -226,9 +226,6 @@ int bev_profile_get(bev_ctx_t *ctx, bev_kernel_stat_t *out, int cap);
  * n_frames * 3750 floats (ground_grid_avg_heights after BatchMultiBevGen.cpp:210), first_frame counted
  * from the start of that sub-batch. */
 int bev_debug_get_cell_avg(bev_ctx_t *ctx, int first_frame, int n_frames, float *out);
-/* Sorted-prefix fast path of the LAST sub-batch processed: per frame, the prefix length M
- * that was tried and whether verification failed (frame redone by the general path). */
-int bev_debug_get_fast_path(bev_ctx_t *ctx, int n_frames, uint32_t *prefix_len, uint32_t *failed);
 /* Evaluates the phase-A angle predicate (BatchMultiBevGen.cpp:169-179) on the
  * device for n (dx,dy,dz) triples given as HOST arrays; out[i] = 1 if GROUND. */
 int bev_debug_angle_predicate(bev_ctx_t *ctx, const float *dx, const float *dy,

@@ -75,7 +75,7 @@ ABI_SYMBOLS = [
     "bev_order_cloud", "bev_mark_ground", "bev_multi_bev", "bev_single_bev",
     "bev_float_bev", "bev_float_bev_size", "bev_project_xyzi", "bev_project_out_points", "bev_host_alloc", "bev_host_free",
     "bev_set_lanes", "bev_profile_enable", "bev_profile_reset", "bev_profile_get",
-    "bev_debug_get_cell_avg", "bev_debug_get_fast_path", "bev_debug_angle_predicate", "bev_abi_version",
+    "bev_debug_get_cell_avg", "bev_debug_angle_predicate", "bev_abi_version",
 ]
 
 
@@ -136,7 +136,6 @@ def load_lib() -> C.CDLL:
     lib.bev_profile_reset.argtypes = [vp]
     lib.bev_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32]
     lib.bev_debug_get_cell_avg.argtypes = [vp, i32, i32, vp]
-    lib.bev_debug_get_fast_path.argtypes = [vp, i32, vp, vp]
     lib.bev_debug_angle_predicate.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.bev_abi_version.restype = i32
     _lib = lib
@@ -296,12 +295,6 @@ class BevContext:
         self._check(self.lib.bev_debug_get_cell_avg(self._h, first_frame, n_frames, _ptr(out)),
                     "bev_debug_get_cell_avg")
         return out
-
-    def fast_path_stats(self, n_frames):
-        ln = np.empty(n_frames, np.uint32)
-        fl = np.empty(n_frames, np.uint32)
-        self._check(self.lib.bev_debug_get_fast_path(self._h, n_frames, _ptr(ln), _ptr(fl)), "bev_debug_get_fast_path")
-        return ln, fl
 
     def angle_predicate(self, dx, dy, dz):
         dx = np.ascontiguousarray(dx, dtype=np.float32)

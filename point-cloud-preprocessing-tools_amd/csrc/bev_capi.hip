@@ -48,7 +48,6 @@ struct Lane {
     float *cand_z = nullptr;
     uint2 *cand_aux = nullptr;
     uint32_t *ncand = nullptr;
-    uint32_t *fast_len = nullptr, *fast_fail = nullptr, *bounds = nullptr, *tail_bits = nullptr;
     float *zsorted = nullptr;
     float *avg = nullptr;
     int8_t *gm = nullptr; /* lazily allocated */
@@ -71,7 +70,6 @@ struct bev_ctx {
     int n_lanes = 1;
     int n_lanes_active = 1; /* <= n_lanes; bev_set_lanes */
     bool staged = true;     /* two-stage pipeline, see run_pipeline; BEV_STAGED=0 falls back to free-running lanes */
-    bool fast_path = false; /* BEV_FAST=1 enables the (experimental) sorted-prefix fast path */
     hipEvent_t fork_ev = nullptr;
     hipEvent_t stagger_ev = nullptr; /* recorded on a lane after its bandwidth-bound kernels */
     bool staggered[kMaxLanes] = {false, false, false, false};
@@ -79,7 +77,6 @@ struct bev_ctx {
     uint32_t *codes = nullptr;
     size_t codes_elems = 0;
     float *last_avg = nullptr;
-    uint32_t *last_fast_len = nullptr, *last_fast_fail = nullptr;
 
     /* frame descriptors: ring of pinned host + device arrays */
     FrameDesc *h_desc[kDescRing] = {nullptr, nullptr, nullptr, nullptr};
@@ -163,8 +160,6 @@ void fill_geometry(const bev_params_t *p, Geometry *g)
     g->tiles = (g->S + kTile - 1) / kTile;
     g->strips = (g->H + kStripCols - 1) / kStripCols;
     g->segs = (g->G + 1) * g->strips;
-    g->rs_tiles = g->N * g->strips;
-    g->bit_words = (g->S + 31) / 32;
     g->rp.max_range_f = (float)p->max_range;
     g->rp.interval = p->interval;
     g->rp.height_res = p->height_res;
@@ -303,10 +298,6 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.cand_z = ln.cand_z;
         b.cand_aux = ln.cand_aux;
         b.ncand = ln.ncand;
-        b.fast_len = ln.fast_len;
-        b.fast_fail = ln.fast_fail;
-        b.bounds = ln.bounds;
-        b.tail_bits = ln.tail_bits;
         b.zsorted = ln.zsorted;
         b.avg = ln.avg;
         b.gm = d_gm ? ln.gm : nullptr;
@@ -315,39 +306,18 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
 
         if (identity) {
             ProfScope ps(c, K_GATHER_GROUND, nb, st);
-            launch_gather_ground(g, b, nb, STRIP_IDENTITY, false, st);
+            launch_gather_ground(g, b, nb, true, st);
         } else {
             uint32_t max_pts = 0;
             for (int f = 0; f < nb; ++f) max_pts = std::max(max_pts, c->h_desc[ds][f0 + f].n_pts);
-            if (c->fast_path) {
-                /* sorted-prefix fast path: verified while consumed; flagged frames fall through to the general path */
-                HIPCK(c, hipMemsetAsync(ln.tail_bits, 0, (size_t)nb * g.bit_words * sizeof(uint32_t), st));
-                {
-                    ProfScope ps(c, K_PREFIX_LEN, nb, st);
-                    launch_prefix_probe(g, b, nb, st);
-                }
-                {
-                    ProfScope ps(c, K_TAIL_SCAN, nb, st);
-                    launch_tail_scan(g, b, nb, max_pts, st);
-                }
-                {
-                    ProfScope ps(c, K_STRIP_FAST, nb, st);
-                    launch_gather_ground(g, b, nb, STRIP_FAST, false, st);
-                }
-                {
-                    ProfScope ps(c, K_WINNER_ZERO, nb, st);
-                    launch_winner_zero_failed(g, b, nb, st);
-                }
-            } else {
-                HIPCK(c, hipMemsetAsync(ln.winner, 0, (size_t)nb * S * sizeof(uint32_t), st));
-            }
+            HIPCK(c, hipMemsetAsync(ln.winner, 0, (size_t)nb * S * sizeof(uint32_t), st));
             {
                 ProfScope ps(c, K_ORDER_SCAN, nb, st);
-                launch_order_scan(g, b, nb, max_pts, c->fast_path, st);
+                launch_order_scan(g, b, nb, max_pts, st);
             }
             {
                 ProfScope ps(c, K_GATHER_GROUND, nb, st);
-                launch_gather_ground(g, b, nb, STRIP_GENERAL, c->fast_path, st);
+                launch_gather_ground(g, b, nb, false, st);
             }
         }
         /* One-time stagger: a lane's FIRST sub-batch starts only after the previous lane has issued its
@@ -387,8 +357,6 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         if (staged) HIPCK(c, hipEventRecord(ln.back_done, st));
         c->last_sub_frames = nb;
         c->last_avg = ln.avg;
-        c->last_fast_len = ln.fast_len;
-        c->last_fast_fail = ln.fast_fail;
         HIPCK(c, hipGetLastError());
     }
     /* join: the main stream continues after every lane */
@@ -525,8 +493,6 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         int nl = e ? atoi(e) : 2;
         c->n_lanes = std::max(1, std::min(kMaxLanes, nl));
         c->n_lanes_active = c->n_lanes;
-        const char *fp = getenv("BEV_FAST");
-        c->fast_path = fp && atoi(fp) != 0;
         const char *sg = getenv("BEV_STAGED");
         c->staged = (!sg || atoi(sg) != 0) && c->n_lanes >= 2;
     }
@@ -552,11 +518,6 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipMalloc((void **)&ln.cand_z, nb * (size_t)c->geo.segs * kSeg * sizeof(float)));
         CK(hipMalloc((void **)&ln.cand_aux, nb * (size_t)c->geo.segs * kSeg * sizeof(uint2)));
         CK(hipMalloc((void **)&ln.ncand, nb * (size_t)c->geo.segs * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.fast_len, nb * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.fast_fail, nb * sizeof(uint32_t)));
-        CK(hipMemset(ln.fast_fail, 0, nb * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.bounds, nb * (size_t)(c->geo.rs_tiles + 1) * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.tail_bits, nb * (size_t)c->geo.bit_words * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.zsorted, nb * S * sizeof(float)));
         CK(hipMalloc((void **)&ln.avg, nb * (size_t)bevx::kGridCells * sizeof(float)));
     }
@@ -583,8 +544,7 @@ void bev_destroy(bev_ctx_t *c)
     for (int l = 0; l < kMaxLanes; ++l) {
         Lane &ln = c->lanes[l];
         if (ln.st) (void)hipStreamSynchronize(ln.st);
-        void *ws[] = {ln.winner, ln.codes, ln.cand_cell, ln.cand_z, ln.cand_aux, ln.ncand, ln.zsorted, ln.avg, ln.gm,
-                      ln.fast_len, ln.fast_fail, ln.bounds, ln.tail_bits};
+        void *ws[] = {ln.winner, ln.codes, ln.cand_cell, ln.cand_z, ln.cand_aux, ln.ncand, ln.zsorted, ln.avg, ln.gm};
         for (void *p : ws)
             if (p) (void)hipFree(p);
         if (ln.done) (void)hipEventDestroy(ln.done);
@@ -813,7 +773,7 @@ int bev_order_cloud(bev_ctx_t *c, const bev_point_t *pts, uint32_t n_pts, bev_po
     HIPCK(c, hipMemsetAsync(c->winner, 0, S * sizeof(uint32_t), c->stream));
     {
         ProfScope ps(c, K_ORDER_SCAN, 1);
-        launch_order_scan(g, b, 1, n_pts, false, c->stream);
+        launch_order_scan(g, b, 1, n_pts, c->stream);
     }
     {
         ProfScope ps(c, K_GATHER_ONLY, 1);
@@ -1050,16 +1010,6 @@ int bev_debug_get_cell_avg(bev_ctx_t *c, int first_frame, int n_frames, float *o
     if (!c->last_avg) return BEV_ERR_INVALID_ARG;
     HIPCK(c, hipMemcpy(out, c->last_avg + (size_t)first_frame * bevx::kGridCells,
                        (size_t)n_frames * bevx::kGridCells * sizeof(float), hipMemcpyDeviceToHost));
-    return BEV_OK;
-}
-
-int bev_debug_get_fast_path(bev_ctx_t *c, int n_frames, uint32_t *prefix_len, uint32_t *failed)
-{
-    if (!c || n_frames < 0 || n_frames > c->last_sub_frames || !c->last_fast_len) return BEV_ERR_INVALID_ARG;
-    HIPCK(c, hipSetDevice(c->device));
-    HIPCK(c, hipDeviceSynchronize());
-    if (prefix_len) HIPCK(c, hipMemcpy(prefix_len, c->last_fast_len, (size_t)n_frames * 4, hipMemcpyDeviceToHost));
-    if (failed) HIPCK(c, hipMemcpy(failed, c->last_fast_fail, (size_t)n_frames * 4, hipMemcpyDeviceToHost));
     return BEV_OK;
 }
 

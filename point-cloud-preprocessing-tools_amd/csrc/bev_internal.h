@@ -50,8 +50,6 @@ struct Geometry {
     int tiles;         /* ceil(S / kTile): slot tiles of the per-slot kernels */
     int strips;        /* ceil(H / kStripCols): column strips of the walk kernel */
     int segs;          /* (G + 1) * strips: candidate segments per frame, row-major */
-    int rs_tiles;      /* N * strips: (row, strip) tiles of the sorted-prefix fast path */
-    int bit_words;     /* ceil(S / 32): words of the per-frame tail bitmap */
     bevx::RasterParams rp;
 };
 
@@ -66,11 +64,6 @@ struct BatchPtrs {
     float *cand_z;               /* [nf][segs][kSeg] */
     uint2 *cand_aux;             /* [nf][segs][kSeg] */
     uint32_t *ncand;             /* [nf][segs] */
-    /* sorted-prefix fast path (see k_strip_ground) */
-    uint32_t *fast_len;          /* [nf]   M: verified-candidate length of the slot-sorted prefix */
-    uint32_t *fast_fail;         /* [nf]   != 0: prefix verification failed, frame redone by the general path */
-    uint32_t *bounds;            /* [nf][rs_tiles + 1] input index where tile (row, strip) starts */
-    uint32_t *tail_bits;         /* [nf][bit_words] slots overridden by a point of the tail [M, P) */
     float *zsorted;              /* [nf][S] */
     float *avg;                  /* [nf][3750] */
     int8_t *gm;                  /* [nf][S] or nullptr: phase-A ground_mat */
@@ -90,24 +83,14 @@ enum KernelId {
     K_ANGLE_DEBUG,
     K_FLOAT_BEV,
     K_PROJECT,
-    K_PREFIX_LEN,
-    K_PREFIX_BOUNDS,
-    K_TAIL_ZERO,
-    K_TAIL_SCAN,
-    K_STRIP_FAST,
-    K_WINNER_ZERO,
     K_COUNT
 };
 const char *kernel_name(int id);
 
 /* launchers (bev_kernels.hip) — all asynchronous on `st` */
-enum StripMode { STRIP_GENERAL = 0, STRIP_IDENTITY = 1, STRIP_FAST = 2 };
-/* only_failed: act only on frames whose fast_fail flag is set */
-void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, bool only_failed, hipStream_t st);
-void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, StripMode mode, bool only_failed, hipStream_t st);
-void launch_prefix_probe(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
-void launch_tail_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, hipStream_t st);
-void launch_winner_zero_failed(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
+void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, hipStream_t st);
+/* the column walk; identity: b.pts already is the ordered cloud (bev_mark_ground) */
+void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st);
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
 void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);

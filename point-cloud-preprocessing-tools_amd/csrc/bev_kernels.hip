@@ -32,7 +32,6 @@ namespace bevk {
 static const char *const kNames[K_COUNT] = {
     "k_order_scan", "k_strip_ground", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project",
-    "k_prefix_len", "k_prefix_bounds", "k_tail_zero", "k_tail_scan", "k_strip_ground_fast", "k_winner_zero_failed",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
 
@@ -59,11 +58,9 @@ constexpr int kScanIdxBits = 10; /* 256 * kScanPerThread = 1024 points per block
 constexpr int kScanRowBins = 128; /* rows the LDS regrouping below can bin (more rows: plain path) */
 __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restrict__ pts,
                                                     const FrameDesc *__restrict__ frames,
-                                                    uint32_t *__restrict__ winner, int N, int H, int S,
-                                                    const uint32_t *__restrict__ only_failed)
+                                                    uint32_t *__restrict__ winner, int N, int H, int S)
 {
     const int f = blockIdx.y;
-    if (only_failed && only_failed[f] == 0u) return;
     const FrameDesc fd = frames[f];
     const uint32_t base = blockIdx.x * (256u * kScanPerThread) + threadIdx.x;
     if (blockIdx.x * (256u * kScanPerThread) >= fd.n_pts) return;
@@ -170,130 +167,6 @@ struct SlotFetch {
 };
 
 /* ------------------------------------------------------------------------- */
-/* SORTED-PREFIX FAST PATH.
- *
- * The general path reads the input twice: k_order_scan (all points -> winner table) and the column
- * walk (winner -> point).  Structured clouds — and BASELINE's synthetic sweeps — come in slot order
- * with few exceptions, e.g. a tail of appended duplicates.  For such a frame the first read is
- * avoidable, WITHOUT trusting the input:
- *   k_prefix_len     guesses M, the length of the slot-sorted prefix (sampled, then refined);
- *   k_prefix_bounds  binary-searches, as if [0, M) were sorted, where each (row, strip) tile starts;
- *   k_tail_zero/scan builds the winner table for the tail [M, P) only, plus a bitmap of the slots it
- *                    overrides (a tail point has a larger input index than any prefix point, so it
- *                    wins its slot: last writer wins);
- *   the column walk (STRIP_FAST) reads each tile's points where the bounds say they are and VERIFIES
- *   while it consumes them: tiles are contiguous and ascending, every point of a tile lies in that
- *   tile's slot range, and slots inside a tile strictly increase.  Together that proves [0, M) is
- *   strictly slot-sorted, hence duplicate-free, hence each slot's prefix owner is the point found.
- *   Any violation sets the frame's fail flag; flagged frames are redone by the general path
- *   (k_winner_zero_failed + k_order_scan + column walk, all predicated on the flag).
- * Results never depend on the guesses: a wrong M or wrong bounds can only cost speed. */
-__device__ __forceinline__ uint32_t point_slot(const bev_point_t *p, uint32_t i, int N, int H)
-{
-    const uint32_t rc = reinterpret_cast<const uint32_t *>(p + i)[5];
-    const uint32_t row = rc & 0xffffu, col = rc >> 16;
-    return (row < (uint32_t)N && col < (uint32_t)H) ? row * (uint32_t)H + col : 0xffffffffu;
-}
-
-__global__ __launch_bounds__(256) void k_prefix_len(BatchPtrs b, Geometry g)
-{
-    const int f = blockIdx.x, tid = threadIdx.x;
-    const FrameDesc fd = b.frames[f];
-    const bev_point_t *fp = b.pts + fd.in_offset;
-    const uint32_t P = fd.n_pts;
-    __shared__ uint32_t first_bad, best;
-    if (tid == 0) { first_bad = 256u; best = 0xffffffffu; }
-    __syncthreads();
-    const uint32_t step = P / 256u + 1u;
-    /* coarse: 256 samples of "slot(i) is valid and >= i" (true on a sorted duplicate-free prefix) */
-    {
-        const uint32_t i = (uint32_t)tid * step;
-        bool bad = false;
-        if (i < P) {
-            const uint32_t s = point_slot(fp, i, g.N, g.H);
-            bad = (s == 0xffffffffu) || (s < i);
-        } else {
-            bad = true; /* virtual sample past the end */
-        }
-        if (bad) atomicMin(&first_bad, (uint32_t)tid);
-    }
-    __syncthreads();
-    const uint32_t kb = first_bad; /* 256 if none: then 256*step > P, the window below ends at P */
-    const uint32_t start = kb == 0u ? 0u : (kb - 1u) * step;
-    const uint32_t end = min(P, kb * step); /* exclusive bound of the refine scan, M <= end */
-    /* refine: first index in [start, end) that breaks "valid, >= i, strictly above its predecessor" */
-    for (uint32_t i = start + tid; i < end; i += 256u) {
-        const uint32_t s = point_slot(fp, i, g.N, g.H);
-        bool ok = (s != 0xffffffffu) && (s >= i);
-        if (ok && i > 0u) {
-            const uint32_t sp = point_slot(fp, i - 1u, g.N, g.H);
-            ok = (sp != 0xffffffffu) && (s > sp);
-        }
-        if (!ok) atomicMin(&best, i);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        b.fast_len[f] = min(best, end);
-        b.fast_fail[f] = 0u;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_prefix_bounds(BatchPtrs b, Geometry g)
-{
-    const int f = blockIdx.y;
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t > (uint32_t)g.rs_tiles) return;
-    const bev_point_t *fp = b.pts + b.frames[f].in_offset;
-    const uint32_t M = b.fast_len[f];
-    uint32_t lo = 0u, hi = M;
-    if (t < (uint32_t)g.rs_tiles) {
-        const uint32_t row = t / (uint32_t)g.strips, strip = t - row * (uint32_t)g.strips;
-        const uint32_t target = row * (uint32_t)g.H + strip * (uint32_t)kStripCols; /* first slot of the tile */
-        while (lo < hi) { /* lower_bound under the sortedness assumption (verified later) */
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (point_slot(fp, mid, g.N, g.H) < target) lo = mid + 1u; else hi = mid;
-        }
-    } else {
-        lo = M;
-    }
-    b.bounds[(size_t)f * (g.rs_tiles + 1) + t] = lo;
-}
-
-/* winner table + override bitmap for the tail [M, P): zero first (plain stores), then atomicMax */
-constexpr int kTailBlocks = 8; /* workgroups per frame; they stride over the tail */
-template <bool kZero>
-__global__ __launch_bounds__(256) void k_tail(BatchPtrs b, Geometry g)
-{
-    const int f = blockIdx.y;
-    const FrameDesc fd = b.frames[f];
-    const uint32_t M = b.fast_len[f];
-    const bev_point_t *fp = b.pts + fd.in_offset;
-    uint32_t *fw = b.winner + (size_t)f * g.S;
-    uint32_t *bits = b.tail_bits + (size_t)f * g.bit_words;
-    for (uint32_t i = M + blockIdx.x * 256u + threadIdx.x; i < fd.n_pts; i += kTailBlocks * 256u) {
-        const uint32_t s = point_slot(fp, i, g.N, g.H);
-        if (s == 0xffffffffu) continue; /* BatchMultiBevGen.cpp:106-111 */
-        if (kZero) {
-            fw[s] = 0u;
-        } else {
-            atomicMax(&fw[s], i + 1u);
-            atomicOr(&bits[s >> 5], 1u << (s & 31u));
-        }
-    }
-}
-
-/* frames whose prefix verification failed get a clean winner table for the general path */
-__global__ __launch_bounds__(256) void k_winner_zero_failed(BatchPtrs b, Geometry g)
-{
-    const int f = blockIdx.y;
-    if (b.fast_fail[f] == 0u) return;
-    uint4 *w = reinterpret_cast<uint4 *>(b.winner + (size_t)f * g.S);
-    const int n16 = g.S / 4;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) w[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (blockIdx.x == 0 && threadIdx.x < (g.S & 3)) b.winner[(size_t)f * g.S + (size_t)n16 * 4 + threadIdx.x] = 0u;
-}
-
-/* ------------------------------------------------------------------------- */
 /* getOrderedCloud gather + markGroundPoints phase A, as a COLUMN WALK.
  *
  * A workgroup owns kStripCols (252) adjacent columns of one frame plus two halo
@@ -323,13 +196,10 @@ struct PendingRow {
     int gflag;       /* ground_mat(row) at the end of phase A */
 };
 
-template <int kMode>
-__global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geometry g, int only_failed)
+template <bool kIdentity>
+__global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geometry g)
 {
-    constexpr bool kIdentity = kMode == STRIP_IDENTITY;
-    constexpr bool kFast = kMode == STRIP_FAST;
     const int f = blockIdx.x / g.strips, strip = blockIdx.x - f * g.strips;
-    if (only_failed && b.fast_fail[f] == 0u) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int N = g.N, H = g.H, lo_row = g.N - g.G;
     const size_t frame_off = (size_t)f * g.S;
@@ -357,150 +227,6 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         return fwin[fl];
     };
 
-    /* ---- fast mode: the winners of a row come from the tile's own input range ---- */
-    /* (sized 1 in the other modes: the general walk keeps its LDS under 1 KiB so that 7 of its workgroups
-     * fit beside a 151 KiB cell-sum workgroup on one CU) */
-    __shared__ uint32_t idx[2][kFast ? kStripThreads : 1]; /* row q -> idx[q & 1][pos] = input index + 1 of virtual column pos */
-    __shared__ Half rowpts[2][kFast ? kStripThreads : 1][2]; /* ... and the point itself (lo, hi halves) */
-    constexpr int kMaxRowsLds = 128;           /* rows whose tile bounds are staged in LDS (else read from global) */
-    __shared__ uint32_t bnd_lds[kFast ? kMaxRowsLds : 1][3]; /* per row: tile start, tile end, row start */
-    const uint32_t M = kFast ? b.fast_len[f] : 0u;
-    const uint32_t *bnd = kFast ? b.bounds + (size_t)f * (g.rs_tiles + 1) : nullptr;
-    const bool bnd_staged = kFast && N <= kMaxRowsLds;
-    if (bnd_staged) {
-        for (int q = tid; q < N; q += kStripThreads) {
-            bnd_lds[q][0] = bnd[q * g.strips + strip];
-            bnd_lds[q][1] = bnd[q * g.strips + strip + 1];
-            bnd_lds[q][2] = bnd[q * g.strips];
-        }
-    }
-    const uint32_t *bits = kFast ? b.tail_bits + (size_t)f * g.bit_words : nullptr;
-    const bool last_strip = strip == g.strips - 1;
-    /* override bitmap of this strip, staged once: per row the 10 words that cover its 256 virtual columns
-     * (plus, for the last strip, the word of the wrapped columns 0 and 1) */
-    constexpr int kBitWords = 10;
-    __shared__ uint32_t tbits[kFast ? kMaxRowsLds : 1][kBitWords + 1];
-    if (bnd_staged) {
-        for (int e = tid; e < N * (kBitWords + 1); e += kStripThreads) {
-            const int q = e / (kBitWords + 1), k = e - q * (kBitWords + 1);
-            uint32_t wv_ = 0u;
-            if (k < kBitWords) {
-                const int first = q * H + strip * kStripCols - 2;          /* may be negative for q = 0 */
-                const int wi = (first >= 0 ? first >> 5 : -1) + k;
-                if (wi >= 0 && wi < g.bit_words) wv_ = bits[wi];
-            } else {
-                wv_ = bits[(q * H) >> 5];                                   /* columns 0, 1 of the row */
-            }
-            tbits[q][k] = wv_;
-        }
-    }
-    bool my_fail = false;
-    /* Candidate of thread tid for row q: the input point at index ci (< 0: none), loaded WHOLE and fully
-     * coalesced (consecutive threads read consecutive input points: 8 KiB per row), then dropped into the LDS
-     * row buffer at the virtual column its row / col fields say. */
-    struct Cand { int ci; int cnt; bool wrap; uint32_t prev_slot; Half lo, hi; };
-    auto load_cand = [&](int q) -> Cand {
-        Cand k;
-        k.ci = -1; k.cnt = 0; k.wrap = false; k.prev_slot = 0xffffffffu;
-        k.lo = Half{{0, 0, 0, 0}};
-        k.hi = Half{{0, 0, 0, 0}};
-        if (q >= N) return k;
-        const uint32_t a = bnd_staged ? bnd_lds[q][0] : bnd[q * g.strips + strip];
-        const uint32_t e = bnd_staged ? bnd_lds[q][1] : bnd[q * g.strips + strip + 1];
-        const int cnt = (int)e - (int)a;
-        k.cnt = cnt;
-        if (cnt < 0 || cnt > kStripCols) return k; /* flagged in place_cand */
-        int ci = (int)a - 2 + tid;                 /* input indices fit 31 bits: bev_create caps max_points */
-        if (last_strip && tid >= cnt + 2 && tid < cnt + 4) { /* right halo wraps to columns 0, 1 of the same row */
-            ci = (int)(bnd_staged ? bnd_lds[q][2] : bnd[q * g.strips]) + (tid - (cnt + 2));
-            k.wrap = true;
-        }
-        if (tid < cnt + 4 && ci >= 0 && ci < (int)M) {
-            k.ci = ci;
-            const Half *src = reinterpret_cast<const Half *>(fpts + ci);
-            k.lo = src[0];
-            k.hi = src[1];
-            /* a wave's first lane cannot get its left neighbour's slot by shuffle: fetch that key now */
-            if (lane == 0 && tid > 2 && ci > 0 && !k.wrap) k.prev_slot = point_slot(fpts, (uint32_t)ci - 1u, N, H);
-        }
-        return k;
-    };
-    auto slot_of = [&](const Half &hi) -> uint32_t {
-        const uint32_t row = hi.w[1] & 0xffffu, col = hi.w[1] >> 16;
-        return (row < (uint32_t)N && col < (uint32_t)H) ? row * (uint32_t)H + col : 0xffffffffu;
-    };
-    auto place_cand = [&](int q, const Cand &k) {
-        if (q >= N) return; /* workgroup-uniform */
-        const uint32_t cs = k.ci >= 0 ? slot_of(k.hi) : 0xffffffffu;
-        /* slot of the candidate one thread to the left (the previous input point for main points) */
-        uint32_t cprev = __shfl_up(cs, 1);
-        if (lane == 0) cprev = k.prev_slot;
-        if (k.cnt < 0 || k.cnt > kStripCols) { my_fail = true; return; }
-        if (k.ci < 0) return;
-        const int base = q * H + strip * kStripCols - 2; /* flat slot of pos 0 (may be -2) */
-        const bool main_pt = !k.wrap && tid >= 2 && tid < k.cnt + 2;
-        int pos = -1;
-        if (cs != 0xffffffffu) {
-            if (k.wrap) {
-                const int w = (int)cs - q * H; /* 0 or 1 expected */
-                if (w >= 0 && w < 2) pos = H + w - (strip * kStripCols - 2);
-            } else if ((int)cs < (q + 1) * H) {
-                pos = (int)cs - base;
-            }
-        }
-        if (main_pt) {
-            /* verification: in the tile's own column range, strictly above the previous point.  With both
-             * true for every tile, [0, M) is strictly slot-sorted, so no two candidates share a position. */
-            if (pos < 2 || pos >= 2 + kStripCols) { my_fail = true; return; }
-            if (tid > 2 && !(cprev != 0xffffffffu && cprev < cs)) { my_fail = true; return; }
-        }
-        if (pos >= 0 && pos < kStripThreads) {
-            rowpts[q & 1][pos][0] = k.lo;
-            rowpts[q & 1][pos][1] = k.hi;
-            idx[q & 1][pos] = (uint32_t)k.ci + 1u;
-        }
-    };
-    auto tail_word = [&](int q) -> uint32_t { /* override bitmap word of this thread's slot in row q */
-        if (!provider || q >= N) return 0u;
-        const int fl = q * H + vcol;
-        if (fl < 0) return 0u;
-        if (!bnd_staged) return bits[fl >> 5];
-        if (v >= H) return tbits[q][kBitWords];                             /* wrapped right halo */
-        const int first = q * H + strip * kStripCols - 2;
-        return tbits[q][(fl >> 5) - (first >= 0 ? first >> 5 : -1)];
-    };
-    /* Tail overrides (a slot whose last writer sits in the tail [M, P)) are fetched ahead of time by the
-     * thread that owns the virtual column: the tail winner index three rows ahead, the point two rows ahead.
-     * Nearly every wave has some overridden lane in every row, so waiting for these loads where they are
-     * needed would stall every row. */
-    auto tail_bit = [&](int q) -> bool {
-        if (!provider || q >= N) return false;
-        const int fl = q * H + vcol;
-        return fl >= 0 && ((tail_word(q) >> (fl & 31)) & 1u);
-    };
-    auto issue_tail_winner = [&](int q) -> uint32_t { return tail_bit(q) ? fwin[q * H + vcol] : 0u; };
-    auto issue_tail_point = [&](uint32_t w, Half &lo, Half &hi) {
-        if (w != 0u) {
-            const Half *src = reinterpret_cast<const Half *>(fpts + (w - 1u));
-            lo = src[0];
-            hi = src[1];
-        }
-    };
-    /* the point of this thread's virtual column in row q, after the barrier that follows place_cand(q) */
-    auto fast_point = [&](int q, uint32_t ovr_w, const Half &ovr_lo, const Half &ovr_hi, Half &lo, Half &hi) {
-        const uint32_t have = idx[q & 1][tid];
-        idx[q & 1][tid] = 0u;
-        lo = Half{{0, 0, 0, 0}};
-        hi = Half{{0, 0, 0, 0}};
-        if (!provider || q >= N) return;
-        if (ovr_w != 0u) { /* a tail point owns this slot (last writer wins) */
-            lo = ovr_lo;
-            hi = ovr_hi;
-        } else if (have != 0u) {
-            lo = rowpts[q & 1][tid][0];
-            hi = rowpts[q & 1][tid][1];
-        }
-    };
     auto load_point = [&](uint32_t w, Half &lo, Half &hi) {
         lo = Half{{0, 0, 0, 0}};
         hi = Half{{0, 0, 0, 0}};
@@ -513,39 +239,12 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
 
     /* software pipeline: nxt = point of the row about to be processed, w_next = winner of the row after it */
     Half cur_lo, cur_hi, nxt_lo, nxt_hi;
-    Half nx2_lo{{0, 0, 0, 0}}, nx2_hi{{0, 0, 0, 0}}; /* general/identity: point of row r+2 (two rows in flight) */
-    uint32_t w_next = 0u, w_nx2 = 0u;                /* general/identity: winners of rows r+3 and r+4 */
-    /* fast: candidates of rows r+1 and r+2 are in flight */
-    Cand cand_a, cand_b;
-    cand_a.ci = cand_b.ci = -1; cand_a.cnt = cand_b.cnt = 0; cand_a.wrap = cand_b.wrap = false;
-    cand_a.prev_slot = cand_b.prev_slot = 0xffffffffu;
-    cand_a.lo = cand_a.hi = cand_b.lo = cand_b.hi = Half{{0, 0, 0, 0}};
-    uint32_t ow_cur = 0u, ow_nxt = 0u, ow_far = 0u;   /* tail winners of rows r+1, r+2, r+3 (0: not overridden) */
-    Half oc_lo{{0, 0, 0, 0}}, oc_hi{{0, 0, 0, 0}}, on_lo{{0, 0, 0, 0}}, on_hi{{0, 0, 0, 0}}; /* their points: r+1, r+2 */
-    if (kFast) {
-        idx[0][tid] = 0u;
-        idx[1][tid] = 0u;
-        __syncthreads(); /* also publishes bnd_lds / tbits */
-        const Cand c0 = load_cand(0);
-        cand_a = load_cand(1);
-        cand_b = load_cand(2);
-        const uint32_t ow0 = issue_tail_winner(0);
-        Half o0_lo{{0, 0, 0, 0}}, o0_hi{{0, 0, 0, 0}};
-        issue_tail_point(ow0, o0_lo, o0_hi);
-        ow_cur = issue_tail_winner(1);
-        issue_tail_point(ow_cur, oc_lo, oc_hi);
-        ow_nxt = issue_tail_winner(2);
-        issue_tail_point(ow_nxt, on_lo, on_hi);
-        ow_far = issue_tail_winner(3);
-        place_cand(0, c0);
-        __syncthreads();
-        fast_point(0, ow0, o0_lo, o0_hi, nxt_lo, nxt_hi);
-    } else {
-        load_point(load_winner(0), nxt_lo, nxt_hi);
-        load_point(load_winner(1), nx2_lo, nx2_hi);
-        w_next = load_winner(2);
-        w_nx2 = load_winner(3);
-    }
+    Half nx2_lo{{0, 0, 0, 0}}, nx2_hi{{0, 0, 0, 0}}; /* point of row r+2 (two rows in flight) */
+    uint32_t w_next = 0u, w_nx2 = 0u;                /* winners of rows r+3 and r+4 */
+    load_point(load_winner(0), nxt_lo, nxt_hi);
+    load_point(load_winner(1), nx2_lo, nx2_hi);
+    w_next = load_winner(2);
+    w_nx2 = load_winner(3);
 
     XYZI prev{0.f, 0.f, 0.f, 0.f}, prevprev{0.f, 0.f, 0.f, 0.f};
     PendingRow p1{}, p2{};              /* rows r-1 (ground flag still open) and r-2 (ready to write) */
@@ -558,31 +257,18 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     for (int r = 0; r < N + 2; ++r) {
         cur_lo = nxt_lo;
         cur_hi = nxt_hi;
-        if (kFast) {
-            place_cand(r + 1, cand_a);    /* scatter row r+1's points into the LDS row buffer (r+1) & 1 */
-            cand_a = cand_b;
-            cand_b = load_cand(r + 3);    /* two rows ahead of its use */
-        } else {
-            /* points of rows r+1 and r+2 and winners of rows r+3 and r+4 are in flight while row r is handled */
-            nxt_lo = nx2_lo;
-            nxt_hi = nx2_hi;
-            load_point(r + 2 < N ? w_next : 0u, nx2_lo, nx2_hi);
-            w_next = w_nx2;
-            w_nx2 = load_winner(r + 4);
-        }
+        /* points of rows r+1 and r+2 and winners of rows r+3 and r+4 are in flight while row r is handled */
+        nxt_lo = nx2_lo;
+        nxt_hi = nx2_hi;
+        load_point(r + 2 < N ? w_next : 0u, nx2_lo, nx2_hi);
+        w_next = w_nx2;
+        w_nx2 = load_winner(r + 4);
 
         const XYZI cur{__uint_as_float(cur_lo.w[0]), __uint_as_float(cur_lo.w[1]), __uint_as_float(cur_lo.w[2]),
                        __uint_as_float(cur_hi.w[0])};
         if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
         if (lane == 0) wave_cnt[r & 1][wv] = (uint32_t)__popcll(m_ready);
         __syncthreads();
-        if (kFast) {
-            fast_point(r + 1, ow_cur, oc_lo, oc_hi, nxt_lo, nxt_hi); /* row r+1 straight from the LDS row buffer */
-            ow_cur = ow_nxt; oc_lo = on_lo; oc_hi = on_hi;           /* shift the override pipeline */
-            ow_nxt = ow_far;
-            issue_tail_point(ow_nxt, on_lo, on_hi);                  /* row r+3's point */
-            ow_far = issue_tail_winner(r + 4);
-        }
 
         /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
         int s_r = kSteep;
@@ -659,7 +345,6 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         prevprev = prev;
         prev = cur;
     }
-    if (kFast && my_fail) atomicOr(&b.fast_fail[f], 1u);
 }
 
 /* getOrderedCloud alone (bev_order_cloud): no ground work. */
@@ -1250,43 +935,21 @@ hipError_t configure_kernels(const Geometry &g)
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)raster_lds_bytes(g));
 }
-void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, bool only_failed, hipStream_t st)
+void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, hipStream_t st)
 {
     if (max_pts == 0 || nf == 0) return;
     const unsigned per_block = 256u * kScanPerThread;
     dim3 grid((max_pts + per_block - 1u) / per_block, (unsigned)nf);
-    hipLaunchKernelGGL(k_order_scan, grid, dim3(256), 0, st, b.pts, b.frames, b.winner, g.N, g.H, g.S,
-                       only_failed ? b.fast_fail : nullptr);
+    hipLaunchKernelGGL(k_order_scan, grid, dim3(256), 0, st, b.pts, b.frames, b.winner, g.N, g.H, g.S);
 }
-void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, StripMode mode, bool only_failed, hipStream_t st)
+void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st)
 {
     if (nf == 0) return;
     const int grid = nf * g.strips;
-    const int of = only_failed ? 1 : 0;
-    if (mode == STRIP_IDENTITY)
-        hipLaunchKernelGGL(k_strip_ground<STRIP_IDENTITY>, dim3(grid), dim3(kStripThreads), 0, st, b, g, of);
-    else if (mode == STRIP_FAST)
-        hipLaunchKernelGGL(k_strip_ground<STRIP_FAST>, dim3(grid), dim3(kStripThreads), 0, st, b, g, of);
+    if (identity)
+        hipLaunchKernelGGL(k_strip_ground<true>, dim3(grid), dim3(kStripThreads), 0, st, b, g);
     else
-        hipLaunchKernelGGL(k_strip_ground<STRIP_GENERAL>, dim3(grid), dim3(kStripThreads), 0, st, b, g, of);
-}
-void launch_prefix_probe(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
-{
-    if (nf == 0) return;
-    hipLaunchKernelGGL(k_prefix_len, dim3(nf), dim3(256), 0, st, b, g);
-    hipLaunchKernelGGL(k_prefix_bounds, dim3((g.rs_tiles + 1 + 255) / 256, nf), dim3(256), 0, st, b, g);
-}
-void launch_tail_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, hipStream_t st)
-{
-    if (nf == 0 || max_pts == 0) return;
-    dim3 grid(kTailBlocks, (unsigned)nf);
-    hipLaunchKernelGGL(k_tail<true>, grid, dim3(256), 0, st, b, g);
-    hipLaunchKernelGGL(k_tail<false>, grid, dim3(256), 0, st, b, g);
-}
-void launch_winner_zero_failed(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
-{
-    if (nf == 0) return;
-    hipLaunchKernelGGL(k_winner_zero_failed, dim3(32, nf), dim3(256), 0, st, b, g);
+        hipLaunchKernelGGL(k_strip_ground<false>, dim3(grid), dim3(kStripThreads), 0, st, b, g);
 }
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {
