@@ -64,7 +64,7 @@ typedef struct bev_params {
     int32_t horizon_scan;       /* SensorParams::Horizon_SCAN */
     int32_t ground_upper_scan;  /* SensorParams::GROUND_UPPER_SCAN */
     float height_res;           /* SensorParams::HEIGHT_RES */
-    float interval;             /* 1.0f  (main :738) */
+    float interval;             /* 1.0f  (main :738); others if M = 2 * max_range / interval is a multiple of 16, 16..512 */
     int32_t max_range;          /* 112   (:266,:336) */
     int32_t n_layers;           /* 24    (:268,:271) */
     float lidar_to_ground;      /* 2.0f  (:269,:338) */

@@ -146,7 +146,7 @@ int validate_params(const bev_params_t *p)
     if ((size_t)(p->ground_upper_scan + 1) * (size_t)((p->horizon_scan + kStripCols - 1) / kStripCols) > (size_t)kMaxSegs)
         return BEV_ERR_UNSUPPORTED;
     const int M = mat_size_of(p);
-    if (M < 16 || M > 512 || (M % 16) != 0) return BEV_ERR_UNSUPPORTED;
+    if (M < 16 || M > 512 || (M % 16) != 0 || raster_bands_for(M) == 0) return BEV_ERR_UNSUPPORTED;
     if (p->n_layers < 1 || p->n_layers > 30) return BEV_ERR_UNSUPPORTED;
     return BEV_OK;
 }
@@ -160,6 +160,7 @@ void fill_geometry(const bev_params_t *p, Geometry *g)
     g->tiles = (g->S + kTile - 1) / kTile;
     g->strips = (g->H + kStripCols - 1) / kStripCols;
     g->segs = (g->G + 1) * g->strips;
+    g->raster_bands = raster_bands_for(mat_size_of(p));
     g->rp.max_range_f = (float)p->max_range;
     g->rp.interval = p->interval;
     g->rp.height_res = p->height_res;

@@ -25,7 +25,7 @@ constexpr int kMaxSegs = 1024;                  /* (G + 1) * strips must not exc
 constexpr int kSumWaves = 8;      /* waves of the per-frame cell-sum workgroup */
 constexpr int kSumThreads = kSumWaves * 64;
 constexpr int kRasterThreads = 1024;
-constexpr int kRasterSplit = 4;   /* x-bands per frame in the raster kernel */
+constexpr int kRasterSplit = 4;   /* x-bands per frame in the raster kernel at the reference's 224 x 224 (see raster_bands_for) */
 
 /* per-frame launch metadata, copied H2D once per sub-batch */
 struct FrameDesc {
@@ -50,6 +50,7 @@ struct Geometry {
     int tiles;         /* ceil(S / kTile): slot tiles of the per-slot kernels */
     int strips;        /* ceil(H / kStripCols): column strips of the walk kernel */
     int segs;          /* (G + 1) * strips: candidate segments per frame, row-major */
+    int raster_bands;  /* x-bands per frame in the raster kernel: a band's two LDS planes must fit one CU */
     bevx::RasterParams rp;
 };
 
@@ -86,6 +87,8 @@ enum KernelId {
     K_COUNT
 };
 const char *kernel_name(int id);
+/* smallest of 4, 8, 16 bands whose LDS planes (2 * (M / bands) * M * 4 B) fit; 0 if none does */
+int raster_bands_for(int mat_size);
 
 /* launchers (bev_kernels.hip) — all asynchronous on `st` */
 void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, hipStream_t st);

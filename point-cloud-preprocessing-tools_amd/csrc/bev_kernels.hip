@@ -688,25 +688,32 @@ __global__ __launch_bounds__(256) void k_cloud_codes(const bev_point_t *__restri
  * 24-bit layer masks and max heights live in LDS (2 * 56 * 224 * 4 B = 98 KiB);
  * codes are streamed with coalesced 4 B loads; the planes leave with 16 B
  * stores, 1 KiB contiguous per wave-instruction.                             */
+int raster_bands_for(int M)
+{
+    for (int bands = kRasterSplit; bands <= 16; bands *= 2)
+        if (M % bands == 0 && (size_t)2 * (M / bands) * M * sizeof(uint32_t) <= (size_t)150 * 1024) return bands;
+    return 0;
+}
 size_t raster_lds_bytes(const Geometry &g)
 {
     const int M = g.rp.mat_size;
-    return (size_t)2 * (M / kRasterSplit) * M * sizeof(uint32_t);
+    return (size_t)2 * (M / g.raster_bands) * M * sizeof(uint32_t);
 }
 
 __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(const uint32_t *__restrict__ codes, size_t code_stride,
                                                               uint32_t n_codes, uint8_t *__restrict__ multi,
-                                                              uint8_t *__restrict__ single, int M, int L, int nf)
+                                                              uint8_t *__restrict__ single, int M, int L, int nf,
+                                                              int bands)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int band_rows = M / kRasterSplit;
+    const int band_rows = M / bands;
     const int cells = band_rows * M;
     uint32_t *mask = lds;
     uint32_t *hmax = lds + cells;
-    /* the kRasterSplit bands of a frame read the same codes: give them to ONE XCD (blocks b and
+    /* the bands of a frame read the same codes: give them to ONE XCD (blocks b and
      * b+8 share an L2) and adjacent launch slots, so three of the four reads are L2 hits */
     const int xl = blockIdx.x & 7, jj = blockIdx.x >> 3;
-    const int f = (jj / kRasterSplit) * 8 + xl, band = jj % kRasterSplit;
+    const int f = (jj / bands) * 8 + xl, band = jj % bands;
     if (f >= nf) return;
     const int x0 = band * band_rows;
     const int tid = threadIdx.x;
@@ -971,9 +978,9 @@ void launch_bev_raster(const Geometry &g, const uint32_t *codes, size_t code_str
                        hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_bev_raster, dim3(8 * ((nf + 7) / 8) * kRasterSplit), dim3(kRasterThreads), raster_lds_bytes(g),
+    hipLaunchKernelGGL(k_bev_raster, dim3(8 * ((nf + 7) / 8) * g.raster_bands), dim3(kRasterThreads), raster_lds_bytes(g),
                        st, codes, code_stride, n_codes, want_multi ? multi : nullptr, want_single ? single : nullptr,
-                       g.rp.mat_size, g.rp.n_layers, nf);
+                       g.rp.mat_size, g.rp.n_layers, nf, g.raster_bands);
 }
 void launch_ground_mat(const Geometry &g, const BatchPtrs &b, int8_t *out, int nf, hipStream_t st)
 {

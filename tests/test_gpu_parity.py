@@ -237,3 +237,28 @@ def test_kitti_projection_matches_oracle(ctxs):
     o_ord, o_gm, o_multi, o_single = orc.process_frame(sp, cloud)
     assert ordered[0].tobytes() == o_ord.tobytes() and np.array_equal(gm[0], o_gm)
     assert np.array_equal(multi[0], o_multi) and np.array_equal(single[0], o_single)
+
+
+@pytest.mark.parametrize("interval", [0.5, 2.0])
+def test_other_grid_intervals(interval):
+    """computeAndSave{Multi,Single}Bev take `interval` (default 1.0f, BatchMultiBevGen.cpp:261 / :331): 448 x 448 and
+    112 x 112 rasters.  The raster kernel splits a frame into more x-bands when a band's LDS planes would not fit."""
+    p = bev_amd.params_for_sensor("HDL_64E")
+    p.interval = interval
+    ctx = bev_amd.BevContext(p, device=0, max_batch=4, max_points=200000)
+    try:
+        sp = orc.sensor_from_params(p)
+        frames = [synth.sweep(p, 3), synth.adversarial(p, 60000, 2, True), synth.firing_order(p, 1)]
+        ordered, multi, single, gm = ctx.process_batch(frames, want_ground_mat=True)
+        M = int(224 / interval)
+        assert multi.shape[1:] == (24, M, M) and single.shape[1:] == (M, M)
+        for i, pts in enumerate(frames):
+            o_ord, o_gm, _, _ = orc.process_frame(sp, pts)
+            assert ordered[i].tobytes() == o_ord.tobytes() and np.array_equal(gm[i], o_gm)
+            assert np.array_equal(multi[i], orc.multi_bev(sp, o_ord, interval).reshape(24, M, M)), i
+            assert np.array_equal(single[i], orc.single_bev(o_ord, interval).reshape(M, M)), i
+        # the per-function entry points on an arbitrary cloud
+        assert np.array_equal(ctx.multi_bev(frames[1]).reshape(24, M, M), orc.multi_bev(sp, frames[1], interval).reshape(24, M, M))
+        assert np.array_equal(ctx.single_bev(frames[1]).reshape(M, M), orc.single_bev(frames[1], interval).reshape(M, M))
+    finally:
+        ctx.close()
