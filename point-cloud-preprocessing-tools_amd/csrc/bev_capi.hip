@@ -43,6 +43,7 @@ struct Lane {
     hipEvent_t done = nullptr;
     hipEvent_t front_done = nullptr, back_done = nullptr; /* staged mode: workspace hand-over between the two stages */
     uint32_t *winner = nullptr;
+    uint32_t win_gen = 0; /* generation tag of the last sub-batch that used this set's winner table */
     uint32_t *codes = nullptr;
     uint16_t *cand_cell = nullptr;
     float *cand_z = nullptr;
@@ -61,6 +62,7 @@ struct bev_ctx {
     Geometry geo{};
     int max_batch = 0;
     size_t max_points = 0;
+    int win_shift = 32;  /* bits an input index + 1 needs; the rest of a winner entry is the generation tag */
     size_t multi_bytes = 0, single_bytes = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;
@@ -293,6 +295,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.pts = identity ? d_pts + (size_t)f0 * S : d_pts;
         b.frames = identity ? nullptr : c->d_desc[ds] + f0;
         b.winner = ln.winner;
+        b.win_shift = c->win_shift;
         b.ordered = d_ordered + (size_t)f0 * S;
         b.codes = ln.codes;
         b.cand_cell = ln.cand_cell;
@@ -311,7 +314,14 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         } else {
             uint32_t max_pts = 0;
             for (int f = 0; f < nb; ++f) max_pts = std::max(max_pts, c->h_desc[ds][f0 + f].n_pts);
-            HIPCK(c, hipMemsetAsync(ln.winner, 0, (size_t)nb * S * sizeof(uint32_t), st));
+            /* winner entries carry the set's generation: no memset between sub-batches (see winner_index) */
+            const uint32_t max_gen = c->win_shift <= 28 ? (1u << (32 - c->win_shift)) - 1u : 0u;
+            if (ln.win_gen + 1u > max_gen) {
+                HIPCK(c, hipMemsetAsync(ln.winner, 0, (size_t)c->max_batch * S * sizeof(uint32_t), st));
+                ln.win_gen = 0;
+            }
+            if (max_gen) ++ln.win_gen;
+            b.win_tag = ln.win_gen;
             {
                 ProfScope ps(c, K_ORDER_SCAN, nb, st);
                 launch_order_scan(g, b, nb, max_pts, st);
@@ -463,6 +473,8 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
     fill_geometry(p, &c->geo);
     c->max_batch = max_batch;
     c->max_points = max_points;
+    c->win_shift = 1;
+    while (c->win_shift < 32 && (max_points >> c->win_shift) != 0) ++c->win_shift; /* index + 1 <= max_points */
     c->multi_bytes = bev_multi_bytes(p);
     c->single_bytes = bev_single_bytes(p);
 
@@ -514,6 +526,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipEventCreateWithFlags(&ln.front_done, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ln.back_done, hipEventDisableTiming));
         CK(hipMalloc((void **)&ln.winner, nb * S * sizeof(uint32_t)));
+        CK(hipMemset(ln.winner, 0, nb * S * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.codes, c->codes_elems * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.cand_cell, nb * (size_t)c->geo.segs * kSeg * sizeof(uint16_t)));
         CK(hipMalloc((void **)&ln.cand_z, nb * (size_t)c->geo.segs * kSeg * sizeof(float)));
@@ -770,6 +783,7 @@ int bev_order_cloud(bev_ctx_t *c, const bev_point_t *pts, uint32_t n_pts, bev_po
     b.pts = c->st_in;
     b.frames = c->d_desc[ds];
     b.winner = c->winner;
+    b.win_shift = c->win_shift; /* tag 0 on a cleared table */
     b.ordered = c->st_ordered;
     HIPCK(c, hipMemsetAsync(c->winner, 0, S * sizeof(uint32_t), c->stream));
     {

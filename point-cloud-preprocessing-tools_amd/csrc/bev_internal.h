@@ -58,7 +58,9 @@ struct Geometry {
 struct BatchPtrs {
     const bev_point_t *pts;      /* packed input points (or ordered cloud in identity mode) */
     const FrameDesc *frames;
-    uint32_t *winner;            /* [nf][S]  index+1 of the last input point per slot */
+    uint32_t *winner;            /* [nf][S]  (win_tag << win_shift) | index+1 of the last input point per slot */
+    uint32_t win_tag;            /* generation of this sub-batch in its workspace set (0: table was cleared) */
+    int win_shift;               /* bits of index+1 */
     bev_point_t *ordered;        /* [nf][S] */
     uint32_t *codes;             /* [nf][S] */
     uint16_t *cand_cell;         /* [nf][segs][kSeg] */

@@ -5,7 +5,7 @@
  *
  * Pipeline for one sub-batch of frames (all launches on one stream):
  *
- *   memset winner
+ *   (winner table: generation-tagged, cleared only when the tag wraps)
  *   order_scan      per input point : winner[slot] = max(index+1)          (getOrderedCloud, last writer wins)
  *   gather_ground   per slot        : ordered cloud, phase-A ground flag,
  *                                     BEV code, candidate list               (getOrderedCloud + markGroundPoints phase A)
@@ -50,6 +50,14 @@ __device__ __forceinline__ bool map_block_xcd(int b, int nf, int tiles, int &f, 
 }
 static inline int xcd_grid(int nf, int tiles) { return 8 * ((nf + 7) / 8) * tiles; }
 
+/* A winner entry is (tag << shift) | (input index + 1).  The tag is the sub-batch generation of the workspace set:
+ * entries left by earlier sub-batches carry a smaller tag, lose every atomicMax against the current one and read as
+ * "empty", so the table needs no memset between sub-batches (bev_capi.hip clears it when the tag would wrap). */
+__device__ __forceinline__ uint32_t winner_index(uint32_t w, uint32_t tag, int shift)
+{
+    return (w != 0u && (w >> shift) == tag) ? (w & ((1u << shift) - 1u)) : 0u;
+}
+
 /* ------------------------------------------------------------------------- */
 /* getOrderedCloud, BatchMultiBevGen.cpp:102-116: bounds test + slot index;
  * "last point in input order wins" == max input index per slot.            */
@@ -58,7 +66,8 @@ constexpr int kScanIdxBits = 10; /* 256 * kScanPerThread = 1024 points per block
 constexpr int kScanRowBins = 128; /* rows the LDS regrouping below can bin (more rows: plain path) */
 __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restrict__ pts,
                                                     const FrameDesc *__restrict__ frames,
-                                                    uint32_t *__restrict__ winner, int N, int H, int S)
+                                                    uint32_t *__restrict__ winner, int N, int H, int S,
+                                                    uint32_t tag_bits)
 {
     const int f = blockIdx.y;
     const FrameDesc fd = frames[f];
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
         /* coalesced already (or too many rows to bin): one atomicMax per point, in input order */
 #pragma unroll
         for (int k = 0; k < kScanPerThread; ++k)
-            if (slot[k] != 0xffffffffu) atomicMax(&fw[slot[k]], base + 256u * k + 1u);
+            if (slot[k] != 0xffffffffu) atomicMax(&fw[slot[k]], tag_bits | (base + 256u * k + 1u));
         return;
     }
     /* Scattering input: regroup the block's (slot, index) pairs by row in LDS (atomicMax is order-free,
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
     for (int k = 0; k < kScanPerThread; ++k) {
         const uint32_t j = threadIdx.x + 256u * k;
         const uint32_t pr = pairs[j];
-        if (pr != 0xffffffffu) atomicMax(&fw[pr >> kScanIdxBits], blockIdx.x * (256u * kScanPerThread) + (pr & ((1u << kScanIdxBits) - 1u)) + 1u);
+        if (pr != 0xffffffffu) atomicMax(&fw[pr >> kScanIdxBits], tag_bits | (blockIdx.x * (256u * kScanPerThread) + (pr & ((1u << kScanIdxBits) - 1u)) + 1u));
     }
 }
 
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         const int fl = r * H + vcol;
         if (fl < 0) return 0u;
         if (kIdentity) return (uint32_t)fl + 1u;
-        return fwin[fl];
+        return winner_index(fwin[fl], b.win_tag, b.win_shift);
     };
 
     auto load_point = [&](uint32_t w, Half &lo, Half &hi) {
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_only(BatchPtrs b, Geo
         const int slot = tile * kTile + k * kGatherThreads + threadIdx.x;
         if (slot >= g.S) continue;
         Half lo = {{0, 0, 0, 0}}, hi = {{0, 0, 0, 0}};
-        const uint32_t w = b.winner[fbase + slot];
+        const uint32_t w = winner_index(b.winner[fbase + slot], b.win_tag, b.win_shift);
         if (w) {
             lo = *reinterpret_cast<const Half *>(fpts + (w - 1));
             hi = *(reinterpret_cast<const Half *>(fpts + (w - 1)) + 1);
@@ -947,7 +956,8 @@ void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t m
     if (max_pts == 0 || nf == 0) return;
     const unsigned per_block = 256u * kScanPerThread;
     dim3 grid((max_pts + per_block - 1u) / per_block, (unsigned)nf);
-    hipLaunchKernelGGL(k_order_scan, grid, dim3(256), 0, st, b.pts, b.frames, b.winner, g.N, g.H, g.S);
+    hipLaunchKernelGGL(k_order_scan, grid, dim3(256), 0, st, b.pts, b.frames, b.winner, g.N, g.H, g.S,
+                       b.win_tag << b.win_shift);
 }
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st)
 {

@@ -70,3 +70,25 @@ def test_sub_batching_and_lanes_do_not_change_results():
     labels = ref[0].view(bev_amd.POINT_DTYPE).reshape(N_FRAMES, S)["label"]
     assert ((labels == 0).sum(axis=1) > 20000).all()
     assert (ref[1].reshape(N_FRAMES, -1).astype(np.int64).sum(axis=1) > 0).all()
+
+
+def test_winner_generation_wraps():
+    """The winner table is generation-tagged instead of cleared per sub-batch; with max_points = 2^27 only 4 tag bits
+    remain, so the tag wraps (and the table is cleared) every 15 sub-batches.  Different frames follow each other in
+    the same workspace slot, so a stale entry surviving a generation would show."""
+    import oracle_lib as orc
+    p = bev_amd.params_for_sensor("HDL_32E")
+    ctx = bev_amd.BevContext(p, device=0, max_batch=2, max_points=(1 << 27) - 1)
+    try:
+        sp = orc.sensor_from_params(p)
+        frames = [synth.sweep(p, 1), synth.adversarial(p, 30000, 4, False), synth.firing_order(p, 2),
+                  synth.sweep(p, 5, keep=0.5)]
+        want = [orc.process_frame(sp, f) for f in frames]
+        for it in range(40):
+            k = (it * 7 + it // 3) % len(frames)
+            ordered, multi, single, gm = ctx.process_batch([frames[k]], want_ground_mat=True)
+            o_ord, o_gm, o_multi, o_single = want[k]
+            assert ordered[0].tobytes() == o_ord.tobytes(), it
+            assert np.array_equal(gm[0], o_gm) and np.array_equal(multi[0], o_multi) and np.array_equal(single[0], o_single), it
+    finally:
+        ctx.close()
