@@ -51,7 +51,10 @@ for k in sorted(agg):
         e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
         e["hbm_bytes_per_frame"] = e["hbm_bytes_per_launch"] / frames
         e["FETCH_SIZE_KiB_raw"], e["WRITE_SIZE_KiB"] = m["FETCH_SIZE"], m["WRITE_SIZE"]
-        total += e["hbm_bytes_per_frame"]
+        if "fillBuffer" in k:
+            e["note"] = "one-time clear of a winner table at context creation, not part of a step"
+        else:
+            total += e["hbm_bytes_per_frame"]
     if "TCC_EA0_RDREQ_sum" in m:
         e["TCC_EA0_RDREQ"], e["TCC_EA0_WRREQ"] = m["TCC_EA0_RDREQ_sum"], m.get("TCC_EA0_WRREQ_sum")
     if "TCC_HIT_sum" in m and m["TCC_HIT_sum"] + m.get("TCC_MISS_sum", 0) > 0:
