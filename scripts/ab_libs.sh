@@ -1,4 +1,9 @@
-# same-box A/B of two builds of the library: csrc/libbev_head.so (copy of an older build) vs csrc/libbev_mi355x.so
-for rep in 1 2 3; do for lib in libbev_head.so libbev_mi355x.so; do
-BEV_AMD_LIB=$PWD/point-cloud-preprocessing-tools_amd/csrc/$lib timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu --no-profile 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$lib', round(d['value']))"
+# same-box A/B of several builds of the library through BEV_AMD_LIB: bash scripts/ab_libs.sh head mi355x a3 ...
+# (csrc/libbev_<name>.so; "head" = a copy of an older build)
+LIBS=${@:-head mi355x}
+for rep in 1 2 3; do for lib in $LIBS; do
+BEV_AMD_LIB=$PWD/point-cloud-preprocessing-tools_amd/csrc/libbev_$lib.so timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu 2>/dev/null | tail -1 > /tmp/b.json; python - <<PY
+import json
+d=json.loads(open("/tmp/b.json").read()); print("$lib", round(d["value"]), [(k["name"][2:8], round(k["avg_launch_ms"]*1e3/250,2)) for k in d["kernels"]])
+PY
 done; done
