@@ -176,6 +176,16 @@ int bev_float_bev(bev_ctx_t *ctx, const bev_point_t *cloud, uint32_t n, float in
                   int skip_label0, float *out);
 size_t bev_float_bev_size(float interval); /* M for a given interval (0 if unsupported) */
 
+/* The rigid transform of cloud_manip (CloudManip.cpp:119-128, pcl::transformPointCloud with an Eigen::Affine3f):
+ * out[i] = cloud[i] with xyz replaced by  col0 * x + (col1 * y + (col2 * z + col3))  of the 3 x 4 row-major
+ * matrix m (12 floats) — the association of pcl::detail::Transformer<float>::se3 (PCL >= 1.10); every other field
+ * is copied.  bev_yaw_translate_matrix builds the matrix the tool builds from its arguments
+ * (translation tx ty tz, then rotate(AngleAxisf(yaw_deg / 180.0f * M_PI, UnitZ()))); host only, no device needed.
+ * Eigen / PCL are third-party: restated from their published sources (parity unpinned). */
+int bev_transform_cloud(bev_ctx_t *ctx, const bev_point_t *cloud, uint32_t n, const float *m /* 12 */,
+                        bev_point_t *out);
+void bev_yaw_translate_matrix(float tx, float ty, float tz, float yaw_deg, float *m /* 12 */);
+
 /* Range-image projection of raw XYZI returns — the selectors' row / col assignment ("polar binning"):
  *   BEV_PROJECT_MULRAN_OS1_64   extractPointCloud, MulranPointCloudSelect.cpp:112-130:
  *                               xyzi = n * (x, y, z, intensity); row = k % 64, col from the azimuth (0..1024)

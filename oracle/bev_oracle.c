@@ -267,6 +267,44 @@ void oracle_float_bev(const oracle_point_t *cloud, size_t n, float interval,
     }
 }
 
+/* CloudManip.cpp:119-128 (see bev_oracle.h) */
+void oracle_yaw_translate_matrix(float tx, float ty, float tz, float yaw_deg, float m[12])
+{
+    const float theta = (float)((double)(yaw_deg / 180.0f) * M_PI); /* :124: float / float, then double * M_PI, stored to float */
+    const float s = sinf(theta), c = cosf(theta);                   /* Eigen: sin / cos of a float angle */
+    const float one_minus_c = 1.0f - c;
+    const float ax = 0.0f, ay = 0.0f, az = 1.0f;                    /* Vector3f::UnitZ() */
+    const float sx = s * ax, sy = s * ay, sz = s * az;              /* sin_axis */
+    const float cx = one_minus_c * ax, cy = one_minus_c * ay, cz = one_minus_c * az; /* cos1_axis */
+    float tmp;
+    float r[9];
+    tmp = cx * ay; r[1] = tmp - sz; r[3] = tmp + sz;
+    tmp = cx * az; r[2] = tmp + sy; r[6] = tmp - sy;
+    tmp = cy * az; r[5] = tmp - sx; r[7] = tmp + sx;
+    r[0] = cx * ax + c; r[4] = cy * ay + c; r[8] = cz * az + c;
+    /* T.rotate(R): linear = Identity * R (products with exact 0 / 1: the sums below are what a 3 x 3 product evaluates) */
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float acc = (i == 0 ? 1.0f : 0.0f) * r[j];
+            acc = acc + (i == 1 ? 1.0f : 0.0f) * r[3 + j];
+            acc = acc + (i == 2 ? 1.0f : 0.0f) * r[6 + j];
+            m[4 * i + j] = acc;
+        }
+    m[3] = tx; m[7] = ty; m[11] = tz;
+}
+
+void oracle_transform_cloud(const oracle_point_t *cloud, size_t n, const float m[12], oracle_point_t *out)
+{
+    for (size_t i = 0; i < n; ++i) {
+        oracle_point_t p = cloud[i];
+        const float x = p.x, y = p.y, z = p.z;
+        p.x = m[0] * x + (m[1] * y + (m[2] * z + m[3]));
+        p.y = m[4] * x + (m[5] * y + (m[6] * z + m[7]));
+        p.z = m[8] * x + (m[9] * y + (m[10] * z + m[11]));
+        out[i] = p;
+    }
+}
+
 /* x86-64 static_cast<uint16_t>(float): cvttss2si, low 16 bits */
 static uint16_t cvtt_f32_to_u16(float v) { return (uint16_t)(uint32_t)cvtt_f32_to_i32(v); }
 

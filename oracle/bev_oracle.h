@@ -98,6 +98,17 @@ void oracle_process_frame(const oracle_sensor_t *sp, const oracle_point_t *in,
 void oracle_float_bev(const oracle_point_t *cloud, size_t n, float interval,
                       int skip_label0, float *out);
 
+/* The rigid transform cloud_manip applies before its second saveAsMat (CloudManip.cpp:119-128):
+ *   Eigen::Affine3f T = Identity; T.translation() << tx, ty, tz;
+ *   theta = stof(argv[5]) / 180.0f * M_PI;  T.rotate(AngleAxisf(theta, UnitZ()));  pcl::transformPointCloud(in, out, T)
+ * oracle_yaw_translate_matrix: the 3 x 4 row-major [R | t] that code builds (Eigen 3.3 AngleAxis::toRotationMatrix:
+ * the diagonal is (1 - c) * axis^2 + c, so m22 = (1 - c) + c, not a literal 1).
+ * oracle_transform_cloud: pcl::detail::Transformer<float>::se3 (PCL >= 1.10, SSE build):
+ *   out.xyz = m.col0 * x + (m.col1 * y + (m.col2 * z + m.col3)),  every other field copied.
+ * Eigen and PCL are not under /root/reference: both are restated from their published sources (PARITY UNPINNED). */
+void oracle_yaw_translate_matrix(float tx, float ty, float tz, float yaw_deg, float m[12]);
+void oracle_transform_cloud(const oracle_point_t *cloud, size_t n, const float m[12], oracle_point_t *out);
+
 /* Range-image projection of the keyframe selectors ("next" row N3).  The reference declares the point
  * without initialising it, so t and the padding are indeterminate there; the oracle writes 0.
  * MulRan (MulranPointCloudSelect.cpp:112-130): xyzi = n * (x, y, z, intensity) interleaved.

@@ -73,7 +73,7 @@ ABI_SYMBOLS = [
     "bev_create", "bev_destroy", "bev_strerror", "bev_last_error",
     "bev_process_batch", "bev_process_device_resident", "bev_synchronize",
     "bev_order_cloud", "bev_mark_ground", "bev_multi_bev", "bev_single_bev",
-    "bev_float_bev", "bev_float_bev_size", "bev_project_xyzi", "bev_project_out_points", "bev_host_alloc", "bev_host_free",
+    "bev_float_bev", "bev_float_bev_size", "bev_transform_cloud", "bev_yaw_translate_matrix", "bev_project_xyzi", "bev_project_out_points", "bev_host_alloc", "bev_host_free",
     "bev_set_lanes", "bev_profile_enable", "bev_profile_reset", "bev_profile_get",
     "bev_debug_get_cell_avg", "bev_debug_angle_predicate", "bev_abi_version",
 ]
@@ -127,6 +127,9 @@ def load_lib() -> C.CDLL:
     lib.bev_float_bev_size.argtypes = [C.c_float]
     lib.bev_float_bev_size.restype = sz
     lib.bev_project_xyzi.argtypes = [vp, i32, vp, u32, vp]
+    lib.bev_transform_cloud.argtypes = [vp, vp, u32, vp, vp]
+    lib.bev_yaw_translate_matrix.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, vp]
+    lib.bev_yaw_translate_matrix.restype = None
     lib.bev_host_alloc.argtypes = [C.POINTER(vp), sz]
     lib.bev_host_free.argtypes = [vp]
     lib.bev_project_out_points.argtypes = [i32, u32]
@@ -255,6 +258,14 @@ class BevContext:
                                            1 if skip_label0 else 0, _ptr(out)), "bev_float_bev")
         return out
 
+    def transform_cloud(self, cloud, m):
+        cloud = np.ascontiguousarray(cloud, dtype=POINT_DTYPE)
+        m = np.ascontiguousarray(m, dtype=np.float32).reshape(12)
+        out = np.empty_like(cloud)
+        self._check(self.lib.bev_transform_cloud(self._h, _ptr(cloud) if len(cloud) else None, len(cloud), _ptr(m),
+                                                 _ptr(out) if len(cloud) else None), "bev_transform_cloud")
+        return out
+
     def project_xyzi(self, kind: int, xyzi):
         """kind 0: MulRan/Ouster (n, 4) interleaved; kind 1: Oxford (4, n) planes; kind 2: KITTI (n, 4)
         interleaved, returns the structured 64 * 2083 cloud."""
@@ -304,6 +315,13 @@ class BevContext:
         self._check(self.lib.bev_debug_angle_predicate(self._h, _ptr(dx), _ptr(dy), _ptr(dz), _ptr(out), dx.shape[0]),
                     "bev_debug_angle_predicate")
         return out
+
+
+def yaw_translate_matrix(tx: float, ty: float, tz: float, yaw_deg: float) -> np.ndarray:
+    """[R | t] of cloud_manip (CloudManip.cpp:119-128) as 12 floats, row-major; host arithmetic only."""
+    m = np.empty(12, dtype=np.float32)
+    load_lib().bev_yaw_translate_matrix(tx, ty, tz, yaw_deg, _ptr(m))
+    return m
 
 
 def host_alloc(shape, dtype) -> np.ndarray:

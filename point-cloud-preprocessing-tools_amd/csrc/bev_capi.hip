@@ -965,6 +965,40 @@ int bev_float_bev(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, float inte
     return BEV_OK;
 }
 
+int bev_transform_cloud(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, const float *m, bev_point_t *out)
+{
+    if (!c || !m || (n && (!cloud || !out))) return BEV_ERR_INVALID_ARG;
+    if ((size_t)n > std::max(c->max_points, (size_t)c->geo.S)) return BEV_ERR_TOO_LARGE;
+    if (n == 0) return BEV_OK;
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c);
+    if (rc != BEV_OK) return rc;
+    /* in place in the input staging (every thread reads and writes its own point) */
+    HIPCK(c, hipMemcpyAsync(c->st_in, cloud, (size_t)n * sizeof(bev_point_t), hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, K_TRANSFORM, 1);
+        launch_transform(c->st_in, n, m, c->st_in, c->stream);
+    }
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(out, c->st_in, (size_t)n * sizeof(bev_point_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BEV_OK;
+}
+
+void bev_yaw_translate_matrix(float tx, float ty, float tz, float yaw_deg, float *m)
+{
+    if (!m) return;
+    /* CloudManip.cpp:119-128: Affine3f = Identity; translation() << t; rotate(AngleAxisf(theta, UnitZ())) with
+     * theta = yaw_deg / 180.0f * M_PI stored to float; Eigen's AngleAxis::toRotationMatrix for the axis (0, 0, 1) gives
+     * [[c, -s, 0], [s, c, 0], [0, 0, (1 - c) + c]] (every other term of its formulas is an exact 0) */
+    const float theta = (float)((double)(yaw_deg / 180.0f) * 3.14159265358979323846);
+    const float s = sinf(theta), c = cosf(theta);
+    const float one_minus_c = 1.0f - c;
+    m[0] = c;    m[1] = 0.0f - s; m[2] = 0.0f;  m[3] = tx;
+    m[4] = s;    m[5] = c;        m[6] = 0.0f;  m[7] = ty;
+    m[8] = 0.0f; m[9] = 0.0f;     m[10] = one_minus_c + c; m[11] = tz;
+}
+
 int bev_set_lanes(bev_ctx_t *c, int n)
 {
     if (!c || n < 1) return BEV_ERR_INVALID_ARG;

@@ -86,6 +86,7 @@ enum KernelId {
     K_ANGLE_DEBUG,
     K_FLOAT_BEV,
     K_PROJECT,
+    K_TRANSFORM,
     K_COUNT
 };
 const char *kernel_name(int id);
@@ -107,6 +108,7 @@ void launch_cloud_codes(const Geometry &g, const bev_point_t *cloud, uint32_t n,
 void launch_float_bev(const bev_point_t *cloud, uint32_t n, float interval, int M, bool skip_label0, float *grid,
                       hipStream_t st);
 void launch_project(int kind, const float *xyzi, uint32_t n, bev_point_t *out, hipStream_t st);
+void launch_transform(const bev_point_t *cloud, uint32_t n, const float m[12], bev_point_t *out, hipStream_t st);
 /* KITTI projection workspace (device): header with the chain of accepted crossings, per-point column,
  * per-block crossing lists, winner table of the 64 x 2083 structured cloud */
 struct KittiHeader {

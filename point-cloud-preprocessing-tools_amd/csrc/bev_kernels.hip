@@ -31,7 +31,7 @@ namespace bevk {
 
 static const char *const kNames[K_COUNT] = {
     "k_order_scan", "k_strip_ground", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
-    "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project",
+    "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project", "k_transform",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
 
@@ -832,6 +832,24 @@ __global__ __launch_bounds__(256) void k_float_bev(const bev_point_t *__restrict
     if (h > 0.0f) atomicMax(&grid[(size_t)x * M + y], __float_as_uint(h)); /* "h > cell" with cells >= 0 */
 }
 
+/* pcl::transformPointCloud with the [R | t] of cloud_manip (CloudManip.cpp:119-128): out.xyz = col0 * x + (col1 * y +
+ * (col2 * z + col3)) — the association of pcl::detail::Transformer<float>::se3 — every other field copied.  The matrix
+ * is built on the host (sinf / cosf of the host libm), so no transcendental is evaluated here. */
+struct Affine34 { float m[12]; };
+__global__ __launch_bounds__(256) void k_transform(const bev_point_t *cloud, uint32_t n, Affine34 a, bev_point_t *out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    Half lo = reinterpret_cast<const Half *>(cloud + i)[0];
+    const Half hi = reinterpret_cast<const Half *>(cloud + i)[1];
+    const float x = __uint_as_float(lo.w[0]), y = __uint_as_float(lo.w[1]), z = __uint_as_float(lo.w[2]);
+    lo.w[0] = __float_as_uint(a.m[0] * x + (a.m[1] * y + (a.m[2] * z + a.m[3])));
+    lo.w[1] = __float_as_uint(a.m[4] * x + (a.m[5] * y + (a.m[6] * z + a.m[7])));
+    lo.w[2] = __float_as_uint(a.m[8] * x + (a.m[9] * y + (a.m[10] * z + a.m[11])));
+    reinterpret_cast<Half *>(out + i)[0] = lo;
+    reinterpret_cast<Half *>(out + i)[1] = hi;
+}
+
 /* Range-image projection of raw returns (see bev_libm.h): one thread per point. */
 __global__ __launch_bounds__(256) void k_project(int kind, const float *__restrict__ xyzi, uint32_t n,
                                                  bev_point_t *__restrict__ out)
@@ -1035,6 +1053,13 @@ void launch_float_bev(const bev_point_t *cloud, uint32_t n, float interval, int 
     if (n == 0) return;
     hipLaunchKernelGGL(k_float_bev, dim3((n + 255u) / 256u), dim3(256), 0, st, cloud, n, interval, M,
                        skip_label0 ? 1 : 0, reinterpret_cast<uint32_t *>(grid));
+}
+void launch_transform(const bev_point_t *cloud, uint32_t n, const float m[12], bev_point_t *out, hipStream_t st)
+{
+    if (n == 0) return;
+    Affine34 a;
+    for (int k = 0; k < 12; ++k) a.m[k] = m[k];
+    hipLaunchKernelGGL(k_transform, dim3((n + 255u) / 256u), dim3(256), 0, st, cloud, n, a, out);
 }
 void launch_project(int kind, const float *xyzi, uint32_t n, bev_point_t *out, hipStream_t st)
 {

@@ -84,15 +84,15 @@ cv::Mat CloudManip::saveAsMat(pcl::PointCloud<PointType>::Ptr cloud, std::string
 void CloudManip::transformYawTranslate(const pcl::PointCloud<PointType> &in, pcl::PointCloud<PointType> &out, float tx,
                                        float ty, float tz, float yaw_deg)
 {
-    /* Eigen: Affine3f T = Identity; T.translation() << t; T.rotate(AngleAxisf(theta, UnitZ())) -> p' = R p + t,
-     * float arithmetic; theta = yaw / 180.0f * M_PI evaluated in double, stored to float (:124) */
-    const float theta = (float)((double)(yaw_deg / 180.0f) * M_PI);
-    const float c = std::cos(theta), s = std::sin(theta);
+    /* Eigen: Affine3f T = Identity; T.translation() << t; T.rotate(AngleAxisf(theta, UnitZ())), then
+     * pcl::transformPointCloud(in, out, T) (CloudManip.cpp:119-128): the matrix is built on the host
+     * (bev_yaw_translate_matrix), the points are transformed on the GPU (bev_transform_cloud) */
+    float m[12];
+    bev_yaw_translate_matrix(tx, ty, tz, yaw_deg, m);
     out = in;
-    for (size_t i = 0; i < in.points.size(); ++i) {
-        const PointType &p = in.points[i];
-        out.points[i].x = c * p.x - s * p.y + tx;
-        out.points[i].y = s * p.x + c * p.y + ty;
-        out.points[i].z = p.z + tz;
-    }
+    bev_ctx_t *c = bevhost_context();
+    if (!c) return;
+    const int rc = bev_transform_cloud(c, reinterpret_cast<const bev_point_t *>(in.points.data()), (uint32_t)in.points.size(), m,
+                                       reinterpret_cast<bev_point_t *>(out.points.data()));
+    if (rc != BEV_OK) std::cerr << "transformPointCloud: " << bev_strerror(rc) << "\n";
 }

@@ -41,6 +41,10 @@ def lib():
         l.oracle_process_frame.restype = None
         l.oracle_float_bev.argtypes = [vp, sz, C.c_float, C.c_int, vp]
         l.oracle_float_bev.restype = None
+        l.oracle_yaw_translate_matrix.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, vp]
+        l.oracle_yaw_translate_matrix.restype = None
+        l.oracle_transform_cloud.argtypes = [vp, sz, vp, vp]
+        l.oracle_transform_cloud.restype = None
         l.oracle_project_mulran.argtypes = [vp, sz, vp]
         l.oracle_project_mulran.restype = None
         l.oracle_project_oxford.argtypes = [vp, sz, vp]
@@ -115,6 +119,20 @@ def float_bev(cloud: np.ndarray, interval: float = 1.0, skip_label0: bool = True
     M = int(np.float32(np.float32(200) / np.float32(interval)) + np.float32(1))
     out = np.empty((M, M), dtype=np.float32)
     lib().oracle_float_bev(cloud.ctypes.data, len(cloud), interval, 1 if skip_label0 else 0, out.ctypes.data)
+    return out
+
+
+def yaw_translate_matrix(tx: float, ty: float, tz: float, yaw_deg: float) -> np.ndarray:
+    m = np.empty(12, dtype=np.float32)
+    lib().oracle_yaw_translate_matrix(tx, ty, tz, yaw_deg, m.ctypes.data)
+    return m
+
+
+def transform_cloud(cloud: np.ndarray, m: np.ndarray) -> np.ndarray:
+    cloud = np.ascontiguousarray(cloud, dtype=POINT_DTYPE)
+    m = np.ascontiguousarray(m, dtype=np.float32)
+    out = np.empty_like(cloud)
+    lib().oracle_transform_cloud(cloud.ctypes.data, len(cloud), m.ctypes.data, out.ctypes.data)
     return out
 
 

@@ -193,6 +193,26 @@ def test_float_bev(ctxs, sensor):
     assert ctx.float_bev(marked, 1.0, True).shape == (201, 201)
 
 
+def test_transform_cloud(ctxs):
+    """cloud_manip's rigid transform (CloudManip.cpp:119-128) on the device, bit-identical to the oracle."""
+    p, ctx = ctxs("HDL_64E")
+    cases = [(0, 0, 0, 0), (1.5, -2.25, 0.125, 30), (-3, 4, 1, -45.5), (10, 20, -1, 180), (0.1, 0.2, 0.3, 359.9)]
+    for seed, (tx, ty, tz, yaw) in enumerate(cases):
+        m = bev_amd.yaw_translate_matrix(tx, ty, tz, yaw)
+        assert np.array_equal(m, orc.yaw_translate_matrix(tx, ty, tz, yaw))
+        for cloud in (synth.sweep(p, seed), synth.adversarial(p, 150001, seed, nonfinite=True)):
+            got, want = ctx.transform_cloud(cloud, m), orc.transform_cloud(cloud, m)
+            nan = np.isnan(want["x"]) | np.isnan(want["y"]) | np.isnan(want["z"])
+            assert got[~nan].tobytes() == want[~nan].tobytes(), seed
+            for f in ("x", "y", "z"):  # NaN results: NaN on both sides (payload bits are not specified)
+                assert np.array_equal(np.isnan(got[f]), np.isnan(want[f]))
+            assert got[nan][["intensity", "row", "col", "t", "label"]].tobytes() == want[nan][["intensity", "row", "col", "t", "label"]].tobytes()
+    assert len(ctx.transform_cloud(np.empty(0, bev_amd.POINT_DTYPE), m)) == 0
+    # the transformed cloud feeds the float raster like cloud_manip does (:136-137)
+    out = ctx.transform_cloud(synth.sweep(p, 3), m)
+    assert ctx.float_bev(out, 1.0, False).tobytes() == orc.float_bev(orc.transform_cloud(synth.sweep(p, 3), m), 1.0, False).tobytes()
+
+
 # ---- SURVEY §8(f) N3: range-image projection of raw XYZI returns (atan2f restated on the device) ----
 @pytest.mark.parametrize("kind", [0, 1])
 def test_projection_matches_oracle(ctxs, kind):
