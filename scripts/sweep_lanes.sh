@@ -1,7 +1,4 @@
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-for lanes in 1 2 3; do for sb in 32 64 128 256; do
-BEV_LANES=$lanes timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu --sub-batch $sb 2>/dev/null | tail -1 > /tmp/b.json; python - <<PY
-import json
-d=json.loads(open("/tmp/b.json").read()); print("lanes $lanes sb", d["config"]["sub_batch"], round(d["value"]), [(k["name"][2:8], round(k["avg_launch_ms"]*1e3/ (1000/ (k["launches"]/3)),2)) for k in d["kernels"]])
-PY
-done; done
+# throughput against the number of workspace sets (BEV_LANES) and the sub-batch size, staged pipeline
+for rep in 1 2; do for lanes in 2 3 4; do for sb in 250 256; do
+BEV_LANES=$lanes timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu --no-profile --sub-batch $sb 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('lanes $lanes sb $sb', round(d['value']))"
+done; done; done
