@@ -5,7 +5,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -256,6 +258,36 @@ BatchMultiBevGen::~BatchMultiBevGen()
     if (ctx_) bev_destroy(ctx_);
 }
 
+namespace {
+/* The file work of a batch (PCD parse, PNG deflate, CSV text, PCD write) is independent per frame: a few host threads
+ * (BEV_IO_THREADS, default min(16, cores)) share it; the reference does all of it on one thread. */
+int io_threads()
+{
+    static const int n = [] {
+        const char *e = std::getenv("BEV_IO_THREADS");
+        int v = e ? std::atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        return std::max(1, std::min(256, v));
+    }();
+    return n;
+}
+template <class F>
+void parallel_frames(int n, F fn)
+{
+    const int workers = std::min(io_threads(), n);
+    if (workers <= 1) {
+        for (int i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int w = 0; w < workers; ++w)
+        pool.emplace_back([&] {
+            for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+        });
+    for (auto &t : pool) t.join();
+}
+} // namespace
+
 double BatchMultiBevGen::processFiles(const std::vector<std::string> &files, std::size_t first, std::size_t count,
                                       bool write_png, bool verbose)
 {
@@ -272,10 +304,12 @@ double BatchMultiBevGen::processFiles(const std::vector<std::string> &files, std
         std::vector<bev_point_t *> ord(nb);
         std::vector<uint8_t *> mo(nb), so(nb);
         std::vector<std::string> names(nb);
+        parallel_frames(nb, [&](int i) {
+            in[i].clear();
+            if (bevio::loadPCDFile(files[b0 + i], in[i]) != 0) std::cerr << "Failed to load " << files[b0 + i] << "\n"; /* :730 */
+        });
         for (int i = 0; i < nb; ++i) {
             const std::string &fn = files[b0 + i];
-            in[i].clear();
-            if (bevio::loadPCDFile(fn, in[i]) != 0) std::cerr << "Failed to load " << fn << "\n"; /* :730 */
             ordered[i].resize(S);
             multi[i].resize((size_t)kLayers * kMat * kMat);
             single[i].resize((size_t)kMat * kMat);
@@ -294,14 +328,16 @@ double BatchMultiBevGen::processFiles(const std::vector<std::string> &files, std
             std::cerr << "bev_process_batch failed: " << bev_strerror(rc) << " " << bev_last_error(ctx_) << "\n";
             continue;
         }
-        for (int i = 0; i < nb; ++i) {
-            if (verbose) std::cout << "Converting file: " << names[i] << "\n"; /* :744 */
+        if (verbose)
+            for (int i = 0; i < nb; ++i) std::cout << "Converting file: " << names[i] << "\n"; /* :744 */
+        parallel_frames(nb, [&](int i) {
             write_multi_outputs(names[i], multi[i].data(), write_png);
             write_single_outputs(names[i], single[i].data(), write_png);
-        }
+        });
         timed_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        for (int i = 0; i < nb; ++i) /* :755-756: the labelled (not filtered) ordered cloud */
+        parallel_frames(nb, [&](int i) { /* :755-756: the labelled (not filtered) ordered cloud */
             bevio::savePCDFileBinary(non_ground_dir + names[i] + ".pcd", ordered[i]);
+        });
     }
     return timed_ms;
 }

@@ -8,6 +8,7 @@
  *                   per GPU, contiguous shards of the sorted file list)
  *   BEV_BATCH=B     frames per bev_process_batch call (default 32)
  *   BEV_NO_PNG=1    skip the 25 PNG files per frame
+ *   BEV_IO_THREADS=T host threads sharing the per-frame file work of a batch (PCD parse, PNG, CSV, PCD write; default 16)
  */
 #include <chrono>
 #include <cstdint>
