@@ -92,3 +92,27 @@ def test_winner_generation_wraps():
             assert np.array_equal(gm[0], o_gm) and np.array_equal(multi[0], o_multi) and np.array_equal(single[0], o_single), it
     finally:
         ctx.close()
+
+
+def test_baseline_config_every_frame_matches_oracle():
+    """BASELINE configs[1] as bench.py runs it (1000 HDL_64E frames, sub-batches of 256, the two-stage pipeline, three
+    back-to-back asynchronous steps over the same buffers): EVERY frame of the last step against the oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    p = bev_amd.params_for_sensor("HDL_64E")
+    n = 1000
+    with ThreadPoolExecutor(16) as ex:
+        frames = list(ex.map(lambda f: synth.sweep(p, f, keep=0.98, n_dup=5000), range(n)))
+    ords, multis, singles = _run(p, frames, sub_batch=256, lanes=2, repeats=3)
+    S, M, L = p.slots, p.mat_size, p.n_layers
+    sp = orc.sensor_from_params(p)
+
+    def check(i):  # the oracle is plain C behind ctypes: the threads run it in parallel
+        o_ord, _, o_multi, o_single = orc.process_frame(sp, frames[i], want_gm=False)
+        return (ords[i * S * 32:(i + 1) * S * 32].tobytes() == o_ord.tobytes()
+                and multis[i * L * M * M:(i + 1) * L * M * M].tobytes() == o_multi.tobytes()
+                and singles[i * M * M:(i + 1) * M * M].tobytes() == o_single.tobytes())
+
+    with ThreadPoolExecutor(16) as ex:
+        bad = [i for i, ok in enumerate(ex.map(check, range(n))) if not ok]
+    assert not bad, f"{len(bad)} of {n} frames differ from the oracle, first: {bad[:8]}"
