@@ -1,10 +1,13 @@
 #include <zlib.h>
 #include "FileFormats.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <limits>
+#include <new>
 #include <sstream>
 
 namespace bevio {
@@ -42,16 +45,26 @@ double read_scalar(const unsigned char *p, int size, char type)
     return 0.0;
 }
 
+/* double -> integer field without undefined behaviour: NaN -> 0, out of range saturates (values a well-formed file of
+ * this point type holds are converted exactly) */
+template <class T>
+T to_int(double v)
+{
+    if (!(v == v)) return 0;
+    const double lo = (double)std::numeric_limits<T>::min(), hi = (double)std::numeric_limits<T>::max();
+    return v <= lo ? std::numeric_limits<T>::min() : (v >= hi ? std::numeric_limits<T>::max() : (T)v);
+}
+
 void assign_field(pcl::PointXYZIRCT &pt, const std::string &name, double v)
 {
     if (name == "x") pt.x = (float)v;
     else if (name == "y") pt.y = (float)v;
     else if (name == "z") pt.z = (float)v;
     else if (name == "intensity") pt.intensity = (float)v;
-    else if (name == "row") pt.row = (std::uint16_t)v;
-    else if (name == "col") pt.col = (std::uint16_t)v;
-    else if (name == "t") pt.t = (std::uint32_t)v;
-    else if (name == "label") pt.label = (std::int16_t)v;
+    else if (name == "row") pt.row = to_int<std::uint16_t>(v);
+    else if (name == "col") pt.col = to_int<std::uint16_t>(v);
+    else if (name == "t") pt.t = to_int<std::uint32_t>(v);
+    else if (name == "label") pt.label = to_int<std::int16_t>(v);
 }
 
 /* liblzf decompression (format used by PCL's DATA binary_compressed) */
@@ -63,16 +76,17 @@ bool lzf_decompress(const unsigned char *in, std::size_t in_len, unsigned char *
         unsigned ctrl = *ip++;
         if (ctrl < 32) { /* literal run */
             ++ctrl;
-            if (op + ctrl > out_end || ip + ctrl > in_end) return false;
+            if (ctrl > (std::size_t)(out_end - op) || ctrl > (std::size_t)(in_end - ip)) return false;
             std::memcpy(op, ip, ctrl);
             op += ctrl; ip += ctrl;
         } else { /* back reference */
             unsigned len = ctrl >> 5;
             if (len == 7) { if (ip >= in_end) return false; len += *ip++; }
             if (ip >= in_end) return false;
-            const unsigned char *ref = op - ((ctrl & 0x1f) << 8) - 1 - *ip++;
+            const std::size_t back = ((std::size_t)(ctrl & 0x1f) << 8) + 1 + *ip++;
             len += 2;
-            if (ref < out || op + len > out_end) return false;
+            if (back > (std::size_t)(op - out) || len > (std::size_t)(out_end - op)) return false;
+            const unsigned char *ref = op - back;
             while (len--) *op++ = *ref++;
         }
     }
@@ -81,10 +95,30 @@ bool lzf_decompress(const unsigned char *in, std::size_t in_len, unsigned char *
 
 } // namespace
 
+namespace {
+int load_pcd(const std::string &path, pcl::PointCloud<pcl::PointXYZIRCT> &cloud);
+}
+
 int loadPCDFile(const std::string &path, pcl::PointCloud<pcl::PointXYZIRCT> &cloud)
+{
+    try {
+        const int rc = load_pcd(path, cloud);
+        if (rc != 0) cloud.clear();
+        return rc;
+    } catch (const std::bad_alloc &) { /* a header that promises more points than memory holds */
+        cloud.clear();
+        return -1;
+    }
+}
+
+namespace {
+int load_pcd(const std::string &path, pcl::PointCloud<pcl::PointXYZIRCT> &cloud)
 {
     std::ifstream f(path, std::ios::binary);
     if (!f) return -1;
+    f.seekg(0, std::ios::end);
+    const std::uint64_t file_size = (std::uint64_t)f.tellg();
+    f.seekg(0, std::ios::beg);
     std::vector<Field> fields;
     std::size_t points = 0, width = 0, height = 1;
     bool have_points = false;
@@ -115,10 +149,23 @@ int loadPCDFile(const std::string &path, pcl::PointCloud<pcl::PointXYZIRCT> &clo
             break;
         }
     }
-    if (fields.empty() || data_kind.empty()) return -1;
-    if (!have_points) points = width * height; /* PCL accepts WIDTH 0 HEIGHT 0 with POINTS n */
+    if (fields.empty() || fields.size() > 64 || data_kind.empty() || !f) return -1;
+    if (!have_points) {
+        if (height != 0 && width > std::numeric_limits<std::size_t>::max() / height) return -1;
+        points = width * height; /* PCL accepts WIDTH 0 HEIGHT 0 with POINTS n */
+    }
     int rec = 0;
-    for (auto &fd : fields) { fd.offset = rec; rec += fd.size * fd.count; }
+    for (auto &fd : fields) {
+        if ((fd.size != 1 && fd.size != 2 && fd.size != 4 && fd.size != 8) || fd.count < 1 || fd.count > 4096) return -1;
+        if (fd.type != 'F' && fd.type != 'U' && fd.type != 'I') return -1;
+        fd.offset = rec;
+        rec += fd.size * fd.count;
+    }
+    /* the payload cannot hold more points than the bytes that follow the header (ascii: at least "0\n" per value) */
+    const std::uint64_t body = file_size - std::min<std::uint64_t>(file_size, (std::uint64_t)f.tellg());
+    const std::uint64_t min_bytes_per_point = data_kind == "ascii" ? 2 * fields.size() : (data_kind == "binary" ? (std::uint64_t)rec : 0);
+    if (min_bytes_per_point && points > body / min_bytes_per_point) return -1;
+    if (data_kind == "binary_compressed" && points > ((std::uint64_t)1 << 32) / (std::uint64_t)rec) return -1;
     cloud.points.assign(points, pcl::PointXYZIRCT{});
     cloud.width = (std::uint32_t)(width ? width : points);
     cloud.height = (std::uint32_t)(height ? height : 1);
@@ -149,7 +196,7 @@ int loadPCDFile(const std::string &path, pcl::PointCloud<pcl::PointXYZIRCT> &clo
         std::uint32_t comp = 0, uncomp = 0;
         f.read(reinterpret_cast<char *>(&comp), 4);
         f.read(reinterpret_cast<char *>(&uncomp), 4);
-        if (!f || uncomp != (std::uint64_t)rec * points) return -1;
+        if (!f || uncomp != (std::uint64_t)rec * points || comp > body) return -1;
         std::vector<unsigned char> cbuf(comp), buf(uncomp);
         f.read(reinterpret_cast<char *>(cbuf.data()), comp);
         if ((std::size_t)f.gcount() != comp) return -1;
@@ -166,6 +213,7 @@ int loadPCDFile(const std::string &path, pcl::PointCloud<pcl::PointXYZIRCT> &clo
     }
     return -1;
 }
+} // namespace
 
 int savePCDFileBinary(const std::string &path, const pcl::PointCloud<pcl::PointXYZIRCT> &cloud)
 {
@@ -205,21 +253,9 @@ bool writeFile(const std::string &path, const void *data, std::size_t n)
 
 /* ---- PNG: 8-bit grayscale, filter 0 on every row, one IDAT chunk ---- */
 namespace {
-std::uint32_t crc_table[256];
-bool crc_ready = false;
-std::uint32_t crc32(const unsigned char *p, std::size_t n, std::uint32_t crc = 0)
+std::uint32_t png_crc(const unsigned char *p, std::size_t n) /* zlib's CRC-32 is the PNG chunk CRC; no shared state */
 {
-    if (!crc_ready) {
-        for (std::uint32_t i = 0; i < 256; ++i) {
-            std::uint32_t c = i;
-            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
-            crc_table[i] = c;
-        }
-        crc_ready = true;
-    }
-    crc = ~crc;
-    for (std::size_t i = 0; i < n; ++i) crc = crc_table[(crc ^ p[i]) & 0xff] ^ (crc >> 8);
-    return ~crc;
+    return (std::uint32_t)::crc32(::crc32(0L, Z_NULL, 0), p, (uInt)n);
 }
 void put32(std::vector<unsigned char> &v, std::uint32_t x)
 {
@@ -231,7 +267,7 @@ void chunk(std::vector<unsigned char> &out, const char *tag, const std::vector<u
     std::vector<unsigned char> t(tag, tag + 4);
     t.insert(t.end(), body.begin(), body.end());
     out.insert(out.end(), t.begin(), t.end());
-    put32(out, crc32(t.data(), t.size()));
+    put32(out, png_crc(t.data(), t.size()));
 }
 } // namespace
 

@@ -43,8 +43,39 @@ def lib():
         l.hc_derive_angle_threshold.restype = None
         l.hc_angle_vs_libm.argtypes = [C.c_uint64, C.c_uint64]
         l.hc_angle_vs_libm.restype = C.c_uint64
+        l.hc_pcd_load.argtypes = [C.c_char_p, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        l.hc_pcd_save.argtypes = [C.c_char_p, vp, C.c_size_t]
+        l.hc_png_write.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
+        l.hc_csv_u8.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
+        l.hc_csv_u8.restype = C.c_size_t
         _lib = l
     return _lib
+
+
+def pcd_load(path, cap=1 << 22):
+    """host/FileFormats.cpp loadPCDFile -> (rc, points, width, height)"""
+    out = np.zeros(cap, POINT_DTYPE)
+    n, w, h = C.c_size_t(0), C.c_uint32(0), C.c_uint32(0)
+    rc = lib().hc_pcd_load(str(path).encode(), out.ctypes.data, cap, C.byref(n), C.byref(w), C.byref(h))
+    return rc, out[:min(n.value, cap)].copy(), w.value, h.value
+
+
+def pcd_save(path, pts):
+    pts = np.ascontiguousarray(pts, POINT_DTYPE)
+    return lib().hc_pcd_save(str(path).encode(), pts.ctypes.data, len(pts))
+
+
+def png_write(path, img):
+    img = np.ascontiguousarray(img, np.uint8)
+    return lib().hc_png_write(str(path).encode(), img.ctypes.data, img.shape[0], img.shape[1])
+
+
+def csv_u8(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    n = lib().hc_csv_u8(img.ctypes.data, img.shape[0], img.shape[1], None, 0)
+    buf = C.create_string_buffer(n)
+    lib().hc_csv_u8(img.ctypes.data, img.shape[0], img.shape[1], buf, n)
+    return buf.raw.decode()
 
 
 def angle(dx, dy, dz):
