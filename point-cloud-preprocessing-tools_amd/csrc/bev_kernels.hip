@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
 
     /* Neighbour exchange: lanes l+-2 of the same wave are reached with shuffles; only the two edge
      * lanes on each side of a wave go through LDS (768 B instead of a 12 KiB row buffer, so that these
-     * workgroups can share a CU with the 151 KiB cell-sum and 98 KiB raster workgroups of the other lane). */
+     * workgroups can share a CU with the 139 KiB cell-sum and 98 KiB raster workgroups of the other lane). */
     constexpr int kWaves = kStripThreads / 64;
     __shared__ float4 edge[3][kWaves][4];                  /* rows r, r-1, (r-2): lanes 0, 1, 62, 63 of every wave */
     __shared__ uint32_t wave_cnt[2][kWaves];               /* per-wave candidate counts of the row being written */
