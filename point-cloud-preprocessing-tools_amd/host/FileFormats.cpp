@@ -14,13 +14,24 @@ namespace bevio {
 
 namespace {
 
+enum Target { T_NONE = -1, T_X, T_Y, T_Z, T_INTENSITY, T_ROW, T_COL, T_T, T_LABEL };
+
 struct Field {
     std::string name;
     int size = 4;
     char type = 'F';
     int count = 1;
     int offset = 0; /* byte offset inside one packed record */
+    Target target = T_NONE; /* which member of PointXYZIRCT the field feeds (resolved once per file) */
 };
+
+Target target_of(const std::string &name)
+{
+    static const char *const names[] = {"x", "y", "z", "intensity", "row", "col", "t", "label"};
+    for (int k = 0; k < 8; ++k)
+        if (name == names[k]) return (Target)k;
+    return T_NONE;
+}
 
 double read_scalar(const unsigned char *p, int size, char type)
 {
@@ -55,16 +66,37 @@ T to_int(double v)
     return v <= lo ? std::numeric_limits<T>::min() : (v >= hi ? std::numeric_limits<T>::max() : (T)v);
 }
 
-void assign_field(pcl::PointXYZIRCT &pt, const std::string &name, double v)
+void assign_field(pcl::PointXYZIRCT &pt, Target target, double v)
 {
-    if (name == "x") pt.x = (float)v;
-    else if (name == "y") pt.y = (float)v;
-    else if (name == "z") pt.z = (float)v;
-    else if (name == "intensity") pt.intensity = (float)v;
-    else if (name == "row") pt.row = to_int<std::uint16_t>(v);
-    else if (name == "col") pt.col = to_int<std::uint16_t>(v);
-    else if (name == "t") pt.t = to_int<std::uint32_t>(v);
-    else if (name == "label") pt.label = to_int<std::int16_t>(v);
+    switch (target) {
+    case T_X: pt.x = (float)v; break;
+    case T_Y: pt.y = (float)v; break;
+    case T_Z: pt.z = (float)v; break;
+    case T_INTENSITY: pt.intensity = (float)v; break;
+    case T_ROW: pt.row = to_int<std::uint16_t>(v); break;
+    case T_COL: pt.col = to_int<std::uint16_t>(v); break;
+    case T_T: pt.t = to_int<std::uint32_t>(v); break;
+    case T_LABEL: pt.label = to_int<std::int16_t>(v); break;
+    case T_NONE: break;
+    }
+}
+
+/* the layout PCL writes for this point type (and savePCDFileBinary below): records are copied member by member */
+bool is_native_layout(const std::vector<Field> &fields)
+{
+    static const int sizes[8] = {4, 4, 4, 4, 2, 2, 4, 2};
+    static const char types[8] = {'F', 'F', 'F', 'F', 'U', 'U', 'U', 'I'};
+    if (fields.size() != 8) return false;
+    for (int k = 0; k < 8; ++k)
+        if (fields[k].target != (Target)k || fields[k].size != sizes[k] || fields[k].type != types[k] || fields[k].count != 1)
+            return false;
+    return true;
+}
+void unpack_native(pcl::PointXYZIRCT &pt, const unsigned char *p)
+{
+    std::memcpy(&pt.x, p, 4); std::memcpy(&pt.y, p + 4, 4); std::memcpy(&pt.z, p + 8, 4);
+    std::memcpy(&pt.intensity, p + 12, 4); std::memcpy(&pt.row, p + 16, 2); std::memcpy(&pt.col, p + 18, 2);
+    std::memcpy(&pt.t, p + 20, 4); std::memcpy(&pt.label, p + 24, 2);
 }
 
 /* liblzf decompression (format used by PCL's DATA binary_compressed) */
@@ -158,6 +190,7 @@ int load_pcd(const std::string &path, pcl::PointCloud<pcl::PointXYZIRCT> &cloud)
     for (auto &fd : fields) {
         if ((fd.size != 1 && fd.size != 2 && fd.size != 4 && fd.size != 8) || fd.count < 1 || fd.count > 4096) return -1;
         if (fd.type != 'F' && fd.type != 'U' && fd.type != 'I') return -1;
+        fd.target = target_of(fd.name);
         fd.offset = rec;
         rec += fd.size * fd.count;
     }
@@ -178,7 +211,7 @@ int load_pcd(const std::string &path, pcl::PointCloud<pcl::PointXYZIRCT> &cloud)
                 for (int k = 0; k < fd.count; ++k) {
                     double v = 0;
                     ss >> v;
-                    if (k == 0) assign_field(cloud.points[i], fd.name, v);
+                    if (k == 0) assign_field(cloud.points[i], fd.target, v);
                 }
         }
         return 0;
@@ -187,9 +220,14 @@ int load_pcd(const std::string &path, pcl::PointCloud<pcl::PointXYZIRCT> &cloud)
         std::vector<unsigned char> buf((std::size_t)rec * points);
         f.read(reinterpret_cast<char *>(buf.data()), (std::streamsize)buf.size());
         if ((std::size_t)f.gcount() != buf.size()) return -1;
+        if (is_native_layout(fields)) {
+            for (std::size_t i = 0; i < points; ++i) unpack_native(cloud.points[i], buf.data() + i * 26);
+            return 0;
+        }
         for (std::size_t i = 0; i < points; ++i)
             for (auto &fd : fields)
-                assign_field(cloud.points[i], fd.name, read_scalar(buf.data() + i * rec + fd.offset, fd.size, fd.type));
+                if (fd.target != T_NONE)
+                    assign_field(cloud.points[i], fd.target, read_scalar(buf.data() + i * rec + fd.offset, fd.size, fd.type));
         return 0;
     }
     if (data_kind == "binary_compressed") {
@@ -205,8 +243,9 @@ int load_pcd(const std::string &path, pcl::PointCloud<pcl::PointXYZIRCT> &cloud)
         std::size_t base = 0;
         for (auto &fd : fields) {
             const std::size_t stride = (std::size_t)fd.size * fd.count;
-            for (std::size_t i = 0; i < points; ++i)
-                assign_field(cloud.points[i], fd.name, read_scalar(buf.data() + base + i * stride, fd.size, fd.type));
+            if (fd.target != T_NONE)
+                for (std::size_t i = 0; i < points; ++i)
+                    assign_field(cloud.points[i], fd.target, read_scalar(buf.data() + base + i * stride, fd.size, fd.type));
             base += stride * points;
         }
         return 0;
