@@ -3,11 +3,11 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 TAG=${1:-r01}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-# 1. kernel trace + stats of the bench command line with ONE lane (BEV_LANES=1): every launch runs back to back, like in
+# 1. plain bench first (with the CPU baseline): the GPU slows down by 5-10 % once the profiled runs have warmed it up
+timeout 900 python3 bench.py --steps 5 --warmup 2 > $OUT/bench.log 2>&1
+# 2. kernel trace + stats of the bench command line with ONE lane (BEV_LANES=1): every launch runs back to back, like in
 #    bench.py's roofline pass, so AverageNs is comparable with roofline.avg_launch_ms
 BEV_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu > $OUT/bench_under_rocprof.log 2>&1
-# 2. plain bench (with the CPU baseline)
-timeout 900 python3 bench.py --steps 5 --warmup 2 > $OUT/bench.log 2>&1
 # 3. PMC passes, one counter group per run (no trace domains mixed in)
 ARGS="bench.py --steps 1 --warmup 1 --no-cpu --no-profile --frames 256 --sub-batch 256"
 i=0
