@@ -48,6 +48,7 @@ struct Lane {
     uint16_t *cand_cell = nullptr;
     float *cand_z = nullptr;
     uint2 *cand_aux = nullptr;
+    uint16_t *cand_cellp = nullptr;
     uint32_t *ncand = nullptr;
     float *zsorted = nullptr;
     float *avg = nullptr;
@@ -301,6 +302,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.cand_cell = ln.cand_cell;
         b.cand_z = ln.cand_z;
         b.cand_aux = ln.cand_aux;
+        b.cand_cellp = ln.cand_cellp;
         b.ncand = ln.ncand;
         b.zsorted = ln.zsorted;
         b.avg = ln.avg;
@@ -531,6 +533,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipMalloc((void **)&ln.cand_cell, nb * (size_t)c->geo.segs * kSeg * sizeof(uint16_t)));
         CK(hipMalloc((void **)&ln.cand_z, nb * (size_t)c->geo.segs * kSeg * sizeof(float)));
         CK(hipMalloc((void **)&ln.cand_aux, nb * (size_t)c->geo.segs * kSeg * sizeof(uint2)));
+        CK(hipMalloc((void **)&ln.cand_cellp, nb * (size_t)c->geo.segs * kSeg * sizeof(uint16_t)));
         CK(hipMalloc((void **)&ln.ncand, nb * (size_t)c->geo.segs * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.zsorted, nb * S * sizeof(float)));
         CK(hipMalloc((void **)&ln.avg, nb * (size_t)bevx::kGridCells * sizeof(float)));
@@ -558,7 +561,7 @@ void bev_destroy(bev_ctx_t *c)
     for (int l = 0; l < kMaxLanes; ++l) {
         Lane &ln = c->lanes[l];
         if (ln.st) (void)hipStreamSynchronize(ln.st);
-        void *ws[] = {ln.winner, ln.codes, ln.cand_cell, ln.cand_z, ln.cand_aux, ln.ncand, ln.zsorted, ln.avg, ln.gm};
+        void *ws[] = {ln.winner, ln.codes, ln.cand_cell, ln.cand_z, ln.cand_aux, ln.cand_cellp, ln.ncand, ln.zsorted, ln.avg, ln.gm};
         for (void *p : ws)
             if (p) (void)hipFree(p);
         if (ln.done) (void)hipEventDestroy(ln.done);

@@ -39,10 +39,17 @@ struct FrameDesc {
  * three parallel arrays per (row, strip) segment so that the per-cell sum kernel reads
  * 2 (cell) resp. 6 (cell + z) bytes per candidate instead of a 16-byte record:
  *   cand_cell u16 : getBelongingGrid cell, row * 50 + col
+ *   cand_cellp u16: the same cell | kCandPredBit if the walk wrote the point with its own label / code (its guess that
+ *                   phase C un-grounds it).  A second array because the per-cell sum kernel must not pay for a mask:
+ *                   with the bit inside cand_cell the compiler interleaved that kernel's batched loads with its
+ *                   scattered stores (in-order vmcnt) and the kernel took 30 % longer.
  *   cand_z    f32 : the height that is summed
  *   cand_aux  2xu32 : x = column offset inside the strip (8 bit) | original label << 8,
  *                     y = BEV code the point gets back if phase C un-grounds it */
 static_assert(sizeof(bev_point_t) == 32, "bev_point_t must be 32 bytes");
+
+constexpr uint32_t kCandCellMask = 0x0fffu; /* 75 * 50 = 3750 cells */
+constexpr uint32_t kCandPredBit = 0x8000u;
 
 struct Geometry {
     int N, H, G;       /* N_SCAN, Horizon_SCAN, GROUND_UPPER_SCAN */
@@ -66,6 +73,7 @@ struct BatchPtrs {
     uint16_t *cand_cell;         /* [nf][segs][kSeg] */
     float *cand_z;               /* [nf][segs][kSeg] */
     uint2 *cand_aux;             /* [nf][segs][kSeg] */
+    uint16_t *cand_cellp;        /* [nf][segs][kSeg] */
     uint32_t *ncand;             /* [nf][segs] */
     float *zsorted;              /* [nf][S] */
     float *avg;                  /* [nf][3750] */

@@ -230,6 +230,7 @@ struct PendingRow {
     uint32_t code;
     int status;      /* s[row] (kInvalid / kSteep / kGround); kSteep for rows that are not tested */
     int gflag;       /* ground_mat(row) at the end of phase A */
+    bool pred;       /* candidate the walk expects phase C to un-ground (see "provisional labels" below) */
 };
 
 template <bool kIdentity>
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
 
     XYZI prev{0.f, 0.f, 0.f, 0.f}, prevprev{0.f, 0.f, 0.f, 0.f};
     PendingRow p1{}, p2{};              /* rows r-1 (ground flag still open) and r-2 (ready to write) */
+    float zref = __uint_as_float(0x7fc00000u); /* height of the column's last candidate taken for ground (NaN: none yet) */
     unsigned long long m_ready = 0;     /* candidate ballot of row r-2 */
 
     const size_t cand_base = (size_t)f * g.segs * kSeg;
@@ -334,6 +336,18 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
             p1.gflag = (q >= 0 && q < N) ? gf : 0;
         }
         const unsigned long long m_new = __ballot(outcol && p1.gflag == 1);
+        /* Provisional labels.  Phase C un-grounds a candidate that lies 0.30 m above a neighbour cell's average ground
+         * height — known only after the whole frame has been summed.  The walk GUESSES: a candidate 0.30 m above the last
+         * candidate of its column that it took for ground is written with its own label and BEV code, every other
+         * candidate with label 0 and no code; k_ground_resolve tests every candidate exactly and patches the wrong
+         * guesses in either direction.  The guess only decides how many sparse 2- and 4-byte patches are needed
+         * (benchmark frames: 1.3 k instead of 7.9 k per frame; without any patch the pipeline would be 8 % faster). */
+        {
+            const float zq = __uint_as_float(p1.lo.w[2]);
+            const bool cand = outcol && p1.gflag == 1;
+            p1.pred = cand && (zq - zref >= 0.3f); /* false while zref is NaN */
+            if (cand && !p1.pred) zref = zq;
+        }
 
         /* ---- write out row r-2 (its per-wave counts were published before the barrier) ---- */
         if (r >= 2) {
@@ -353,6 +367,8 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
                     const uint32_t rank = before + (uint32_t)__popcll(m_ready & ((1ull << lane) - 1ull));
                     const size_t at = cand_base + seg * kSeg + rank;
                     store_stream(&b.cand_cell[at], (uint16_t)ground_cell(__uint_as_float(p2.lo.w[0]), __uint_as_float(p2.lo.w[1])));
+                    store_stream(&b.cand_cellp[at], (uint16_t)((uint32_t)ground_cell(__uint_as_float(p2.lo.w[0]), __uint_as_float(p2.lo.w[1])) |
+                                                               (p2.pred ? kCandPredBit : 0u)));
                     store_stream(&b.cand_z[at], __uint_as_float(p2.lo.w[2]));
                     store_stream(&b.cand_aux[at], make_uint2((uint32_t)(tid - 2) | ((p2.hi.w[3] & 0xffffu) << 8), p2.code));
                 }
@@ -360,12 +376,13 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
             }
             if (outcol) {
                 Half hi = p2.hi;
-                if (is_cand) hi.w[3] &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
+                const bool as_ground = is_cand && !p2.pred;
+                if (as_ground) hi.w[3] &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
                 const size_t idx = frame_off + (size_t)(q * H + v);
                 Half *dst = reinterpret_cast<Half *>(b.ordered + idx);
                 store_stream(dst, p2.lo);
                 store_stream(dst + 1, hi);
-                store_stream(&b.codes[idx], is_cand ? kSkip : p2.code);
+                store_stream(&b.codes[idx], as_ground ? kSkip : p2.code);
                 if (b.gm) b.gm[idx] = (int8_t)p2.gflag;
             }
         }
@@ -688,7 +705,7 @@ __global__ __launch_bounds__(kSeg) void k_ground_resolve(BatchPtrs b, Geometry g
             const int st = q.s0 + k;
             const bool ok = st < g.strips && (uint32_t)tid < cnt[q.rr * g.strips + (st < g.strips ? st : 0)];
             const size_t at = (seg0 + st) * kSeg + tid;
-            q.cell[k] = ok ? (uint32_t)b.cand_cell[at] : 0u;
+            q.cell[k] = ok ? (uint32_t)b.cand_cellp[at] : 0u; /* cell | kCandPredBit */
             q.z[k] = ok ? b.cand_z[at] : 0.f;
             q.ok |= ok ? (1u << k) : 0u;
         }
@@ -697,20 +714,28 @@ __global__ __launch_bounds__(kSeg) void k_ground_resolve(BatchPtrs b, Geometry g
         if (q.ok == 0u) return;
         const size_t seg0 = (size_t)f * g.segs + (size_t)q.rr * g.strips;
         const size_t row_off = (size_t)f * g.S + (size_t)(q.rr + g.N - g.G - 1) * g.H;
-        uint32_t hits = 0u;
-#pragma unroll
-        for (int k = 0; k < kMaxResolveStrips; ++k)
-            if (((q.ok >> k) & 1u) && above_neighbour_ground(q.z[k], (int)q.cell[k], avg)) hits |= 1u << k;
-        uint2 aux[kMaxResolveStrips];
-#pragma unroll
-        for (int k = 0; k < kMaxResolveStrips; ++k) /* all aux loads of the unit's hits in flight together */
-            aux[k] = ((hits >> k) & 1u) ? b.cand_aux[(seg0 + q.s0 + k) * kSeg + tid] : make_uint2(0u, 0u);
+        /* hits: un-grounded by phase C.  wrong: the walk's provisional label / code (written for its guess) differ. */
+        uint32_t hits = 0u, wrong = 0u;
 #pragma unroll
         for (int k = 0; k < kMaxResolveStrips; ++k) {
-            if ((hits >> k) & 1u) {
+            if (!((q.ok >> k) & 1u)) continue;
+            const bool hit = above_neighbour_ground(q.z[k], (int)(q.cell[k] & kCandCellMask), avg);
+            const bool pred = (q.cell[k] & kCandPredBit) != 0u;
+            hits |= hit ? (1u << k) : 0u;
+            wrong |= (hit != pred) ? (1u << k) : 0u;
+        }
+        uint2 aux[kMaxResolveStrips];
+#pragma unroll
+        for (int k = 0; k < kMaxResolveStrips; ++k) /* all aux loads of the unit's wrong guesses in flight together */
+            aux[k] = ((wrong >> k) & 1u) ? b.cand_aux[(seg0 + q.s0 + k) * kSeg + tid] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int k = 0; k < kMaxResolveStrips; ++k) {
+            if ((wrong >> k) & 1u) {
                 const size_t idx = row_off + (size_t)(q.s0 + k) * kStripCols + (aux[k].x & 0xffu);
-                reinterpret_cast<uint16_t *>(b.ordered + idx)[14] = (uint16_t)(aux[k].x >> 8); /* label @28 */
-                b.codes[idx] = aux[k].y;
+                const bool hit = (hits >> k) & 1u;
+                /* label @28: the point's own label back, or 0 for ground (BatchMultiBevGen.cpp:245) */
+                reinterpret_cast<uint16_t *>(b.ordered + idx)[14] = hit ? (uint16_t)(aux[k].x >> 8) : (uint16_t)0;
+                b.codes[idx] = hit ? aux[k].y : kSkip;
             }
         }
     };
