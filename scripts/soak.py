@@ -1,0 +1,41 @@
+"""Soak: many different BASELINE-config frames through the pipelined device-resident path, EVERY frame compared with the
+oracle.  usage (GPU box): python scripts/soak.py [rounds] [frames_per_round]"""
+import sys, os, time
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "point-cloud-preprocessing-tools_amd")); sys.path.insert(0, str(REPO / "tests"))
+import numpy as np, torch
+import bev_amd, oracle_lib as orc
+from bev_amd import synth
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+p = bev_amd.params_for_sensor("HDL_64E"); sp = orc.sensor_from_params(p)
+S, M, L = p.slots, p.mat_size, p.n_layers
+dev = torch.device("cuda:0")
+ctx = bev_amd.BevContext(p, device=0, max_batch=256, max_points=S + 6000)
+bad_total = 0
+for rnd in range(rounds):
+    t0 = time.time()
+    with ThreadPoolExecutor(16) as ex:
+        frames = list(ex.map(lambda f: synth.sweep(p, 100000 + rnd * n + f, keep=0.98 - 0.02 * (rnd % 3), n_dup=5000 + 500 * (rnd % 4)), range(n)))
+    offs = np.zeros(n + 1, np.uint64); offs[1:] = np.cumsum([len(f) for f in frames])
+    d_in = torch.from_numpy(np.concatenate(frames).view(np.uint8).reshape(-1)).to(dev)
+    d_ord = torch.zeros(n * S * 32, dtype=torch.uint8, device=dev)
+    d_multi = torch.zeros(n * L * M * M, dtype=torch.uint8, device=dev); d_single = torch.zeros(n * M * M, dtype=torch.uint8, device=dev)
+    for _ in range(2):
+        ctx.process_device(n, d_in.data_ptr(), offs, d_ord.data_ptr(), d_multi.data_ptr(), d_single.data_ptr())
+    ctx.synchronize()
+    ords, multis, singles = d_ord.cpu().numpy(), d_multi.cpu().numpy(), d_single.cpu().numpy()
+    def check(i):
+        o_ord, _, o_multi, o_single = orc.process_frame(sp, frames[i], want_gm=False)
+        return (ords[i * S * 32:(i + 1) * S * 32].tobytes() == o_ord.tobytes() and multis[i * L * M * M:(i + 1) * L * M * M].tobytes() == o_multi.tobytes()
+                and singles[i * M * M:(i + 1) * M * M].tobytes() == o_single.tobytes())
+    with ThreadPoolExecutor(16) as ex:
+        bad = [i for i, ok in enumerate(ex.map(check, range(n))) if not ok]
+    bad_total += len(bad)
+    print(f"round {rnd}: {n} frames, {len(bad)} differ from the oracle {bad[:5]}, {time.time() - t0:.1f} s", flush=True)
+    del d_in, d_ord, d_multi, d_single
+print("TOTAL frames", rounds * n, "mismatches", bad_total)
+sys.exit(1 if bad_total else 0)
