@@ -232,7 +232,29 @@ def main() -> int:
         parity = (got == o_ord.tobytes()
                   and d_multi[i * L * M * M:(i + 1) * L * M * M].cpu().numpy().tobytes() == o_multi.tobytes()
                   and d_single[i * M * M:(i + 1) * M * M].cpu().numpy().tobytes() == o_single.tobytes())
+        # the same oracle frame-parallel on the host's cores (the reference is single-threaded: context only).  ctypes
+        # releases the GIL, every worker has its own output buffers; bounded to the same frames as above.
+        n_thr = max(1, min(os.cpu_count() or 1, 64))
+        bufs = [(np.empty(S, bev_amd.POINT_DTYPE), np.empty((L, M, M), np.uint8), np.empty((M, M), np.uint8)) for _ in range(n_thr)]
+
+        def cpu_worker(w):
+            o, m, s_ = bufs[w]
+            for i in range(w, n_cpu, n_thr):
+                fr = host[i, : counts[i]]
+                lib.oracle_process_frame(C.byref(sp), fr.ctypes.data, len(fr), o.ctypes.data, None, m.ctypes.data, s_.ctypes.data)
+
+        tp = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=n_thr) as ex:
+            list(ex.map(cpu_worker, range(n_thr)))
+        tp = time.perf_counter() - tp
+        cpu_model = ""
+        try:
+            cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        except Exception:
+            pass
         cpu = {"value": n_cpu / tc, "unit": "frames/s", "cores": 1, "kind": "port",
+               "frame_parallel": {"value": n_cpu / tp, "unit": "frames/s", "cores": n_thr},
+               "cpu_model": cpu_model,
                "sample": f"first {n_cpu} of the {count} frames, oracle_process_frame (order+ground+both rasters, outputs to memory), gcc -O3 no -march",
                "ms_per_frame": tc / n_cpu * 1e3, "host_cpus": os.cpu_count(),
                "gpu_output_matches_oracle_on_sampled_frame": bool(parity)}
