@@ -193,6 +193,31 @@ def test_float_bev(ctxs, sensor):
     assert ctx.float_bev(marked, 1.0, True).shape == (201, 201)
 
 
+@pytest.mark.parametrize("geom", [(128, 2048, 100, 0.25), (16, 1800, 10, 1.0), (64, 4000, 50, 0.5), (128, 1024, 126, 0.5)])
+def test_other_sensor_geometries(geom):
+    """Sensors outside the reference's table (128 beams, 16 beams, 4000 columns, every row but two ground-tested): the
+    kernels take N_SCAN / Horizon_SCAN / GROUND_UPPER_SCAN as parameters; (G + 1) * strips stays within the 1024
+    candidate segments a frame may have."""
+    n, h, g, res = geom
+    p = bev_amd.params_for_sensor("HDL_64E")
+    p.n_scan, p.horizon_scan, p.ground_upper_scan, p.height_res = n, h, g, res
+    sp = orc.sensor_from_params(p)
+    frames = [synth.sweep(p, 40 + i, keep=0.95, n_dup=3000) for i in range(2)] + [synth.adversarial(p, 50000, 8, True)]
+    ctx = bev_amd.BevContext(p, device=0, max_batch=4, max_points=max(len(f) for f in frames))
+    try:
+        ordered, multi, single, gm = ctx.process_batch(frames, want_ground_mat=True)
+        for i, pts in enumerate(frames):
+            o_ord, o_gm, o_multi, o_single = orc.process_frame(sp, pts)
+            assert ordered[i].tobytes() == o_ord.tobytes(), (geom, i)
+            assert np.array_equal(gm[i], o_gm) and np.array_equal(multi[i], o_multi) and np.array_equal(single[i], o_single), (geom, i)
+    finally:
+        ctx.close()
+    # one row more of ground testing than the kernels' segment table holds is refused, not mis-computed
+    p.n_scan, p.horizon_scan, p.ground_upper_scan = 200, 2048, 150
+    with pytest.raises(bev_amd.BevError):
+        bev_amd.BevContext(p, device=0, max_batch=1, max_points=1000)
+
+
 def test_transform_cloud(ctxs):
     """cloud_manip's rigid transform (CloudManip.cpp:119-128) on the device, bit-identical to the oracle."""
     p, ctx = ctxs("HDL_64E")
