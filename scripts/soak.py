@@ -1,5 +1,5 @@
 """Soak: many different BASELINE-config frames through the pipelined device-resident path, EVERY frame compared with the
-oracle.  usage (GPU box): python scripts/soak.py [rounds] [frames_per_round]"""
+oracle.  usage (GPU box): python scripts/soak.py [rounds] [frames_per_round] [hdl64_sweep | os1_firing | hdl32_sweep | hdl64_adversarial]"""
 import sys, os, time
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -11,15 +11,28 @@ from bev_amd import synth
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-p = bev_amd.params_for_sensor("HDL_64E"); sp = orc.sensor_from_params(p)
+workload = sys.argv[3] if len(sys.argv) > 3 else "hdl64_sweep"
+p = bev_amd.params_for_sensor({"hdl64_sweep": "HDL_64E", "os1_firing": "OS1_64", "hdl32_sweep": "HDL_32E", "hdl64_adversarial": "HDL_64E"}[workload])
+sp = orc.sensor_from_params(p)
+
+
+def make_frame(rnd, f):
+    fid = 100000 + rnd * n + f
+    if workload == "os1_firing":
+        return synth.firing_order(p, fid)
+    if workload == "hdl64_adversarial":
+        return synth.adversarial(p, 60000 + 1000 * (f % 70), fid, nonfinite=bool(f % 2))
+    return synth.sweep(p, fid, keep=0.98 - 0.02 * (rnd % 3), n_dup=5000 + 500 * (rnd % 4))
+
+
 S, M, L = p.slots, p.mat_size, p.n_layers
 dev = torch.device("cuda:0")
-ctx = bev_amd.BevContext(p, device=0, max_batch=256, max_points=S + 6000)
+ctx = bev_amd.BevContext(p, device=0, max_batch=256, max_points=max(S + 8000, 140000))
 bad_total = 0
 for rnd in range(rounds):
     t0 = time.time()
     with ThreadPoolExecutor(16) as ex:
-        frames = list(ex.map(lambda f: synth.sweep(p, 100000 + rnd * n + f, keep=0.98 - 0.02 * (rnd % 3), n_dup=5000 + 500 * (rnd % 4)), range(n)))
+        frames = list(ex.map(lambda f: make_frame(rnd, f), range(n)))
     offs = np.zeros(n + 1, np.uint64); offs[1:] = np.cumsum([len(f) for f in frames])
     d_in = torch.from_numpy(np.concatenate(frames).view(np.uint8).reshape(-1)).to(dev)
     d_ord = torch.zeros(n * S * 32, dtype=torch.uint8, device=dev)
