@@ -13,6 +13,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -99,9 +100,28 @@ int oracle_angle_is_ground(float diff_x, float diff_y, float diff_z)
     return fabsf(angle - mount) <= 10.0f;
 }
 
+/* The OTHER overload reading of the same lines.  BatchMultiBevGen.h:38 has "using namespace std" commented out, so
+ * the unqualified sqrt / atan2 / abs at :173,:179 bind to whatever the third-party headers made visible: the float
+ * overloads (above, adopted) when libstdc++'s <math.h> / <cmath> wrappers are in scope, the C double functions
+ * otherwise.  Double reading: the products and their sum are still float (float operands), sqrt and atan2 run in
+ * double on the promoted values, the result is stored to the float `angle` (:126), fabs of a float is exact. */
+int oracle_angle_is_ground_f64(float diff_x, float diff_y, float diff_z)
+{
+    double horiz = sqrt((double)(diff_x * diff_x + diff_y * diff_y));
+    float angle = (float)(atan2((double)diff_z, horiz) * 180.0 / M_PI);
+    const float mount = 0.0f;
+    return fabs((double)(angle - mount)) <= 10.0f;
+}
+
 /* BatchMultiBevGen.cpp:119-252 */
 void oracle_mark_ground(const oracle_sensor_t *sp, oracle_point_t *cloud,
                         int8_t *ground_mat, float *avg_out)
+{
+    oracle_mark_ground_variant(sp, cloud, ground_mat, avg_out, ORACLE_ANGLE_F32);
+}
+
+void oracle_mark_ground_variant(const oracle_sensor_t *sp, oracle_point_t *cloud,
+                                int8_t *ground_mat, float *avg_out, int angle_variant)
 {
     const int N = sp->n_scan, H = sp->horizon_scan, G = sp->ground_upper_scan;
     const size_t S = (size_t)N * (size_t)H;
@@ -138,7 +158,8 @@ void oracle_mark_ground(const oracle_sensor_t *sp, oracle_point_t *cloud,
             float dx = cloud[upper].x - cloud[lower].x; /* :169-171 */
             float dy = cloud[upper].y - cloud[lower].y;
             float dz = cloud[upper].z - cloud[lower].z;
-            if (oracle_angle_is_ground(dx, dy, dz)) { /* :173-182 */
+            if (angle_variant == ORACLE_ANGLE_F64 ? oracle_angle_is_ground_f64(dx, dy, dz)
+                                                  : oracle_angle_is_ground(dx, dy, dz)) { /* :173-182 */
                 ground_mat[(size_t)row * H + col] = 1;
                 ground_mat[(size_t)(row - 1) * H + col] = 1;
             }
@@ -247,6 +268,38 @@ void oracle_process_frame(const oracle_sensor_t *sp, const oracle_point_t *in,
     oracle_multi_bev(sp, ordered, S, 1.0f, multi);    /* :746 */
     oracle_single_bev(ordered, S, 1.0f, single);      /* :747 */
     if (!ground_mat) free(gm);
+}
+
+/* The file outputs inside the reference's timed region (BatchMultiBevGen.cpp:732-752) other than the PNGs:
+ * the .bin of computeAndSaveMultiBev (:294-314: layer by layer, row by row, 224 bytes per write through one ofstream)
+ * and the .csv of computeAndSaveSingleBev (:365-372: cv::format(mat, FMT_CSV) streamed into an ofstream).  The CSV
+ * framing is OpenCV's, restated FROM MEMORY of modules/core/src/out.cpp (u8 as "%3d", values joined by ", ", rows by
+ * "\n", one trailing "\n"): PARITY UNPINNED.  Used by bench.py's cpu_baseline "timed_region"
+ * leg only.  Returns 0 on success. */
+int oracle_save_bin_csv(const uint8_t *multi, const uint8_t *single, int M, int layers,
+                        const char *bin_path, const char *csv_path)
+{
+    FILE *fb = fopen(bin_path, "wb");
+    if (!fb) return -1;
+    for (int l = 0; l < layers; ++l)
+        for (int r = 0; r < M; ++r)
+            if (fwrite(multi + ((size_t)l * M + r) * M, 1, (size_t)M, fb) != (size_t)M) { fclose(fb); return -1; }
+    if (fclose(fb) != 0) return -1;
+    FILE *fc = fopen(csv_path, "w");
+    if (!fc) return -1;
+    char *line = (char *)malloc((size_t)M * 5 + 2);
+    if (!line) { fclose(fc); return -1; }
+    for (int r = 0; r < M; ++r) {
+        size_t n = 0;
+        for (int c = 0; c < M; ++c) {
+            n += (size_t)snprintf(line + n, 6, "%3d", (int)single[(size_t)r * M + c]);
+            if (c + 1 < M) { line[n++] = ','; line[n++] = ' '; }
+        }
+        line[n++] = '\n';
+        if (fwrite(line, 1, n, fc) != n) { free(line); fclose(fc); return -1; }
+    }
+    free(line);
+    return fclose(fc) == 0 ? 0 : -1;
 }
 
 /* BatchCloudManip.cpp:201-225 / CloudManip.cpp:79-99 */

@@ -69,12 +69,21 @@ void oracle_order_cloud(const oracle_sensor_t *sp, const oracle_point_t *in,
 /* The angle test of markGroundPoints phase A, BatchMultiBevGen.cpp:169-179,
  * for one (upper - lower) difference vector. Returns 1 if "ground". */
 int oracle_angle_is_ground(float diff_x, float diff_y, float diff_z);
+/* The same test under the other overload resolution the reference's source admits (double sqrt / atan2 / fabs;
+ * BatchMultiBevGen.h:38, .cpp:173,179).  NOT the adopted reading: it exists so that tests can MEASURE how many slots
+ * and labels the choice changes (tests/test_oracle_overloads.py). */
+int oracle_angle_is_ground_f64(float diff_x, float diff_y, float diff_z);
+#define ORACLE_ANGLE_F32 0
+#define ORACLE_ANGLE_F64 1
 
 /* markGroundPoints, BatchMultiBevGen.cpp:119-252.  cloud: S ordered points,
  * labels rewritten in place.  ground_mat: S int8 (required).  avg_out: NULL or
  * 75*50 floats = ground_grid_avg_heights after the divide at :210. */
 void oracle_mark_ground(const oracle_sensor_t *sp, oracle_point_t *cloud,
                         int8_t *ground_mat, float *avg_out);
+/* markGroundPoints with the angle test of the chosen overload reading (ORACLE_ANGLE_F32 = oracle_mark_ground). */
+void oracle_mark_ground_variant(const oracle_sensor_t *sp, oracle_point_t *cloud,
+                                int8_t *ground_mat, float *avg_out, int angle_variant);
 
 /* Raster part of computeAndSaveMultiBev, BatchMultiBevGen.cpp:266-292.
  * out: 24 * M * M bytes laid out as the .bin file (:307-314), M = 224/interval. */
@@ -91,6 +100,11 @@ void oracle_single_bev(const oracle_point_t *cloud, size_t n, float interval,
 void oracle_process_frame(const oracle_sensor_t *sp, const oracle_point_t *in,
                           size_t n_in, oracle_point_t *ordered, int8_t *ground_mat,
                           uint8_t *multi, uint8_t *single);
+
+/* .bin + .csv writes of the reference's timed region (BatchMultiBevGen.cpp:294-314, :365-372), CSV framing from
+ * memory of OpenCV (PARITY UNPINNED); bench.py's cpu_baseline "timed_region" leg. */
+int oracle_save_bin_csv(const uint8_t *multi, const uint8_t *single, int M, int layers,
+                        const char *bin_path, const char *csv_path);
 
 /* Float max-height BEV of batch_cloud_manip / cloud_manip (saveAsMat,
  * BatchCloudManip.cpp:201-225, CloudManip.cpp:79-99).  skip_label0 = 1 for the

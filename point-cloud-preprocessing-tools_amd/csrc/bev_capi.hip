@@ -291,7 +291,10 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
          * higher-priority one, so that exactly one of each kind is in flight */
         const bool staged = c->staged && lanes_used >= 2 && !identity;
         hipStream_t st = staged ? c->lanes[1].st : ln.st;
-        if (staged) HIPCK(c, hipStreamWaitEvent(st, ln.back_done, 0)); /* the set's previous tenant has left */
+        /* The workspace set's previous tenant has left.  Recorded by EVERY sub-batch on the stream that ran its back
+         * stage (staged or not, identity or not) and waited on by every front: a call that runs wholly on one lane may
+         * be followed, without a synchronisation, by a staged call whose front uses the same set from another stream. */
+        HIPCK(c, hipStreamWaitEvent(st, ln.back_done, 0));
         BatchPtrs b{};
         b.pts = identity ? d_pts + (size_t)f0 * S : d_pts;
         b.frames = identity ? nullptr : c->d_desc[ds] + f0;
@@ -367,7 +370,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             launch_bev_raster(g, ln.codes, S, (uint32_t)S, b.multi, b.single, d_multi != nullptr,
                               d_single != nullptr, nb, st);
         }
-        if (staged) HIPCK(c, hipEventRecord(ln.back_done, st));
+        HIPCK(c, hipEventRecord(ln.back_done, st));
         c->last_sub_frames = nb;
         c->last_avg = ln.avg;
         HIPCK(c, hipGetLastError());

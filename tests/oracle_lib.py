@@ -33,6 +33,10 @@ def lib():
         l.oracle_angle_is_ground.argtypes = [C.c_float, C.c_float, C.c_float]
         l.oracle_mark_ground.argtypes = [SP, vp, vp, vp]
         l.oracle_mark_ground.restype = None
+        l.oracle_mark_ground_variant.argtypes = [SP, vp, vp, vp, C.c_int]
+        l.oracle_mark_ground_variant.restype = None
+        l.oracle_angle_is_ground_f64.argtypes = [C.c_float, C.c_float, C.c_float]
+        l.oracle_save_bin_csv.argtypes = [vp, vp, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
         l.oracle_multi_bev.argtypes = [SP, vp, sz, C.c_float, vp]
         l.oracle_multi_bev.restype = None
         l.oracle_single_bev.argtypes = [vp, sz, C.c_float, vp]
@@ -78,11 +82,12 @@ def order_cloud(sp: OracleSensor, pts: np.ndarray) -> np.ndarray:
     return out
 
 
-def mark_ground(sp: OracleSensor, ordered: np.ndarray):
+def mark_ground(sp: OracleSensor, ordered: np.ndarray, angle_variant: int = 0):
+    """angle_variant 0: float overloads of sqrt / atan2 / abs (adopted); 1: the double reading (bev_oracle.h)."""
     cloud = np.array(ordered, dtype=POINT_DTYPE, copy=True)
     gm = np.empty((sp.n_scan, sp.horizon_scan), dtype=np.int8)
     avg = np.empty(75 * 50, dtype=np.float32)
-    lib().oracle_mark_ground(C.byref(sp), cloud.ctypes.data, gm.ctypes.data, avg.ctypes.data)
+    lib().oracle_mark_ground_variant(C.byref(sp), cloud.ctypes.data, gm.ctypes.data, avg.ctypes.data, angle_variant)
     return cloud, gm, avg
 
 

@@ -78,7 +78,7 @@ def test_ragged_batch_with_empty_and_tiny_frames(ctxs):
     full = synth.sweep(p, 0)
     frames = [np.empty(0, bev_amd.POINT_DTYPE), full[:1], full, full[:1000], np.empty(0, bev_amd.POINT_DTYPE),
               synth.sweep(p, 1, keep=0.3, n_dup=20000)]
-    _check_batch(p, ctx, frames)  # 6 frames through a max_batch=4 context: two sub-batches
+    _check_batch(p, ctx, frames)  # 6 frames through a max_batch=4 context: host-buffer chunks of max_batch / 2 frames
 
 
 def test_degenerate_clouds(ctxs):
@@ -96,11 +96,16 @@ def test_degenerate_clouds(ctxs):
     _check_batch(p, ctx, [allsame, noret, lab0, oob])
 
 
-def test_oxford_concat(ctxs):
+@pytest.mark.parametrize("n_sweeps", [20, 60])
+def test_oxford_concat(ctxs, n_sweeps):
+    """BASELINE configs[4]: 60 concatenated sweeps = ~2 M points into 33,792 slots (P >> S, getOrderedCloud
+    BatchMultiBevGen.cpp:102-116); at that size the winner entries need 21 index bits and keep 11 tag bits."""
     p = bev_amd.params_for_sensor("HDL_32E")
-    pts = synth.concat(p, 0, n_sweeps=20)  # ~660k points into 33,792 slots
+    pts = synth.concat(p, 0, n_sweeps=n_sweeps)
+    if n_sweeps == 60:
+        assert len(pts) > 1_900_000
     p, ctx = ctxs("HDL_32E", 2, len(pts))
-    _check_batch(p, ctx, [pts])
+    _check_batch(p, ctx, [pts, synth.concat(p, 1, n_sweeps=n_sweeps)])
 
 
 # ---- per-function entry points (what the reference-named C++ functions call) ----

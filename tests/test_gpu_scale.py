@@ -116,3 +116,69 @@ def test_baseline_config_every_frame_matches_oracle():
     with ThreadPoolExecutor(16) as ex:
         bad = [i for i, ok in enumerate(ex.map(check, range(n))) if not ok]
     assert not bad, f"{len(bad)} of {n} frames differ from the oracle, first: {bad[:8]}"
+
+
+def test_unstaged_call_followed_by_staged_call_without_sync():
+    """A call that fits one sub-batch runs wholly on lane 0 with workspace set 0; a call with several sub-batches that
+    follows WITHOUT a synchronisation runs its front on another stream and reuses set 0: the second call's front must
+    wait for the first call's back (the hand-over event is recorded by every sub-batch, staged or not)."""
+    import torch
+
+    p = bev_amd.params_for_sensor("HDL_64E")
+    sb = 24
+    small = [synth.sweep(p, 9000 + f) for f in range(sb)]
+    big = [synth.sweep(p, 9100 + f, keep=0.9, n_dup=3000) for f in range(4 * sb + 5)]
+    ctx = bev_amd.BevContext(p, device=0, max_batch=sb, max_points=max(len(f) for f in small + big))
+    dev = torch.device("cuda:0")
+    S, M, L = p.slots, p.mat_size, p.n_layers
+    sp = orc.sensor_from_params(p)
+
+    def stage(frames):
+        offs = np.zeros(len(frames) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(f) for f in frames])
+        d_in = torch.from_numpy(np.concatenate(frames).view(np.uint8).reshape(-1)).to(dev)
+        outs = [torch.zeros(len(frames) * k, dtype=torch.uint8, device=dev) for k in (S * 32, L * M * M, M * M)]
+        return offs, d_in, outs
+
+    a, b = stage(small), stage(big)
+    torch.cuda.synchronize()
+    try:
+        for _ in range(3):  # small, big, small, big, ... never synchronised in between
+            for offs, d_in, outs in (a, b):
+                ctx.process_device(len(offs) - 1, d_in.data_ptr(), offs, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr())
+        ctx.synchronize()
+        for frames, (_, _, outs) in ((small, a), (big, b)):
+            got = [o.cpu().numpy() for o in outs]
+            for i, pts in enumerate(frames):
+                o_ord, _, o_multi, o_single = orc.process_frame(sp, pts, want_gm=False)
+                assert got[0][i * S * 32:(i + 1) * S * 32].tobytes() == o_ord.tobytes(), (len(frames), i)
+                assert got[1][i * L * M * M:(i + 1) * L * M * M].tobytes() == o_multi.tobytes(), (len(frames), i)
+                assert got[2][i * M * M:(i + 1) * M * M].tobytes() == o_single.tobytes(), (len(frames), i)
+    finally:
+        ctx.close()
+
+
+def test_os1_firing_order_config_every_frame_matches_oracle():
+    """BASELINE configs[2] at its stated size: 1000 MulRan-style OS1_64 clouds in firing order (65,536 points each,
+    column-major, incl. the col == 1024 overflow; MulranPointCloudSelect.cpp:120-125) through the pipelined
+    device-resident path, EVERY frame against the oracle.  This is where k_order_scan regroups scattering blocks by row
+    in LDS (BatchMultiBevGen.cpp:102-116 sees an unordered cloud)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    p = bev_amd.params_for_sensor("OS1_64")
+    n = 1000
+    with ThreadPoolExecutor(16) as ex:
+        frames = list(ex.map(lambda f: synth.firing_order(p, f), range(n)))
+    ords, multis, singles = _run(p, frames, sub_batch=256, lanes=2, repeats=2)
+    S, M, L = p.slots, p.mat_size, p.n_layers
+    sp = orc.sensor_from_params(p)
+
+    def check(i):
+        o_ord, _, o_multi, o_single = orc.process_frame(sp, frames[i], want_gm=False)
+        return (ords[i * S * 32:(i + 1) * S * 32].tobytes() == o_ord.tobytes()
+                and multis[i * L * M * M:(i + 1) * L * M * M].tobytes() == o_multi.tobytes()
+                and singles[i * M * M:(i + 1) * M * M].tobytes() == o_single.tobytes())
+
+    with ThreadPoolExecutor(16) as ex:
+        bad = [i for i, ok in enumerate(ex.map(check, range(n))) if not ok]
+    assert not bad, f"{len(bad)} of {n} frames differ from the oracle, first: {bad[:8]}"
