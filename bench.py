@@ -42,6 +42,9 @@ def main() -> int:
     ap.add_argument("--cpu-sample", type=int, default=400, help="frames timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-build", action="store_true",
+                    help="do not run __graft_entry__.build() first (profiling scripts build once, then run "
+                         "`rocprofv3 ... -- python3 bench.py --no-build`: no child process under the profiler)")
     args = ap.parse_args()
 
     import numpy as np
@@ -49,14 +52,44 @@ def main() -> int:
     import torch.distributed as dist
 
     import __graft_entry__ as ge
-    import bev_amd
-    from bev_amd import shard, synth
+
+    # ---- everything up to here has made no GPU call (torch.cuda.device_count() does not initialise the device) ----
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` by itself: start N ranks (one process per GPU) and relay rank 0's JSON line.
+        # This parent never touches the GPU.
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this machine shows {n_dev}", file=sys.stderr)
+            return 2
+        if not args.no_build:
+            ge.build()
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        child_args = [a for a in sys.argv[1:]]
+        if "--no-build" not in child_args:
+            child_args.append("--no-build")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *child_args]
+        return subprocess.run(cmd).returncode
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if not args.no_build:
+        # before the first GPU call of this process (make / hipcc children must not be forked from a process that holds
+        # the GPU); ranks of one node serialise on a file lock, the build is a no-op when everything is up to date
+        import fcntl
+        with open(os.path.join(os.environ.get("TMPDIR", "/tmp"), "bev_bench_build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            ge.build()
+    import bev_amd
+    from bev_amd import shard, synth
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path to fall back to)")
     torch.cuda.set_device(local_rank)
@@ -67,10 +100,6 @@ def main() -> int:
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
-    if rank == 0:
-        ge.build()
-    if use_dist:
-        dist.barrier()
     lib_missing = not bev_amd.LIB_PATH.exists()
     if lib_missing:
         raise SystemExit(f"{bev_amd.LIB_PATH} missing")
@@ -145,12 +174,20 @@ def main() -> int:
     elapsed = shard.max_over_ranks(elapsed, world, device=dev, force_collective=use_dist)
     total_frames = shard.sum_over_ranks(float(count * args.steps), world, device=dev, force_collective=use_dist)
 
-    # ---- roofline pass: the same steps again with ONE lane, every launch bracketed by HIP events on its
-    # stream.  In the timed region two sub-batch lanes overlap, which makes a single kernel's duration depend
-    # on what the other lane happens to run beside it; back to back, a launch's duration is its own.
-    stats = []
+    # ---- profile passes (after the timed region, which carries no events): (1) the same steps again, still pipelined,
+    # every launch bracketed by HIP events on its own stream: what each kernel costs UNDER OVERLAP, i.e. in the
+    # configuration the headline number comes from; (2) the same steps with ONE lane, launches back to back: a
+    # launch's duration is then its own, which is what the roofline of the dominant kernel is computed from.
+    stats, stats_pipe = [], []
     if not args.no_profile:
-        lanes_timed = ctx.set_lanes(1)
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        for _ in range(args.steps):
+            step()
+        fence()
+        stats_pipe = ctx.profile_get()
+        ctx.profile_enable(False)
+        ctx.set_lanes(1)
         ctx.profile_enable(True)
         ctx.profile_reset()
         for _ in range(args.steps):
@@ -164,12 +201,13 @@ def main() -> int:
     b_frame = bev_amd.algorithmic_bytes_per_frame(p, mean_pts)  # 32P + 32S + L*M*M + M*M
     # which part of B_frame each kernel is the one to move (DESIGN.md "Kernels")
     own_bytes = {
-        "k_strip_ground_fast": 32.0 * mean_pts + 32.0 * S,   # sorted-prefix fast path (one read of the input)
-        "k_strip_ground": 32.0 * mean_pts + 32.0 * S,        # general path (only frames that fail verification)
+        "k_strip_ground": 32.0 * mean_pts + 32.0 * S,        # the one read of the points that is counted + the ordered cloud
         "k_bev_raster": float(L * M * M + M * M),
     }
     roofline = None
     kernels = []
+    kernels_pipelined = [{"name": s["name"], "launches": s["launches"], "avg_launch_ms": s["total_ms"] / s["launches"],
+                          "total_ms": s["total_ms"]} for s in stats_pipe]
     if stats:
         tot_ms = sum(s["total_ms"] for s in stats)
         for s in stats:
@@ -187,14 +225,21 @@ def main() -> int:
         achieved = dom_bytes / (avg_ms * 1e-3) / 1e9
         # HBM bytes of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs, gfx950 FETCH correction applied; see profiles/): per frame, scaled to this launch size
-        traffic, traffic_src = None, None
-        pmc_file = REPO / "profiles" / "r01_final_pmc_traffic.json"
-        if pmc_file.exists():
-            pmc = json.loads(pmc_file.read_text())
-            for kname, kv in pmc["kernels"].items():
-                if kname.split("<")[0] == dom["name"]:
-                    traffic = kv["hbm_bytes_per_frame"] * per_launch_frames
-                    traffic_src = "profiles/r01_final_pmc_traffic.json (rocprofv3 --pmc, earlier run of the same kernel and workload)"
+        # PMC counters cannot be read from inside the process: they come from the committed rocprofv3 --pmc passes of
+        # THIS command line (scripts/profile_round.sh; 1000 frames, sub-batch 256), per frame, scaled to this launch.
+        traffic, traffic_src, traffic_total = None, None, None
+        if args.workload == "hdl64_sweep":
+            for name in ("r02_pmc_traffic.json", "r01_final_pmc_traffic.json"):
+                pmc_file = REPO / "profiles" / name
+                if not pmc_file.exists():
+                    continue
+                pmc = json.loads(pmc_file.read_text())
+                for kname, kv in pmc["kernels"].items():
+                    if kname.split("<")[0] == dom["name"]:
+                        traffic = kv["hbm_bytes_per_frame"] * per_launch_frames
+                        traffic_src = f"profiles/{name}: {pmc.get('source', 'rocprofv3 --pmc')}"
+                traffic_total = pmc.get("hbm_bytes_per_frame_all_kernels")
+                break
         # whole hot path against the wall clock of the timed region (this rank): B_frame * frames / time
         pipe_achieved = b_frame * (count * args.steps) / elapsed / 1e9
         roofline = {
@@ -205,6 +250,7 @@ def main() -> int:
             "note": "kernel durations from a one-lane pass of the same steps right after the timed region (back-to-back launches); "
                     "the timed region itself runs the two-stage pipeline (front of sub-batch k+1 beside the back of sub-batch k)",
             "pipeline": {"bytes_per_frame": b_frame, "achieved": pipe_achieved, "frac": pipe_achieved / HBM_PEAK_GBPS,
+                         "hbm_traffic_per_frame_all_kernels": traffic_total,
                          "definition": "algorithmic bytes of the whole hot path / wall time of the timed region, this GPU"},
         }
 
@@ -247,6 +293,20 @@ def main() -> int:
         with ThreadPoolExecutor(max_workers=n_thr) as ex:
             list(ex.map(cpu_worker, range(n_thr)))
         tp = time.perf_counter() - tp
+        # the reference's own timed region (BatchMultiBevGen.cpp:732-752) also writes the .bin and the .csv of every
+        # frame (PNG encodes excluded here): the same oracle calls plus those two files, on a smaller sample
+        import tempfile
+        n_io = min(100, n_cpu)
+        with tempfile.TemporaryDirectory(prefix="bev_cpu_") as td:
+            tio = time.perf_counter()
+            for i in range(n_io):
+                fr = host[i, : counts[i]]
+                lib.oracle_process_frame(C.byref(sp), fr.ctypes.data, len(fr), o_ord.ctypes.data, None,
+                                         o_multi.ctypes.data, o_single.ctypes.data)
+                rc_io = lib.oracle_save_bin_csv(o_multi.ctypes.data, o_single.ctypes.data, M, L,
+                                                os.path.join(td, f"{i:06d}.bin").encode(), os.path.join(td, f"{i:06d}.csv").encode())
+                assert rc_io == 0
+            tio = time.perf_counter() - tio
         cpu_model = ""
         try:
             cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
@@ -254,6 +314,10 @@ def main() -> int:
             pass
         cpu = {"value": n_cpu / tc, "unit": "frames/s", "cores": 1, "kind": "port",
                "frame_parallel": {"value": n_cpu / tp, "unit": "frames/s", "cores": n_thr},
+               "timed_region": {"value": n_io / tio, "unit": "frames/s", "cores": 1, "ms_per_frame": tio / n_io * 1e3,
+                                "sample": f"first {n_io} frames: oracle_process_frame + the .bin (1,204,224 B) and .csv (250,656 B) "
+                                          "writes the reference's timer covers (BatchMultiBevGen.cpp:732-752), PNG encodes excluded, "
+                                          "files on the box's temp dir"},
                "cpu_model": cpu_model,
                "sample": f"first {n_cpu} of the {count} frames, oracle_process_frame (order+ground+both rasters, outputs to memory), gcc -O3 no -march",
                "ms_per_frame": tc / n_cpu * 1e3, "host_cpus": os.cpu_count(),
@@ -276,11 +340,12 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": f"{F} synthetic {args.workload} {args.sensor} clouds per GPU (mean {mean_pts:.0f} input pts, "
                                    f"{S} slots), single+multi BEV, device-resident",
-                       "frames_per_gpu": F, "sub_batch": args.sub_batch, "sensor": args.sensor,
+                       "frames_per_gpu": F, "frames_per_step": F * world, "sub_batch": args.sub_batch, "sensor": args.sensor,
                        "algorithmic_bytes_per_frame": b_frame, "parallelism": f"frames x{world}"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": kernels,
+            "kernels_pipelined": kernels_pipelined,
             "gen_seconds": t_gen,
         }
         print(json.dumps(out))

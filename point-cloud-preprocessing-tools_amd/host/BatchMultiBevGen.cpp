@@ -237,20 +237,32 @@ std::pair<int, int> getBelongingGrid(const pcl::PointCloud<PointType>::Ptr &clou
 
 /* ------------------------------------------------------------------------ */
 BatchMultiBevGen::BatchMultiBevGen(const std::string &keyframes_root_dir, const std::string &sensor_type, int device,
-                                   int batch_frames)
+                                   int batch_frames, std::size_t max_points)
     : root_(keyframes_root_dir), batch_frames_(std::max(1, batch_frames))
 {
     if (root_.empty() || root_.back() != '/') root_ += "/";
     params_ = getSensorParams(parseSensorType(sensor_type));
     if (params_.N_SCAN <= 0) return;
+    device_ = device;
+    initial_max_points_ = std::max<std::size_t>(1, max_points);
+    (void)createContext(initial_max_points_);
+}
+
+/* (re)creates the GPU context for clouds of up to max_points input points */
+bool BatchMultiBevGen::createContext(std::size_t max_points)
+{
+    if (ctx_) bev_destroy(ctx_);
+    ctx_ = nullptr;
     bev_params_t bp = to_bev_params(params_);
     bev_ctx_t *c = nullptr;
-    const int rc = bev_create(&c, device, &bp, batch_frames_, (size_t)4 << 20);
+    const int rc = bev_create(&c, device_, &bp, batch_frames_, max_points);
     if (rc != BEV_OK) {
         std::cerr << "bev_create failed: " << bev_strerror(rc) << "\n";
-        return;
+        return false;
     }
     ctx_ = c;
+    max_points_ = max_points;
+    return true;
 }
 
 BatchMultiBevGen::~BatchMultiBevGen()
@@ -322,21 +334,48 @@ double BatchMultiBevGen::processFiles(const std::vector<std::string> &files, std
             const size_t end = fn.find_last_of('.');
             names[i] = fn.substr(start, end - start);
         }
+        /* a cloud larger than the context was created for: grow the context instead of dropping the batch (the
+         * reference processes every file whatever its size) */
+        uint32_t largest = 0;
+        for (int i = 0; i < nb; ++i) largest = std::max(largest, npts[i]);
+        if ((std::size_t)largest > max_points_) {
+            std::size_t want = max_points_;
+            while (want < (std::size_t)largest) want *= 2;
+            if (!createContext(std::min<std::size_t>(want, 0xfffffffeull))) {
+                failed_frames_ += (std::size_t)nb;
+                (void)createContext(initial_max_points_);
+                if (!ctx_) return timed_ms;
+                continue;
+            }
+        }
         const auto t0 = std::chrono::steady_clock::now();
-        const int rc = bev_process_batch(ctx_, nb, pts.data(), npts.data(), ord.data(), mo.data(), so.data(), nullptr);
+        std::vector<char> done(nb, 1);
+        int rc = bev_process_batch(ctx_, nb, pts.data(), npts.data(), ord.data(), mo.data(), so.data(), nullptr);
         if (rc != BEV_OK) {
-            std::cerr << "bev_process_batch failed: " << bev_strerror(rc) << " " << bev_last_error(ctx_) << "\n";
-            continue;
+            /* one bad frame must not take the other frames of its batch with it: retry frame by frame, count what
+             * still fails; main() exits non-zero when anything failed */
+            std::cerr << "bev_process_batch failed: " << bev_strerror(rc) << " " << bev_last_error(ctx_)
+                      << "; retrying the batch frame by frame\n";
+            for (int i = 0; i < nb; ++i) {
+                rc = bev_process_batch(ctx_, 1, &pts[i], &npts[i], &ord[i], &mo[i], &so[i], nullptr);
+                if (rc != BEV_OK) {
+                    std::cerr << "Failed to process " << files[b0 + i] << ": " << bev_strerror(rc) << " " << bev_last_error(ctx_) << "\n";
+                    done[i] = 0;
+                    ++failed_frames_;
+                }
+            }
         }
         if (verbose)
-            for (int i = 0; i < nb; ++i) std::cout << "Converting file: " << names[i] << "\n"; /* :744 */
+            for (int i = 0; i < nb; ++i)
+                if (done[i]) std::cout << "Converting file: " << names[i] << "\n"; /* :744 */
         parallel_frames(nb, [&](int i) {
+            if (!done[i]) return;
             write_multi_outputs(names[i], multi[i].data(), write_png);
             write_single_outputs(names[i], single[i].data(), write_png);
         });
         timed_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         parallel_frames(nb, [&](int i) { /* :755-756: the labelled (not filtered) ordered cloud */
-            bevio::savePCDFileBinary(non_ground_dir + names[i] + ".pcd", ordered[i]);
+            if (done[i]) bevio::savePCDFileBinary(non_ground_dir + names[i] + ".pcd", ordered[i]);
         });
     }
     return timed_ms;

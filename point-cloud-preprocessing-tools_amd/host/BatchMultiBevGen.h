@@ -43,8 +43,9 @@ void shutdownBev();
 class BatchMultiBevGen {
 public:
     /* sensor_type as on the command line ("HDL_32E", "HDL_64E", "OS1_64") */
+    /* max_points: input points per cloud the GPU context is sized for at first; a larger cloud makes the context grow */
     BatchMultiBevGen(const std::string &keyframes_root_dir, const std::string &sensor_type, int device = 0,
-                     int batch_frames = 32);
+                     int batch_frames = 32, std::size_t max_points = (std::size_t)4 << 20);
     ~BatchMultiBevGen();
     BatchMultiBevGen(const BatchMultiBevGen &) = delete;
     BatchMultiBevGen &operator=(const BatchMultiBevGen &) = delete;
@@ -57,9 +58,16 @@ public:
      * writes; PCD load/save excluded, :732-752). */
     double processFiles(const std::vector<std::string> &files, std::size_t first, std::size_t count,
                         bool write_png = true, bool verbose = true);
+    /* frames whose outputs are missing because the GPU path failed on them (after a frame-by-frame retry of their
+     * batch); the tool exits non-zero when this is not 0 */
+    std::size_t failedFrames() const { return failed_frames_; }
 
 private:
+    bool createContext(std::size_t max_points);
     struct bev_ctx *ctx_ = nullptr;
+    int device_ = 0;
+    std::size_t max_points_ = 0, initial_max_points_ = 0;
+    std::size_t failed_frames_ = 0;
     SensorParams params_{};
     std::string root_;
     int batch_frames_;

@@ -7,6 +7,8 @@
  *   BEV_DEVICES=N   use GPUs 0..N-1 of this node (one host thread + one context
  *                   per GPU, contiguous shards of the sorted file list)
  *   BEV_BATCH=B     frames per bev_process_batch call (default 32)
+ *   BEV_MAX_POINTS=P input points per cloud the GPU contexts are sized for at first (default 4 Mi; larger clouds make
+ *                   a context grow)
  *   BEV_NO_PNG=1    skip the 25 PNG files per frame
  *   BEV_IO_THREADS=T host threads sharing the per-frame file work of a batch (PCD parse, PNG, CSV, PCD write; default 16)
  */
@@ -57,12 +59,15 @@ int main(int argc, char **argv)
     const int n_dev = std::max(1, std::atoi(std::getenv("BEV_DEVICES") ? std::getenv("BEV_DEVICES") : "1"));
     const int batch = std::max(1, std::atoi(std::getenv("BEV_BATCH") ? std::getenv("BEV_BATCH") : "32"));
     const bool png = std::getenv("BEV_NO_PNG") == nullptr;
+    const long long max_pts_env = std::getenv("BEV_MAX_POINTS") ? std::atoll(std::getenv("BEV_MAX_POINTS")) : 0;
+    const size_t max_pts = max_pts_env > 0 ? (size_t)max_pts_env : ((size_t)4 << 20);
 
     /* Step 1: frames are independent -> contiguous shards of the sorted list, one GPU each.  GPU 0 owns
      * the frame-range table; the other GPUs get it by an RCCL broadcast (over xGMI on a multi-GPU node) —
      * the only inter-GPU communication of the whole tool. */
     std::vector<double> ms(n_dev, 0.0);
     std::vector<int> bad(n_dev, 0);
+    std::vector<size_t> failed(n_dev, 0);
     std::vector<std::thread> workers;
     const size_t F = files.size();
     std::vector<int64_t> ranges(2 * (size_t)n_dev, 0);
@@ -109,14 +114,17 @@ int main(int argc, char **argv)
     for (int d = 0; d < n_dev; ++d) {
         const size_t first = (size_t)ranges[2 * d], count = (size_t)ranges[2 * d + 1];
         workers.emplace_back([&, d, first, count]() {
-            BatchMultiBevGen gen(root, argv[2], d, batch);
+            BatchMultiBevGen gen(root, argv[2], d, batch, max_pts);
             if (!gen.ok()) { bad[d] = 1; return; }
             ms[d] = gen.processFiles(files, first, count, png, n_dev == 1);
+            failed[d] = gen.failedFrames();
         });
     }
     for (auto &w : workers) w.join();
     for (int d = 0; d < n_dev; ++d)
         if (bad[d]) return 1;
+    size_t n_failed = 0;
+    for (size_t v : failed) n_failed += v;
     double total_ms = 0;
     for (double v : ms) total_ms += v;
     std::cout << "[TIME] Average preprocessing and BEV generation: " << (F ? total_ms / (double)F : 0.0) << "\n";
@@ -132,6 +140,10 @@ int main(int argc, char **argv)
     std::vector<int32_t> major = selectMajorFrames(poses);
     std::vector<LabelType> labels = getKeyFrameLabel(poses, major);
     if (!saveLabels(labels, label_file)) return 1;
+    if (n_failed) { /* outputs of those frames are missing: not a success, whatever else was written */
+        std::cerr << n_failed << " of " << F << " frames failed on the GPU path\n";
+        return 1;
+    }
     std::cout << "Done. " << std::endl;
     return 0;
 }

@@ -3,10 +3,12 @@
    <prefix>_bench_under_rocprof.json  bench.py line of that profiled run
    <prefix>_bench.json                bench.py line of the unprofiled default run (with the CPU baseline)
    <prefix>_pmc_traffic.json          per-kernel HBM bytes from the PMC passes (gfx950 corrections applied)
-usage: python scripts/make_profiles.py gpurun_out/<tag> profiles/<prefix>"""
+   <prefix>_<workload>_bench.json / _kernel_stats.csv   the same for BASELINE configs 3 and 5 when present
+usage: python scripts/make_profiles.py gpurun_out/<tag> profiles/<prefix> [frame passes of a PMC run, default 2000]"""
 import collections, csv, glob, json, os, shutil, sys
 
 src, prefix = sys.argv[1], sys.argv[2]
+pmc_frames = int(sys.argv[3]) if len(sys.argv) > 3 else 2000  # bench.py --frames 1000 --steps 1 --warmup 1
 
 
 def last_json_line(path):
@@ -25,6 +27,15 @@ for name, out in (("bench_under_rocprof.log", "_bench_under_rocprof.json"), ("be
     if os.path.exists(p):
         json.dump(last_json_line(p), open(prefix + out, "w"), indent=1)
 
+for wl in ("os1_firing", "oxford_concat"):
+    st = glob.glob(os.path.join(src, "trace_" + wl, "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        shutil.copy(st[0], f"{prefix}_{wl}_kernel_stats.csv")
+    for name, out in ((f"bench_under_rocprof_{wl}.log", f"_{wl}_bench_under_rocprof.json"), (f"bench_{wl}.log", f"_{wl}_bench.json")):
+        p = os.path.join(src, name)
+        if os.path.exists(p):
+            json.dump(last_json_line(p), open(prefix + out, "w"), indent=1)
+
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
@@ -34,22 +45,24 @@ for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), r
             continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k][r["Counter_Name"]] += 1
-frames = 256
-out = {"source": "rocprofv3 --pmc (one counter group per run), bench.py --frames 256 --sub-batch 256, BEV_LANES=1; "
-                 "per-launch means",
-       "frames_per_launch": frames,
+out = {"source": "rocprofv3 --pmc (one counter group per run) of `bench.py --steps 1 --warmup 1` (the 1000-frame workload, "
+                 f"sub-batch 256, BEV_LANES=1): counters summed over all dispatches of a kernel / {pmc_frames} frame passes",
+       "frame_passes": pmc_frames,
        "corrections": "FETCH_SIZE is reported in KiB and counts 128-B requests as 64 B on gfx950 (MI355X_MICROARCH.md, "
                       "HBM): hbm_read_bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE KiB is exact",
        "kernels": {}}
 total = 0.0
 for k in sorted(agg):
-    m = {c: agg[k][c] / cnt[k][c] for c in agg[k]}
-    e = {}
+    m = {c: agg[k][c] / cnt[k][c] for c in agg[k]}   # per-dispatch means
+    tot = {c: agg[k][c] for c in agg[k]}               # sums over the run
+    e = {"dispatches": max(cnt[k].values())}
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         e["hbm_read_bytes_per_launch"] = 2 * m["FETCH_SIZE"] * 1024
         e["hbm_write_bytes_per_launch"] = m["WRITE_SIZE"] * 1024
         e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
-        e["hbm_bytes_per_frame"] = e["hbm_bytes_per_launch"] / frames
+        e["hbm_bytes_per_frame"] = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / pmc_frames
+        e["hbm_read_bytes_per_frame"] = 2 * tot["FETCH_SIZE"] * 1024 / pmc_frames
+        e["hbm_write_bytes_per_frame"] = tot["WRITE_SIZE"] * 1024 / pmc_frames
         e["FETCH_SIZE_KiB_raw"], e["WRITE_SIZE_KiB"] = m["FETCH_SIZE"], m["WRITE_SIZE"]
         if "fillBuffer" in k:
             e["note"] = "one-time clear of a winner table at context creation, not part of a step"

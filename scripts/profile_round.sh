@@ -1,18 +1,36 @@
-# usage (on the GPU box): bash scripts/profile_round.sh <tag>   -> gpurun_out/<tag>/...
+# usage (on the GPU box): bash scripts/profile_round.sh <tag> [pmc] [others]   -> gpurun_out/<tag>/...
+#   default : plain bench line (with CPU baseline) + rocprofv3 kernel trace/stats of the same command with one lane
+#   pmc     : + the PMC passes (one counter group per run) on the SAME 1000-frame workload
+#   others  : + bench line and kernel stats of BASELINE configs 3 (os1_firing) and 5 (oxford_concat)
+# The libraries are built ONCE up front; every profiled command is `rocprofv3 ... -- python3 bench.py --no-build`, so
+# nothing is spawned from a process the profiler has already attached to the GPU.
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
-TAG=${1:-r01}
+TAG=${1:-r02}; shift
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
+python3 -c "import __graft_entry__ as g; g.build()" || exit 1
 # 1. plain bench first (with the CPU baseline): the GPU slows down by 5-10 % once the profiled runs have warmed it up
-timeout 900 python3 bench.py --steps 5 --warmup 2 > $OUT/bench.log 2>&1
+timeout 900 python3 bench.py --no-build --steps 20 --warmup 5 > $OUT/bench.log 2>$OUT/bench.err || exit 1
+tail -c 600 $OUT/bench.log
 # 2. kernel trace + stats of the bench command line with ONE lane (BEV_LANES=1): every launch runs back to back, like in
 #    bench.py's roofline pass, so AverageNs is comparable with roofline.avg_launch_ms
-BEV_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu > $OUT/bench_under_rocprof.log 2>&1
-# 3. PMC passes, one counter group per run (no trace domains mixed in)
-ARGS="bench.py --steps 1 --warmup 1 --no-cpu --no-profile --frames 256 --sub-batch 256"
+BEV_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-build --steps 5 --warmup 2 --no-cpu > $OUT/bench_under_rocprof.log 2>$OUT/bench_under_rocprof.err || exit 1
+for w in "$@"; do
+if [ "$w" = pmc ]; then
+# 3. PMC passes, one counter group per run (no trace domains mixed in); 1 warm-up + 1 step = 2000 frame passes
+ARGS="bench.py --no-build --steps 1 --warmup 1 --no-cpu --no-profile"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU"; do
   i=$((i+1))
-  BEV_LANES=1 timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -- python3 $ARGS > $OUT/pmc$i.log 2>&1
+  BEV_LANES=1 timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -- python3 $ARGS > $OUT/pmc$i.log 2>&1 || exit 1
 done
-tail -1 $OUT/bench.log
+fi
+if [ "$w" = others ]; then
+for wl in os1_firing oxford_concat; do
+  F=1000; if [ $wl = oxford_concat ]; then F=100; fi
+  timeout 900 python3 bench.py --no-build --steps 5 --warmup 2 --workload $wl --frames $F --cpu-sample 50 > $OUT/bench_$wl.log 2>$OUT/bench_$wl.err || exit 1
+  BEV_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -- python3 bench.py --no-build --steps 3 --warmup 1 --no-cpu --workload $wl --frames $F > $OUT/bench_under_rocprof_$wl.log 2>&1 || exit 1
+done
+fi
+done
+echo profile_round done

@@ -121,3 +121,53 @@ def test_cli_usage_and_unknown_sensor(tmp_path):
     (tmp_path / "keyframe_point_cloud").mkdir()
     r = subprocess.run([str(CLI), str(tmp_path), "VLP_16"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "Unknown sensor type" in r.stderr
+
+
+def _make_dataset(root, p, n):
+    (root / "keyframe_point_cloud").mkdir(parents=True)
+    for i in range(n):
+        pcd_util.write_pcd_binary(root / "keyframe_point_cloud" / f"{i:06d}.pcd", synth.sweep(p, 300 + i, keep=0.9, n_dup=700))
+    (root / "keyframe_pose.csv").write_text("\n".join(_pose_line(i, 7.0 * i, 0.5 * i, 0.0, 0.01 * i) for i in range(n)) + "\n")
+
+
+def _tree(root):
+    """relative path -> bytes of every file the tool wrote"""
+    return {str(f.relative_to(root)): f.read_bytes() for f in sorted(root.rglob("*"))
+            if f.is_file() and "keyframe_point_cloud" not in f.parts and f.name != "keyframe_pose.csv"}
+
+
+def test_cli_context_grows_for_clouds_larger_than_its_first_size(tmp_path):
+    """A cloud with more points than the context was sized for makes the context grow; no frame is dropped and the
+    outputs do not depend on the starting size (the reference processes every file whatever its size)."""
+    import os
+    p = bev_amd.params_for_sensor("HDL_32E")
+    a, b = tmp_path / "a", tmp_path / "b"
+    _make_dataset(a, p, 5)
+    _make_dataset(b, p, 5)
+    env = dict(os.environ, BEV_NO_PNG="1", BEV_BATCH="2")
+    ra = subprocess.run([str(CLI), str(a), "HDL_32E"], capture_output=True, text=True, timeout=300, env=env)
+    rb = subprocess.run([str(CLI), str(b), "HDL_32E"], capture_output=True, text=True, timeout=300,
+                        env=dict(env, BEV_MAX_POINTS="1000"))
+    assert ra.returncode == 0 and rb.returncode == 0, ra.stderr + rb.stderr
+    ta, tb = _tree(a), _tree(b)
+    assert len(ta) == 5 * 3 + 1 and ta.keys() == tb.keys()
+    assert all(ta[k] == tb[k] for k in ta), [k for k in ta if ta[k] != tb[k]][:4]
+
+
+def test_cli_two_gpus_write_the_same_tree_as_one(tmp_path):
+    """BEV_DEVICES=2: contiguous shards of the sorted file list, one host thread + context per GPU, the frame-range
+    table broadcast by RCCL (BatchMultiBevGen.cpp:727-757: iterations are independent) -> byte-identical output tree."""
+    import os
+    torch = pytest.importorskip("torch")
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs 2 GPUs, this box shows {torch.cuda.device_count()} (the 1-GPU path of the same code runs in test_cli_end_to_end)")
+    p = bev_amd.params_for_sensor("HDL_32E")
+    a, b = tmp_path / "one", tmp_path / "two"
+    _make_dataset(a, p, 9)
+    _make_dataset(b, p, 9)
+    env = dict(os.environ, BEV_BATCH="2")
+    ra = subprocess.run([str(CLI), str(a), "HDL_32E"], capture_output=True, text=True, timeout=300, env=env)
+    rb = subprocess.run([str(CLI), str(b), "HDL_32E"], capture_output=True, text=True, timeout=300, env=dict(env, BEV_DEVICES="2"))
+    assert ra.returncode == 0 and rb.returncode == 0, ra.stderr + rb.stderr
+    ta, tb = _tree(a), _tree(b)
+    assert ta.keys() == tb.keys() and all(ta[k] == tb[k] for k in ta), [k for k in ta if ta.get(k) != tb.get(k)][:4]
