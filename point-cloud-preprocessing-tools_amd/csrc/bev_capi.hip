@@ -44,13 +44,10 @@ struct Lane {
     hipEvent_t front_done = nullptr, back_done = nullptr; /* staged mode: workspace hand-over between the two stages */
     uint32_t *winner = nullptr;
     uint32_t win_gen = 0; /* generation tag of the last sub-batch that used this set's winner table */
-    uint32_t *codes = nullptr;
-    uint16_t *cand_cell = nullptr;
+    uint32_t *cand_key = nullptr;
     float *cand_z = nullptr;
-    uint2 *cand_aux = nullptr;
-    uint16_t *cand_cellp = nullptr;
     uint32_t *ncand = nullptr;
-    float *zsorted = nullptr;
+    uint32_t *code_main = nullptr, *ncode = nullptr; /* per-(strip, band) lists of final BEV codes */
     float *avg = nullptr;
     int8_t *gm = nullptr; /* lazily allocated */
 };
@@ -163,13 +160,18 @@ void fill_geometry(const bev_params_t *p, Geometry *g)
     g->tiles = (g->S + kTile - 1) / kTile;
     g->strips = (g->H + kStripCols - 1) / kStripCols;
     g->segs = (g->G + 1) * g->strips;
+    g->parts = (g->segs + kPartSegs - 1) / kPartSegs;
     g->raster_bands = raster_bands_for(mat_size_of(p));
+    g->band_rows = g->raster_bands ? mat_size_of(p) / g->raster_bands : 0;
+    g->code_cap = (uint32_t)g->N * (uint32_t)kStripCols;
     g->rp.max_range_f = (float)p->max_range;
     g->rp.interval = p->interval;
     g->rp.height_res = p->height_res;
     g->rp.lidar_to_ground = p->lidar_to_ground;
     g->rp.mat_size = mat_size_of(p);
     g->rp.n_layers = p->n_layers;
+    g->rp.band_rows = g->band_rows;
+    g->rp.bands = g->raster_bands;
 }
 
 /* ---- profiling -------------------------------------------------------- */
@@ -301,13 +303,11 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.winner = ln.winner;
         b.win_shift = c->win_shift;
         b.ordered = d_ordered + (size_t)f0 * S;
-        b.codes = ln.codes;
-        b.cand_cell = ln.cand_cell;
+        b.cand_key = ln.cand_key;
         b.cand_z = ln.cand_z;
-        b.cand_aux = ln.cand_aux;
-        b.cand_cellp = ln.cand_cellp;
         b.ncand = ln.ncand;
-        b.zsorted = ln.zsorted;
+        b.code_main = ln.code_main;
+        b.ncode = ln.ncode;
         b.avg = ln.avg;
         b.gm = d_gm ? ln.gm : nullptr;
         b.multi = d_multi ? d_multi + (size_t)f0 * c->multi_bytes : nullptr;
@@ -357,18 +357,13 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             ProfScope ps(c, K_CELL_SUMS, nb, st);
             launch_cell_sums(g, b, nb, st);
         }
-        {
-            ProfScope ps(c, K_GROUND_RESOLVE, nb, st);
-            launch_ground_resolve(g, b, nb, st);
-        }
         if (d_gm) {
             ProfScope ps(c, K_GROUND_MAT, nb, st);
             launch_ground_mat(g, b, d_gm + (size_t)f0 * S, nb, st);
         }
-        if (d_multi || d_single) {
+        {   /* phase C for the candidates (labels) + both rasters */
             ProfScope ps(c, K_BEV_RASTER, nb, st);
-            launch_bev_raster(g, ln.codes, S, (uint32_t)S, b.multi, b.single, d_multi != nullptr,
-                              d_single != nullptr, nb, st);
+            launch_bev_raster(g, b, d_multi != nullptr, d_single != nullptr, nb, identity, st);
         }
         HIPCK(c, hipEventRecord(ln.back_done, st));
         c->last_sub_frames = nb;
@@ -505,7 +500,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipEventCreateWithFlags(&c->desc_done[k], hipEventDisableTiming));
     }
     const size_t S = (size_t)c->geo.S, nb = (size_t)max_batch;
-    c->codes_elems = std::max(nb * S, std::max(max_points, S));
+    c->codes_elems = std::max(std::max(max_points, S), (size_t)1024 * 1024); /* dense codes of one cloud, or the float BEV grid */
     {
         const char *e = getenv("BEV_LANES");
         int nl = e ? atoi(e) : 2;
@@ -532,17 +527,15 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipEventCreateWithFlags(&ln.back_done, hipEventDisableTiming));
         CK(hipMalloc((void **)&ln.winner, nb * S * sizeof(uint32_t)));
         CK(hipMemset(ln.winner, 0, nb * S * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.codes, c->codes_elems * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.cand_cell, nb * (size_t)c->geo.segs * kSeg * sizeof(uint16_t)));
+        CK(hipMalloc((void **)&ln.cand_key, nb * (size_t)c->geo.segs * kSeg * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.cand_z, nb * (size_t)c->geo.segs * kSeg * sizeof(float)));
-        CK(hipMalloc((void **)&ln.cand_aux, nb * (size_t)c->geo.segs * kSeg * sizeof(uint2)));
-        CK(hipMalloc((void **)&ln.cand_cellp, nb * (size_t)c->geo.segs * kSeg * sizeof(uint16_t)));
         CK(hipMalloc((void **)&ln.ncand, nb * (size_t)c->geo.segs * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.zsorted, nb * S * sizeof(float)));
+        CK(hipMalloc((void **)&ln.code_main, nb * (size_t)c->geo.strips * c->geo.raster_bands * c->geo.code_cap * sizeof(uint32_t)));
+        CK(hipMalloc((void **)&ln.ncode, nb * (size_t)c->geo.strips * c->geo.raster_bands * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.avg, nb * (size_t)bevx::kGridCells * sizeof(float)));
     }
     c->winner = c->lanes[0].winner;
-    c->codes = c->lanes[0].codes;
+    CK(hipMalloc((void **)&c->codes, c->codes_elems * sizeof(uint32_t))); /* single-cloud entry points */
     /* >64 KiB dynamic LDS needs an explicit opt-in per kernel */
     CK(configure_kernels(c->geo));
     c->prof_pool.resize(kEventPairs);
@@ -564,7 +557,7 @@ void bev_destroy(bev_ctx_t *c)
     for (int l = 0; l < kMaxLanes; ++l) {
         Lane &ln = c->lanes[l];
         if (ln.st) (void)hipStreamSynchronize(ln.st);
-        void *ws[] = {ln.winner, ln.codes, ln.cand_cell, ln.cand_z, ln.cand_aux, ln.cand_cellp, ln.ncand, ln.zsorted, ln.avg, ln.gm};
+        void *ws[] = {ln.winner, ln.cand_key, ln.cand_z, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
         for (void *p : ws)
             if (p) (void)hipFree(p);
         if (ln.done) (void)hipEventDestroy(ln.done);
@@ -577,7 +570,7 @@ void bev_destroy(bev_ctx_t *c)
     if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     for (auto e : c->out_ready)
         if (e) (void)hipEventDestroy(e);
-    void *dev[] = {c->st_in, c->st_ordered, c->st_multi, c->st_single, c->st_gm, c->kitti_buf};
+    void *dev[] = {c->st_in, c->st_ordered, c->st_multi, c->st_single, c->st_gm, c->kitti_buf, c->codes};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     for (int k = 0; k < kDescRing; ++k) {
@@ -852,8 +845,8 @@ static int raster_cloud(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, uint
     }
     {
         ProfScope ps(c, K_BEV_RASTER, 1);
-        launch_bev_raster(c->geo, c->codes, 0, n, c->st_multi, c->st_single, multi_out != nullptr,
-                          single_out != nullptr, 1, c->stream);
+        launch_bev_raster_dense(c->geo, c->codes, n, multi_out ? c->st_multi : nullptr, single_out ? c->st_single : nullptr,
+                                c->stream);
     }
     HIPCK(c, hipGetLastError());
     if (multi_out) HIPCK(c, hipMemcpyAsync(multi_out, c->st_multi, c->multi_bytes, hipMemcpyDeviceToHost, c->stream));
@@ -967,7 +960,7 @@ int bev_float_bev(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, float inte
     const size_t M = bev_float_bev_size(interval);
     if (M == 0) return BEV_ERR_UNSUPPORTED;
     if ((size_t)n > std::max(c->max_points, (size_t)c->geo.S)) return BEV_ERR_TOO_LARGE;
-    if (M * M > c->codes_elems) return BEV_ERR_UNSUPPORTED; /* the grid borrows lane 0's code buffer */
+    if (M * M > c->codes_elems) return BEV_ERR_UNSUPPORTED; /* the grid borrows the single-cloud code buffer */
     HIPCK(c, hipSetDevice(c->device));
     int rc = ensure_staging(c);
     if (rc != BEV_OK) return rc;

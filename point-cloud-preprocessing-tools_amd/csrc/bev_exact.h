@@ -145,6 +145,8 @@ struct RasterParams {
     float lidar_to_ground; /* :269 */
     int mat_size;        /* :267 */
     int n_layers;        /* :268 */
+    int band_rows;       /* x bins per raster band (mat_size / bands): how the rasters are cut into workgroups, not part of the result */
+    int bands;
 };
 
 /* (int)round((double)v + 0.5), half away from zero, without doubles.  d = v + 0.5 in double:
@@ -172,22 +174,85 @@ BEVX_HD int height_times4(float t)
     return (u >= -2147483648.0f && u < 2147483648.0f) ? (int)u : kIntMin;
 }
 
-BEVX_HD uint32_t bev_code(float px, float py, float pz, int label, const RasterParams &rp)
+/* the part of the code that depends on the height only (layer, clamped height), for bins already known to be in range */
+BEVX_HD uint32_t bev_code_from_bins(int x, int y, float pz, const RasterParams &rp)
 {
-    if (label == 0) return kSkip;                                      /* :285, :349 */
-    int x = bev_bin(px, rp.max_range_f, rp.interval);                  /* :279, :343 */
-    int y = bev_bin(py, rp.max_range_f, rp.interval);                  /* :280, :344 */
-    if (x < 0 || x >= rp.mat_size || y < 0 || y >= rp.mat_size) return kSkip;
     int layer = cvtt_f32(roundf(pz / rp.height_res + rp.lidar_to_ground)); /* :281 */
     int h = height_times4(pz + rp.lidar_to_ground);                    /* :345 */
     h = h < 0 ? 0 : (h > 255 ? 255 : h);                               /* :346 */
     uint32_t l = (layer >= 0 && layer < rp.n_layers) ? (uint32_t)layer : kNoLayer;
     return (uint32_t)x | ((uint32_t)y << 9) | ((uint32_t)h << 18) | (l << 26);
 }
+BEVX_HD uint32_t bev_code(float px, float py, float pz, int label, const RasterParams &rp)
+{
+    if (label == 0) return kSkip;                                      /* :285, :349 */
+    int x = bev_bin(px, rp.max_range_f, rp.interval);                  /* :279, :343 */
+    int y = bev_bin(py, rp.max_range_f, rp.interval);                  /* :280, :344 */
+    if (x < 0 || x >= rp.mat_size || y < 0 || y >= rp.mat_size) return kSkip;
+    return bev_code_from_bins(x, y, pz, rp);
+}
 BEVX_HD int code_x(uint32_t c) { return (int)(c & 511u); }
 BEVX_HD int code_y(uint32_t c) { return (int)((c >> 9) & 511u); }
 BEVX_HD int code_h(uint32_t c) { return (int)((c >> 18) & 255u); }
 BEVX_HD uint32_t code_layer(uint32_t c) { return (c >> 26) & 31u; }
+
+/* ---------------------------------------------------------------------------
+ * Candidate key.  A "candidate" is a slot that phase A marked ground_mat == 1 (BatchMultiBevGen.cpp:180-181): the only
+ * slots whose label — and with it their BEV contribution — depends on the per-cell averages (:236-246).  The column
+ * walk hands each one to the later kernels as 8 bytes: its height (float, summed by phase B) and this key:
+ *   bits  0..11  getBelongingGrid cell, row * 50 + col                      (phase B, phase C)
+ *   bits 12..19  column offset of the slot inside its strip                 (phase C: where to patch the label)
+ *   bit  20      the walk's guess that phase C un-grounds it (the point was written with its own label)
+ *   bits 21..22  x bin of the point's BEV code minus the x bin of its cell's lower edge, 0..2;  3 = "escape"
+ *   bits 23..24  the same for y                                             (3 in either: read the point instead)
+ *   bit  25      the point has no BEV code whatever phase C says (label 0 on input, or outside the raster)
+ *   bit  26      the point's input label is -2 (what every producer writes, MulranPointCloudSelect.cpp:126): phase C
+ *                can put it back without fetching the input point
+ *   bits 27..30  owner: the raster band (x band of the BEV images) whose workgroup tests this candidate in phase C —
+ *                the band its code falls into, so that the workgroup can rasterise it into its own planes; candidates
+ *                without a code are dealt out by cell row; 15 = escape: every band's workgroup looks at the point
+ * A 2 m cell spans two or three 1 m bins, so together with the height the key reproduces the point's whole code
+ * (layer and clamped height are functions of z alone).  Encoding and decoding are exact inverses by construction —
+ * no assumption that the float roundings of x + 75 and x + 112 agree: when they do not, or the cell was clamped, the
+ * difference is out of range and the escape value is stored.
+ * ------------------------------------------------------------------------- */
+constexpr uint32_t kKeyCellMask = 0x0fffu;
+constexpr int kKeyColShift = 12;
+constexpr uint32_t kKeyPredBit = 1u << 20;
+constexpr int kKeyDxShift = 21, kKeyDyShift = 23;
+constexpr uint32_t kKeyNoCodeBit = 1u << 25;
+constexpr uint32_t kKeyLabelM2Bit = 1u << 26;
+constexpr uint32_t kKeyEscape = 3u;
+constexpr int kKeyOwnerShift = 27;
+constexpr uint32_t kKeyOwnerAll = 15u;
+
+/* BEV bin of the lower edge of ground-grid row / column s (the edge is 2 * s - offset, exact in float) */
+BEVX_HD int cell_edge_bin(int s, float grid_offset, const RasterParams &rp)
+{
+    return bev_bin((float)(2 * s) - grid_offset, rp.max_range_f, rp.interval);
+}
+BEVX_HD uint32_t candidate_key(int cell, int col_in_strip, bool pred, uint32_t code, int label, const RasterParams &rp)
+{
+    uint32_t key = (uint32_t)cell | ((uint32_t)col_in_strip << kKeyColShift) | (pred ? kKeyPredBit : 0u) |
+                   (label == -2 ? kKeyLabelM2Bit : 0u);
+    if (code == kSkip) /* only its label can change: any one band will do */
+        return key | kKeyNoCodeBit | ((uint32_t)((cell / kGridCols) * rp.bands / kGridRows) << kKeyOwnerShift);
+    const int dx = (int)(code & 511u) - cell_edge_bin(cell / kGridCols, 75.0f, rp);
+    const int dy = (int)((code >> 9) & 511u) - cell_edge_bin(cell % kGridCols, 50.0f, rp);
+    const bool ok = dx >= 0 && dx < (int)kKeyEscape && dy >= 0 && dy < (int)kKeyEscape;
+    const uint32_t owner = ok ? (code & 511u) / (uint32_t)rp.band_rows : kKeyOwnerAll;
+    return key | ((ok ? (uint32_t)dx : kKeyEscape) << kKeyDxShift) | ((ok ? (uint32_t)dy : kKeyEscape) << kKeyDyShift) |
+           (owner << kKeyOwnerShift);
+}
+/* the code of a candidate whose key is not an escape and has no kKeyNoCodeBit */
+BEVX_HD uint32_t candidate_code(uint32_t key, float z, const RasterParams &rp)
+{
+    const int cell = (int)(key & kKeyCellMask);
+    const int x = cell_edge_bin(cell / kGridCols, 75.0f, rp) + (int)((key >> kKeyDxShift) & 3u);
+    const int y = cell_edge_bin(cell % kGridCols, 50.0f, rp) + (int)((key >> kKeyDyShift) & 3u);
+    return bev_code_from_bins(x, y, z, rp);
+}
+BEVX_HD bool candidate_key_escapes(uint32_t key) { return ((key >> kKeyDxShift) & 3u) == kKeyEscape; }
 
 /* ---------------------------------------------------------------------------
  * Phase A per slot.  `fetch(flat_index)` returns (x, y, z, intensity) of the

@@ -22,10 +22,14 @@ constexpr int kStripThreads = 256;              /* column-walk workgroup: 252 co
 constexpr int kStripCols = kStripThreads - 4;
 constexpr int kSeg = 256;                       /* capacity of one candidate segment = one (row, strip) */
 constexpr int kMaxSegs = 1024;                  /* (G + 1) * strips must not exceed this (bev_create checks) */
-constexpr int kSumWaves = 8;      /* waves of the per-frame cell-sum workgroup */
+constexpr int kSumWaves = 4;      /* waves of the per-frame cell-sum workgroup: the size of a column-walk workgroup */
 constexpr int kSumThreads = kSumWaves * 64;
-constexpr int kRasterThreads = 1024;
-constexpr int kRasterSplit = 4;   /* x-bands per frame in the raster kernel at the reference's 224 x 224 (see raster_bands_for) */
+constexpr int kSegsPerWave = 4;                              /* segments a wave keeps in registers per part */
+constexpr int kPartSegs = kSumWaves * kSegsPerWave;          /* segments per part: 16 (4,096 candidates at most) */
+constexpr int kRasterThreads = 512;
+constexpr int kRasterSplit = 8;   /* x-bands per frame in the raster kernel at the reference's 224 x 224 (see raster_bands_for) */
+constexpr int kMaxBands = 16;     /* raster_bands_for never returns more */
+constexpr int kMaxStrips = 264;   /* ceil(65535 / kStripCols) rounded up */
 
 /* per-frame launch metadata, copied H2D once per sub-batch */
 struct FrameDesc {
@@ -34,22 +38,16 @@ struct FrameDesc {
     uint32_t _pad;
 };
 
-/* A "candidate" is a slot that phase A marked ground_mat == 1: the only slots whose
- * label depends on the per-cell averages (BatchMultiBevGen.cpp:244-246).  Stored as
- * three parallel arrays per (row, strip) segment so that the per-cell sum kernel reads
- * 2 (cell) resp. 6 (cell + z) bytes per candidate instead of a 16-byte record:
- *   cand_cell u16 : getBelongingGrid cell, row * 50 + col
- *   cand_cellp u16: the same cell | kCandPredBit if the walk wrote the point with its own label / code (its guess that
- *                   phase C un-grounds it).  A second array because the per-cell sum kernel must not pay for a mask:
- *                   with the bit inside cand_cell the compiler interleaved that kernel's batched loads with its
- *                   scattered stores (in-order vmcnt) and the kernel took 30 % longer.
- *   cand_z    f32 : the height that is summed
- *   cand_aux  2xu32 : x = column offset inside the strip (8 bit) | original label << 8,
- *                     y = BEV code the point gets back if phase C un-grounds it */
+/* Workspace streams between the kernels of one sub-batch (see bev_exact.h for the candidate key):
+ *   cand_key u32 / cand_z f32  [nf][segs][kSeg]   candidates, one segment per (row, strip), compacted in column order;
+ *                                                  segments in row-major order => concatenation = slot order
+ *   ncand u32                  [nf][segs]
+ *   code_main u32              [nf][strips][bands][N * kStripCols]   BEV codes of the slots that are NOT candidates
+ *                                                  (final when the walk writes them), one list per raster band, appended
+ *                                                  row by row by the strip's workgroup (no atomics)
+ *   ncode u32                  [nf][strips][bands]
+ * Candidates reach the rasters through their keys: k_bev_raster tests them (phase C) and rasterises the un-grounded ones. */
 static_assert(sizeof(bev_point_t) == 32, "bev_point_t must be 32 bytes");
-
-constexpr uint32_t kCandCellMask = 0x0fffu; /* 75 * 50 = 3750 cells */
-constexpr uint32_t kCandPredBit = 0x8000u;
 
 struct Geometry {
     int N, H, G;       /* N_SCAN, Horizon_SCAN, GROUND_UPPER_SCAN */
@@ -57,7 +55,10 @@ struct Geometry {
     int tiles;         /* ceil(S / kTile): slot tiles of the per-slot kernels */
     int strips;        /* ceil(H / kStripCols): column strips of the walk kernel */
     int segs;          /* (G + 1) * strips: candidate segments per frame, row-major */
+    int parts;         /* ceil(segs / kPartSegs): parts k_cell_sums works through, in slot order */
     int raster_bands;  /* x-bands per frame in the raster kernel: a band's two LDS planes must fit one CU */
+    int band_rows;     /* mat_size / raster_bands */
+    uint32_t code_cap; /* N * kStripCols: capacity of one (strip, band) code list */
     bevx::RasterParams rp;
 };
 
@@ -69,13 +70,11 @@ struct BatchPtrs {
     uint32_t win_tag;            /* generation of this sub-batch in its workspace set (0: table was cleared) */
     int win_shift;               /* bits of index+1 */
     bev_point_t *ordered;        /* [nf][S] */
-    uint32_t *codes;             /* [nf][S] */
-    uint16_t *cand_cell;         /* [nf][segs][kSeg] */
+    uint32_t *cand_key;          /* [nf][segs][kSeg] */
     float *cand_z;               /* [nf][segs][kSeg] */
-    uint2 *cand_aux;             /* [nf][segs][kSeg] */
-    uint16_t *cand_cellp;        /* [nf][segs][kSeg] */
     uint32_t *ncand;             /* [nf][segs] */
-    float *zsorted;              /* [nf][S] */
+    uint32_t *code_main;         /* [nf][strips][bands][code_cap] */
+    uint32_t *ncode;             /* [nf][strips][bands] */
     float *avg;                  /* [nf][3750] */
     int8_t *gm;                  /* [nf][S] or nullptr: phase-A ground_mat */
     uint8_t *multi;              /* [nf][L*M*M] */
@@ -86,7 +85,6 @@ enum KernelId {
     K_ORDER_SCAN = 0,
     K_GATHER_GROUND,
     K_CELL_SUMS,
-    K_GROUND_RESOLVE,
     K_BEV_RASTER,
     K_GATHER_ONLY,
     K_GROUND_MAT,
@@ -107,10 +105,13 @@ void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t m
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st);
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
 void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
-void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
-void launch_bev_raster(const Geometry &g, const uint32_t *codes, size_t code_stride, uint32_t n_codes,
-                       uint8_t *multi, uint8_t *single, bool want_multi, bool want_single,
-                       int nf, hipStream_t st);
+/* phase C for the candidates (labels) + the rasters of a sub-batch from its code lists and candidates; runs even when no
+ * image is wanted (labels) */
+void launch_bev_raster(const Geometry &g, const BatchPtrs &b, bool want_multi, bool want_single, int nf, bool identity,
+                       hipStream_t st);
+/* rasters of ONE arbitrary cloud from a dense code array (bev_multi_bev / bev_single_bev) */
+void launch_bev_raster_dense(const Geometry &g, const uint32_t *codes, uint32_t n_codes, uint8_t *multi, uint8_t *single,
+                             hipStream_t st);
 void launch_ground_mat(const Geometry &g, const BatchPtrs &b, int8_t *out, int nf, hipStream_t st);
 void launch_cloud_codes(const Geometry &g, const bev_point_t *cloud, uint32_t n, uint32_t *codes, hipStream_t st);
 void launch_float_bev(const bev_point_t *cloud, uint32_t n, float interval, int M, bool skip_label0, float *grid,
@@ -133,7 +134,7 @@ struct KittiWork {
 };
 void launch_project_kitti(const float *xyzi, uint32_t n, const KittiWork &w, bev_point_t *out, hipStream_t st);
 void launch_angle_debug(const float *dx, const float *dy, const float *dz, uint8_t *out, size_t n, hipStream_t st);
-/* opt in to > 64 KiB of dynamic LDS for the two kernels that need it */
+/* opt in to > 64 KiB of dynamic LDS for the kernels that need it */
 hipError_t configure_kernels(const Geometry &g);
 size_t cell_sums_lds_bytes();
 size_t raster_lds_bytes(const Geometry &g);

@@ -22,15 +22,42 @@
  *     slot order, sorted STABLY by cell, and each cell is summed by one lane
  *     sequentially (a tree or atomic float reduction would change low bits).
  */
+#include <cstdlib>
+#include <type_traits>
+
 #include "bev_internal.h"
 #include "bev_libm.h"
 
 using namespace bevx;
 
+/* developer aid (make clk): phase durations of one workgroup per kernel, printed in 10 ns ticks */
+#ifdef BEV_CS_CLOCK
+#define PH_DECL long long ph_clk[12]; int ph_n = 0
+#define PH() ph_clk[ph_n++] = wall_clock64()
+#define PH_PRINT(name, cond)                                                                      \
+    do {                                                                                          \
+        if (cond) {                                                                               \
+            long long d_[6] = {0, 0, 0, 0, 0, 0};                                                 \
+            for (int i_ = 1; i_ < ph_n && i_ <= 6; ++i_) d_[i_ - 1] = ph_clk[i_] - ph_clk[i_ - 1]; \
+            printf("%s: %lld %lld %lld %lld %lld %lld (x10 ns)\n", name, d_[0], d_[1], d_[2], d_[3], d_[4], d_[5]); \
+        }                                                                                         \
+    } while (0)
+#define PHA_DECL long long pha_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pha_t = wall_clock64()
+#define PHA(i) do { const long long n_ = wall_clock64(); pha_[i] += n_ - pha_t; pha_t = n_; } while (0)
+#define PHA_PRINT(name, cond) do { if (cond) printf("%s: %lld %lld %lld %lld %lld %lld %lld %lld (x10 ns)\n", name, pha_[0], pha_[1], pha_[2], pha_[3], pha_[4], pha_[5], pha_[6], pha_[7]); } while (0)
+#else
+#define PH_DECL
+#define PH()
+#define PH_PRINT(name, cond)
+#define PHA_DECL
+#define PHA(i)
+#define PHA_PRINT(name, cond)
+#endif
+
 namespace bevk {
 
 static const char *const kNames[K_COUNT] = {
-    "k_order_scan", "k_strip_ground", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
+    "k_order_scan", "k_strip_ground", "k_cell_sums", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project", "k_transform",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
@@ -77,6 +104,16 @@ __device__ __forceinline__ void store_stream(uint4 *p, uint4 a)
 {
     const u32x4 v = {a.x, a.y, a.z, a.w};
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+}
+
+/* Workgroup barrier for data exchanged through LDS ONLY.  `__syncthreads()` is a release / acquire fence over global
+ * memory as well: with global stores (or LDS-DMA) pending, the compiler drains them — `s_waitcnt vmcnt(0)`, which on
+ * gfx950 counts loads AND stores — before every barrier, so a loop with one barrier per step can keep nothing in flight
+ * across steps.  The kernels below exchange only LDS words between their waves; nothing a wave writes to global memory
+ * is read by another wave of the same launch. */
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 /* A winner entry is (tag << shift) | (input index + 1).  The tag is the sub-batch generation of the workspace set:
@@ -231,15 +268,26 @@ struct PendingRow {
     int status;      /* s[row] (kInvalid / kSteep / kGround); kSteep for rows that are not tested */
     int gflag;       /* ground_mat(row) at the end of phase A */
     bool pred;       /* candidate the walk expects phase C to un-ground (see "provisional labels" below) */
+    uint32_t key;    /* candidate key (bev_exact.h), valid when gflag == 1 */
 };
 
+/* Narrow workspace streams (candidate keys / heights, code lists) are written with the default cache policy: a row's
+ * pieces from the four waves are contiguous, so L2 merges them into whole lines before they leave (with `nt` every
+ * piece left as partial lines: the walk wrote 6.5 MB per frame where 5.8 MB were needed).  The 32-byte ordered-cloud
+ * stores (whole 2 KiB wave rows) keep `nt`. */
+template <class T>
+__device__ __forceinline__ void store_ws(T *p, T v) { *p = v; }
+
 template <bool kIdentity>
-__global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geometry g)
+__global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geometry g, int nf)
 {
-    const int f = blockIdx.x / g.strips, strip = blockIdx.x - f * g.strips;
+    /* the strips of a frame share halo columns and the lines at their seams: one XCD (one L2) per frame */
+    int f, strip;
+    if (!map_block_xcd(blockIdx.x, nf, g.strips, f, strip)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int N = g.N, H = g.H, lo_row = g.N - g.G;
     const size_t frame_off = (size_t)f * g.S;
+    const int bands = g.raster_bands;
 
     const int v = strip * kStripCols + tid - 2;                      /* virtual column */
     const bool provider = (v < H + 2) && (v >= 0 || strip == 0);     /* has a point to load */
@@ -251,62 +299,98 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
 
     /* Neighbour exchange: lanes l+-2 of the same wave are reached with shuffles; only the two edge
      * lanes on each side of a wave go through LDS (768 B instead of a 12 KiB row buffer, so that these
-     * workgroups can share a CU with the 139 KiB cell-sum and 98 KiB raster workgroups of the other lane). */
+     * workgroups can share a CU with the back end's workgroups of the other lane). */
     constexpr int kWaves = kStripThreads / 64;
     __shared__ float4 edge[3][kWaves][4];                  /* rows r, r-1, (r-2): lanes 0, 1, 62, 63 of every wave */
     __shared__ uint32_t wave_cnt[2][kWaves];               /* per-wave candidate counts of the row being written */
+    __shared__ uint32_t wave_own[2][kWaves];               /* ... and the raster bands that own them (bit per band) */
+    __shared__ uint32_t band_cnt[2][kMaxBands][kWaves];    /* per-wave code counts of that row, per raster band */
+    __shared__ uint32_t band_base[2][kMaxBands];           /* entries already in this strip's code list of each band */
+    if (tid < kMaxBands) band_base[0][tid] = 0u;
 
-    auto load_winner = [&](int r) -> uint32_t {
-        if (!provider || r >= N) return 0u;
-        const int fl = r * H + vcol;
-        if (fl < 0) return 0u;
-        if (kIdentity) return (uint32_t)fl + 1u;
-        return winner_index(load_once(&fwin[fl]), b.win_tag, b.win_shift);
+    /* Winner words are loaded UNCONDITIONALLY from a clamped address and decoded only when they are used, two rows
+     * later: a predicated load whose result is decoded on the spot makes the compiler branch around the load and wait
+     * for it — with vmcnt(0), i.e. for every point load in flight as well — inside the branch, once per row (that was
+     * the shape of this loop in round 1: the software pipeline below existed on paper only). */
+    auto has_slot = [&](int r) -> bool { return provider && r < N && r * H + vcol >= 0; };
+    auto load_winner_raw = [&](int r) -> uint32_t {
+        if (kIdentity) return 0u;
+        const int fl = has_slot(r) ? r * H + vcol : 0;
+        return load_once(&fwin[fl]);
+    };
+    auto winner_of = [&](int r, uint32_t raw) -> uint32_t { /* input index + 1 of slot (r, this column), 0 = empty */
+        if (!has_slot(r)) return 0u;
+        if (kIdentity) return (uint32_t)(r * H + vcol) + 1u;
+        return winner_index(raw, b.win_tag, b.win_shift);
     };
 
+    /* the same for the points: an empty slot loads a dummy (the first point of this frame's OUTPUT, always allocated,
+     * one cached line) and is zeroed when the row is consumed, so that every iteration issues exactly three loads and
+     * the compiler can wait for "all but the last six" instead of for everything */
+    const Half *dummy = reinterpret_cast<const Half *>(b.ordered + frame_off);
     auto load_point = [&](uint32_t w, Half &lo, Half &hi) {
-        lo = Half{{0, 0, 0, 0}};
-        hi = Half{{0, 0, 0, 0}};
-        if (w != 0u) {
-            const Half *src = reinterpret_cast<const Half *>(fpts + (w - 1u));
-            lo = src[0];
-            hi = src[1];
-        }
+        const Half *src = w != 0u ? reinterpret_cast<const Half *>(fpts + (w - 1u)) : dummy;
+        lo = src[0];
+        hi = src[1];
     };
 
-    /* software pipeline: nxt = point of the row about to be processed, w_next = winner of the row after it */
-    Half cur_lo, cur_hi, nxt_lo, nxt_hi;
-    Half nx2_lo{{0, 0, 0, 0}}, nx2_hi{{0, 0, 0, 0}}; /* point of row r+2 (two rows in flight) */
-    uint32_t w_next = 0u, w_nx2 = 0u;                /* winners of rows r+3 and r+4 */
-    load_point(load_winner(0), nxt_lo, nxt_hi);
-    load_point(load_winner(1), nx2_lo, nx2_hi);
-    w_next = load_winner(2);
-    w_nx2 = load_winner(3);
+    /* software pipeline: while row r is handled, the points of rows r+1 and r+2 and the raw winner words of rows r+3
+     * and r+4 are in flight.  The stages live in small arrays indexed by r mod 3 / r mod 2 and the row loop is unrolled
+     * six times with compile-time indices: rotating the stages through variables instead ("next = next2") makes the
+     * compiler copy registers that a load is still writing, and wait for that load — the newest one — every row. */
+    Half plo[3], phi[3];   /* point of row r at [r % 3] */
+    bool pfull[3];         /* the slot of that row holds a point (else: the dummy was loaded) */
+    uint32_t wraw[2];      /* raw winner word of row r at [r % 2] */
+    {
+        const uint32_t r0 = load_winner_raw(0), r1 = load_winner_raw(1);
+        wraw[0] = load_winner_raw(2);
+        wraw[1] = load_winner_raw(3);
+        const uint32_t w0 = winner_of(0, r0), w1 = winner_of(1, r1);
+        pfull[0] = w0 != 0u;
+        pfull[1] = w1 != 0u;
+        pfull[2] = false;
+        load_point(w0, plo[0], phi[0]);
+        load_point(w1, plo[1], phi[1]);
+        plo[2] = phi[2] = Half{{0, 0, 0, 0}};
+    }
 
     XYZI prev{0.f, 0.f, 0.f, 0.f}, prevprev{0.f, 0.f, 0.f, 0.f};
     PendingRow p1{}, p2{};              /* rows r-1 (ground flag still open) and r-2 (ready to write) */
     float zref = __uint_as_float(0x7fc00000u); /* height of the column's last candidate taken for ground (NaN: none yet) */
     unsigned long long m_ready = 0;     /* candidate ballot of row r-2 */
+    uint32_t own_ready = 0;             /* row r-2: OR over this wave's candidates of (1 << owner band) */
+    unsigned long long cm_ready = 0;    /* row r-2: ballot of the lanes whose code goes to the same band as this lane's */
+    uint32_t bc_ready = 0;              /* row r-2: lane b < bands holds this wave's code count of band b */
 
     const size_t cand_base = (size_t)f * g.segs * kSeg;
     uint32_t *fncand = b.ncand + (size_t)f * g.segs;
+    uint32_t *flist = b.code_main + ((size_t)f * g.strips + strip) * bands * (size_t)g.code_cap;
 
-    /* two extra iterations drain the pipeline */
-    for (int r = 0; r < N + 2; ++r) {
-        cur_lo = nxt_lo;
-        cur_hi = nxt_hi;
-        /* points of rows r+1 and r+2 and winners of rows r+3 and r+4 are in flight while row r is handled */
-        nxt_lo = nx2_lo;
-        nxt_hi = nx2_hi;
-        load_point(r + 2 < N ? w_next : 0u, nx2_lo, nx2_hi);
-        w_next = w_nx2;
-        w_nx2 = load_winner(r + 4);
+    /* one row; I = r mod 6 at compile time */
+    auto row_step = [&](auto I, const int r) {
+        constexpr int i3 = decltype(I)::value % 3, i2 = decltype(I)::value % 2, n3 = (decltype(I)::value + 2) % 3;
+        const int par = r & 1;
+        Half cur_lo = plo[i3], cur_hi = phi[i3];
+        if (!pfull[i3]) { /* untouched slot: value-initialised, BatchMultiBevGen.cpp:98 */
+            cur_lo = Half{{0, 0, 0, 0}};
+            cur_hi = Half{{0, 0, 0, 0}};
+        }
+        {
+            const uint32_t w2 = winner_of(r + 2, wraw[i2]);
+            pfull[n3] = w2 != 0u;
+            load_point(w2, plo[n3], phi[n3]);
+        }
+        wraw[i2] = load_winner_raw(r + 4);
 
         const XYZI cur{__uint_as_float(cur_lo.w[0]), __uint_as_float(cur_lo.w[1]), __uint_as_float(cur_lo.w[2]),
                        __uint_as_float(cur_hi.w[0])};
         if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
-        if (lane == 0) wave_cnt[r & 1][wv] = (uint32_t)__popcll(m_ready);
-        __syncthreads();
+        if (lane == 0) {
+            wave_cnt[par][wv] = (uint32_t)__popcll(m_ready);
+            wave_own[par][wv] = own_ready;
+        }
+        if (lane < bands) band_cnt[par][lane][wv] = bc_ready;
+        lds_barrier();
 
         /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
         int s_r = kSteep;
@@ -335,18 +419,42 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
             else if (q == lo_row - 1) gf = (s_r == kGround) ? 1 : 0;
             p1.gflag = (q >= 0 && q < N) ? gf : 0;
         }
-        const unsigned long long m_new = __ballot(outcol && p1.gflag == 1);
+        const bool cand1 = outcol && p1.gflag == 1;
+        const unsigned long long m_new = __ballot(cand1);
         /* Provisional labels.  Phase C un-grounds a candidate that lies 0.30 m above a neighbour cell's average ground
          * height — known only after the whole frame has been summed.  The walk GUESSES: a candidate 0.30 m above the last
-         * candidate of its column that it took for ground is written with its own label and BEV code, every other
-         * candidate with label 0 and no code; k_ground_resolve tests every candidate exactly and patches the wrong
-         * guesses in either direction.  The guess only decides how many sparse 2- and 4-byte patches are needed
-         * (benchmark frames: 1.3 k instead of 7.9 k per frame; without any patch the pipeline would be 8 % faster). */
+         * candidate of its column that it took for ground is written with its own label, every other candidate with
+         * label 0; k_ground_resolve tests every candidate exactly and patches the wrong guesses in either direction.
+         * The guess only decides how many sparse 2-byte patches are needed (benchmark frames: 1.3 k instead of 7.9 k per
+         * frame). */
         {
             const float zq = __uint_as_float(p1.lo.w[2]);
-            const bool cand = outcol && p1.gflag == 1;
-            p1.pred = cand && (zq - zref >= 0.3f); /* false while zref is NaN */
-            if (cand && !p1.pred) zref = zq;
+            p1.pred = cand1 && (zq - zref >= 0.3f); /* false while zref is NaN */
+            if (cand1 && !p1.pred) zref = zq;
+        }
+        /* the candidate's key, and which raster bands own candidates of this (row, strip) segment: k_bev_raster's
+         * workgroup of band b only reads segments whose mask has bit b (an escape key is everybody's) */
+        uint32_t own_new = 0u;
+        if (cand1) {
+            const int cell = ground_cell(__uint_as_float(p1.lo.w[0]), __uint_as_float(p1.lo.w[1]));
+            p1.key = candidate_key(cell, tid - 2, p1.pred, p1.code, (int)(int16_t)(p1.hi.w[3] & 0xffffu), g.rp);
+            const uint32_t owner = (p1.key >> kKeyOwnerShift) & 15u;
+            own_new = owner == kKeyOwnerAll ? 0xffffu : (1u << owner);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) own_new |= __shfl_xor(own_new, d);
+        /* BEV codes of row r-1.  A slot that is not a candidate has its final label, so its code is final too: it goes
+         * to this strip's list of the raster band its x bin falls into.  Candidates' codes travel in their keys. */
+        unsigned long long cm_new = 0;
+        uint32_t bc_new = 0;
+        {
+            const bool has = outcol && !cand1 && p1.code != kSkip;
+            const int band = has ? code_x(p1.code) / g.band_rows : -1;
+            for (int bb = 0; bb < bands; ++bb) {
+                const unsigned long long m = __ballot(band == bb);
+                if (band == bb) cm_new = m;
+                if (lane == bb) bc_new = (uint32_t)__popcll(m);
+            }
         }
 
         /* ---- write out row r-2 (its per-wave counts were published before the barrier) ---- */
@@ -355,24 +463,38 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
             const bool is_cand = outcol && p2.gflag == 1;
             const int rr = q - (lo_row - 1);        /* only rows lo-1 .. N-1 can hold candidates */
             if (rr >= 0) {
-                uint32_t before = 0, total = 0;
+                uint32_t before = 0, total = 0, own = 0;
 #pragma unroll
-                for (int w = 0; w < kStripThreads / 64; ++w) {
-                    const uint32_t c = wave_cnt[r & 1][w];
+                for (int w = 0; w < kWaves; ++w) {
+                    const uint32_t c = wave_cnt[par][w];
                     if (w < wv) before += c;
                     total += c;
+                    own |= wave_own[par][w];
                 }
                 const size_t seg = (size_t)rr * g.strips + strip;
                 if (is_cand) {
                     const uint32_t rank = before + (uint32_t)__popcll(m_ready & ((1ull << lane) - 1ull));
                     const size_t at = cand_base + seg * kSeg + rank;
-                    store_stream(&b.cand_cell[at], (uint16_t)ground_cell(__uint_as_float(p2.lo.w[0]), __uint_as_float(p2.lo.w[1])));
-                    store_stream(&b.cand_cellp[at], (uint16_t)((uint32_t)ground_cell(__uint_as_float(p2.lo.w[0]), __uint_as_float(p2.lo.w[1])) |
-                                                               (p2.pred ? kCandPredBit : 0u)));
-                    store_stream(&b.cand_z[at], __uint_as_float(p2.lo.w[2]));
-                    store_stream(&b.cand_aux[at], make_uint2((uint32_t)(tid - 2) | ((p2.hi.w[3] & 0xffffu) << 8), p2.code));
+                    store_ws(&b.cand_key[at], p2.key);
+                    store_ws(&b.cand_z[at], __uint_as_float(p2.lo.w[2]));
                 }
-                if (tid == 2) fncand[seg] = total;
+                if (tid == 2) fncand[seg] = total | (own << 16); /* count (<= 252) | owner-band mask */
+            }
+            const bool has = outcol && !is_cand && p2.code != kSkip;
+            if (has) {
+                const int band = code_x(p2.code) / g.band_rows;
+                uint32_t before = 0;
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w)
+                    if (w < wv) before += band_cnt[par][band][w];
+                const uint32_t pos = band_base[par][band] + before + (uint32_t)__popcll(cm_ready & ((1ull << lane) - 1ull));
+                store_ws(&flist[(size_t)band * g.code_cap + pos], p2.code);
+            }
+            if (tid < bands) {
+                uint32_t total = 0;
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) total += band_cnt[par][tid][w];
+                band_base[par ^ 1][tid] = band_base[par][tid] + total;
             }
             if (outcol) {
                 Half hi = p2.hi;
@@ -382,22 +504,38 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
                 Half *dst = reinterpret_cast<Half *>(b.ordered + idx);
                 store_stream(dst, p2.lo);
                 store_stream(dst + 1, hi);
-                store_stream(&b.codes[idx], as_ground ? kSkip : p2.code);
                 if (b.gm) b.gm[idx] = (int8_t)p2.gflag;
             }
+        } else if (tid < bands) {
+            band_base[par ^ 1][tid] = band_base[par][tid];
         }
 
         /* ---- shift the pipeline ---- */
         p2 = p1;
         m_ready = m_new;
+        own_ready = own_new;
+        cm_ready = cm_new;
+        bc_ready = bc_new;
         p1.lo = cur_lo;
         p1.hi = cur_hi;
         p1.status = s_r;
         p1.gflag = 0;
+        p1.key = 0u;
         p1.code = bev_code(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w[3] & 0xffffu), g.rp);
         prevprev = prev;
         prev = cur;
+    };
+    /* two extra iterations drain the pipeline */
+    for (int r0 = 0; r0 < N + 2; r0 += 6) {
+        row_step(std::integral_constant<int, 0>{}, r0);
+        if (r0 + 1 < N + 2) row_step(std::integral_constant<int, 1>{}, r0 + 1);
+        if (r0 + 2 < N + 2) row_step(std::integral_constant<int, 2>{}, r0 + 2);
+        if (r0 + 3 < N + 2) row_step(std::integral_constant<int, 3>{}, r0 + 3);
+        if (r0 + 4 < N + 2) row_step(std::integral_constant<int, 4>{}, r0 + 4);
+        if (r0 + 5 < N + 2) row_step(std::integral_constant<int, 5>{}, r0 + 5);
     }
+    lds_barrier();
+    if (tid < bands) b.ncode[((size_t)f * g.strips + strip) * bands + tid] = band_base[(N + 2) & 1][tid];
 }
 
 /* getOrderedCloud alone (bev_order_cloud): no ground work. */
@@ -425,327 +563,266 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_only(BatchPtrs b, Geo
 
 /* ------------------------------------------------------------------------- */
 /* markGroundPoints phase B + divide, BatchMultiBevGen.cpp:187-210.
- * One workgroup (8 waves) per frame.
- *   LDS: hist[8][3750] u32 (later reused as the z staging chunk) | cell_start |
- *        per-wave tile counts | scan scratch
- *   pass 1  wave w owns a contiguous range of tiles (slot order) and counts its
- *           candidates per cell (LDS atomics; order-free, so loads are issued
- *           several slices at a time).
- *   scan    hist[w][c] -> offset of wave w inside cell c's run;
- *           cell_start = exclusive scan of the totals.
- *   pass 2  each wave re-walks its range IN ORDER (next slice prefetched);
- *           inside a 64-slice, lanes of the same cell are ranked with ballots,
- *           so the placement into zsorted is a stable sort by cell, i.e. each
- *           cell's run is in row-major slot order.
- *   pass 3  zsorted is staged through LDS in coalesced chunks; one lane per
- *           cell adds its run sequentially in float32 (sum += z; cnt = cnt + 1
- *           from 0.01f) — the reference's accumulation order — then
- *           avg = sum / cnt.                                                  */
+ *
+ * What must be reproduced: per 2 m cell, sum += z in ROW-MAJOR SLOT ORDER in float32 (and cnt = cnt + 1 from 0.01f).
+ * Cells are independent; only the order inside a cell matters.  Candidates arrive in slot order (segments in
+ * (row, strip) order, compacted in column order), so a STABLE sort by cell puts every cell's heights in the order the
+ * reference adds them; then one lane per cell adds its run sequentially.
+ *
+ * One SMALL workgroup per frame (4 waves, the size of a column-walk workgroup, so that it is dispatched into whatever
+ * slot a workgroup of the other sub-batch's streaming kernels leaves — an 8-wave / 139 KB workgroup waited for the
+ * whole column walk to drain) works through the frame part by part; a part = kPartSegs consecutive segments, so parts
+ * in order = slot order.  Per part, everything happens in LDS and registers:
+ *   hist    every wave counts its kSegsPerWave segments' candidates per cell (LDS atomics, two 16-bit counters per
+ *           word); keys and heights stay in registers
+ *   scan    per-cell totals over the waves, exclusive scan over the cells -> the part's runs
+ *   place   stable placement into the part's height buffer: lanes of a 64-slice that share a cell rank themselves with
+ *           12 ballots (one per key bit): constant work however many distinct cells a slice has
+ *   sum     thread t continues the running (sum, cnt) of cells t, t + 256, ... through their runs of this part
+ * while the next part's keys and heights are already in flight, so the only memory round trip that is ever exposed is
+ * the first one.  No intermediate of phase B touches HBM (round 1: the sorted heights bounced through global memory). */
 constexpr int kCells = kGridCells;
-constexpr int kCellsPerThread = (kCells + kSumThreads - 1) / kSumThreads; /* 8 */
-constexpr int kChunk = kSumWaves * kCells;  /* floats staged per pass-3 chunk (the dead hist region) */
-constexpr int kMaxSegsPerWave = kMaxSegs / kSumWaves + 1;
+constexpr int kCellPairs = (kCells + 1) / 2;        /* two 16-bit counters per 32-bit word */
+constexpr int kHistStride = (kCellPairs + 3) / 4 * 4; /* words per wave's histogram */
+constexpr int kTouchWords = (kCells + 31) / 32;
+static_assert(kPartSegs * kSeg <= 4096, "a part's run start (12 bits) and length (13 bits) share a word with room to spare");
 
 size_t cell_sums_lds_bytes()
 {
-    return sizeof(uint32_t) * ((size_t)kSumWaves * kCells + (kCells + 1) + (size_t)kSumWaves * kMaxSegsPerWave + 16);
+    return sizeof(uint32_t) * ((size_t)kSumWaves * kHistStride + kCells + (size_t)kPartSegs * kSeg + 2 * (size_t)kCells +
+                               kTouchWords + (kCells + 1) / 2 + 16);
 }
 
-/* developer aid (make clk): phase durations of one workgroup of k_cell_sums, in 10 ns ticks */
-#ifdef BEV_CS_CLOCK
-#define CS_CLK(i) cs_clk[i] = wall_clock64()
-#else
-#define CS_CLK(i)
-#endif
 __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry g)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *hist = lds;                         /* [kSumWaves][kCells] */
-    uint32_t *cell_start = hist + kSumWaves * kCells; /* [kCells + 1], the last entry is the candidate count */
-    uint32_t *tile_cnt = cell_start + kCells + 1;    /* [kSumWaves][kMaxSegsPerWave] */
-    uint32_t *wave_sum = tile_cnt + kSumWaves * kMaxSegsPerWave; /* [kSumWaves] */
+    uint32_t *hist = lds;                                 /* [kSumWaves][kHistStride]: 16-bit counts, cells 2i | 2i+1 << 16 */
+    uint32_t *start = hist + kSumWaves * kHistStride;     /* [kCells]: the part's runs, start | length << 16 */
+    float *zbuf = reinterpret_cast<float *>(start + kCells); /* [kPartSegs * kSeg]: the part's heights by cell */
+    float *sumv = zbuf + kPartSegs * kSeg;                /* [kCells] running sums */
+    float *cntv = sumv + kCells;                          /* [kCells] running counts */
+    uint32_t *tbits = reinterpret_cast<uint32_t *>(cntv + kCells); /* [kTouchWords]: cells this part has touched */
+    uint16_t *tlist = reinterpret_cast<uint16_t *>(tbits + kTouchWords); /* [kCells]: ... listed, in any order */
+    uint32_t *misc = reinterpret_cast<uint32_t *>(tlist) + (kCells + 1) / 2; /* [0..1] list lengths (by part parity), [4..7] wave sums, [8] carry */
+    uint16_t *hist16 = reinterpret_cast<uint16_t *>(hist); /* the same counters, cell c of wave w at [w * 2 * kHistStride + c] */
 
     const int f = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int T = g.segs;
-#ifdef BEV_CS_CLOCK
-    long long cs_clk[8];
-#endif
-    CS_CLK(0);
-    const uint16_t *ccell = b.cand_cell + (size_t)f * T * kSeg;
+    const int T = g.segs, P = g.parts;
+    const uint32_t *ckey = b.cand_key + (size_t)f * T * kSeg;
     const float *cz = b.cand_z + (size_t)f * T * kSeg;
-    const uint32_t *ncand = b.ncand + (size_t)f * T;
-    float *zs = b.zsorted + (size_t)f * g.S;
-
-    const int t0 = (int)((long long)T * wv / kSumWaves), t1 = (int)((long long)T * (wv + 1) / kSumWaves);
-    uint32_t *mycnt = tile_cnt + wv * kMaxSegsPerWave;
-    for (int t = t0 + lane; t < t1; t += 64) mycnt[t - t0] = ncand[t];
-    for (int k = tid; k < kSumWaves * kCells; k += kSumThreads) hist[k] = 0u;
-    __syncthreads();
-
-    uint32_t *myhist = hist + wv * kCells;
-    CS_CLK(1);
-
-    /* pass 1: order-free histogram of this wave's range.  The workgroup is alone on its CU (LDS) with two waves per
-     * SIMD, and it usually runs beside another sub-batch's streaming kernels, where a memory round trip takes
-     * several microseconds: the candidate loads are therefore requested kBatch1 segments (of at most kSeg = 4 x 64
-     * candidates) at a time, not one. */
+    const uint32_t *fn = b.ncand + (size_t)f * T;
     constexpr int kSl = kSeg / 64;
-    constexpr int kBatch1 = 8;
-    for (int tb = t0; tb < t1; tb += kBatch1) {
-        uint32_t cc[kBatch1][kSl];
-#pragma unroll
-        for (int j = 0; j < kBatch1; ++j) {
-            const int t = tb + j;
-            const int n = t < t1 ? (int)mycnt[t - t0] : 0;
-#pragma unroll
-            for (int k = 0; k < kSl; ++k)
-                cc[j][k] = (lane + 64 * k < n) ? (uint32_t)ccell[(size_t)t * kSeg + lane + 64 * k] : 0xffffu;
-        }
-#pragma unroll
-        for (int j = 0; j < kBatch1; ++j)
-#pragma unroll
-            for (int k = 0; k < kSl; ++k)
-                if (cc[j][k] != 0xffffu) atomicAdd(&myhist[cc[j][k]], 1u);
-    }
-    __syncthreads();
-    CS_CLK(2);
+    PH_DECL;
+    PH();
 
-    /* per-cell totals, hist -> wave offsets inside the cell's run */
+    for (int k = tid; k < kSumWaves * kHistStride; k += kSumThreads) hist[k] = 0u;
+    for (int k = tid; k < kTouchWords; k += kSumThreads) tbits[k] = 0u;
+    if (tid < 16) misc[tid] = 0u;
     for (int c = tid; c < kCells; c += kSumThreads) {
-        uint32_t tot = 0;
-#pragma unroll
-        for (int w = 0; w < kSumWaves; ++w) {
-            const uint32_t v = hist[w * kCells + c];
-            hist[w * kCells + c] = tot;
-            tot += v;
-        }
-        cell_start[c] = tot; /* the cell's total until the scan below turns it into its start */
+        sumv[c] = 0.0f;   /* :133-134 */
+        cntv[c] = 0.01f;  /* :135-136 */
     }
-    __syncthreads();
 
-    /* exclusive scan of the totals: thread owns kCellsPerThread consecutive cells (reads and rewrites only those) */
-    {
-        const int c0 = tid * kCellsPerThread;
-        uint32_t loc[kCellsPerThread];
-        uint32_t s = 0;
+    /* software pipeline: counts two parts ahead, keys + heights one part ahead */
+    auto load_counts = [&](int p) -> uint32_t { /* lane j < kSegsPerWave: count of this wave's segment j of part p */
+        const int t = p * kPartSegs + wv * kSegsPerWave + lane;
+        return (p < P && lane < kSegsPerWave && t < T) ? (fn[t] & 0xffffu) : 0u; /* | band mask << 16 */
+    };
+    uint32_t key_n[kSegsPerWave][kSl]; /* next part (raw keys; lanes past the segment's count hold garbage) */
+    float z_n[kSegsPerWave][kSl];
+    int n_n[kSegsPerWave];
+    auto request = [&](int p, uint32_t counts) {
+        const int t0 = p * kPartSegs + wv * kSegsPerWave;
 #pragma unroll
-        for (int k = 0; k < kCellsPerThread; ++k) {
-            const int c = c0 + k;
-            loc[k] = (c < kCells) ? cell_start[c] : 0u;
-            s += loc[k];
-        }
-        uint32_t incl = s;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t v = __shfl_up(incl, d);
-            if (lane >= d) incl += v;
-        }
-        if (lane == 63) wave_sum[wv] = incl;
-        __syncthreads();
-        uint32_t base = 0;
-        for (int w = 0; w < wv; ++w) base += wave_sum[w];
-        uint32_t run = base + incl - s;
-#pragma unroll
-        for (int k = 0; k < kCellsPerThread; ++k) {
-            const int c = c0 + k;
-            if (c < kCells) cell_start[c] = run;
-            run += loc[k];
-            if (c == kCells - 1) cell_start[kCells] = run;
-        }
-    }
-    __syncthreads();
-
-    CS_CLK(3);
-    /* pass 2: stable placement.  Segments are walked IN ORDER, kBatch2 at a time: all (cell, z) pairs of a batch
-     * are requested first, then its 64-slices are ranked one after the other. */
-    constexpr int kBatch2 = 4;
-    for (int tb = t0; tb < t1; tb += kBatch2) {
-        uint32_t cc[kBatch2][kSl];
-        float zz[kBatch2][kSl];
-        int nn[kBatch2];
-#pragma unroll
-        for (int j = 0; j < kBatch2; ++j) {
-            const int t = tb + j;
-            nn[j] = t < t1 ? (int)mycnt[t - t0] : 0;
+        for (int j = 0; j < kSegsPerWave; ++j) {
+            n_n[j] = (int)__shfl(counts, j);
+            /* whole 64-slices, loaded or skipped by a WAVE-UNIFORM test, and nothing but the loads inside the test: a
+             * per-lane predicated load makes the compiler branch around it and wait for the data inside the branch —
+             * one round trip after the other (this loop took 4 us per part that way).  Lanes past the count read stale
+             * entries of the segment (allocated memory) and are masked where the values are used. */
+            const int n = __builtin_amdgcn_readfirstlane(n_n[j]);
+            const size_t at = (size_t)(t0 + j) * kSeg + lane;
 #pragma unroll
             for (int k = 0; k < kSl; ++k) {
-                const bool ok = lane + 64 * k < nn[j];
-                cc[j][k] = ok ? (uint32_t)ccell[(size_t)t * kSeg + lane + 64 * k] : 0xfffu;
-                zz[j][k] = ok ? cz[(size_t)t * kSeg + lane + 64 * k] : 0.f;
+                key_n[j][k] = 0u;
+                z_n[j][k] = 0.f;
+                if (64 * k < n) {
+                    key_n[j][k] = ckey[at + 64 * k];
+                    z_n[j][k] = cz[at + 64 * k];
+                }
             }
         }
+    };
+    uint32_t cnt_next = load_counts(0);
+    request(0, cnt_next);
+    cnt_next = load_counts(1);
+    lds_barrier(); /* LDS state initialised */
+
+    uint32_t *myhist = hist + wv * kHistStride;
+    PHA_DECL;
+    for (int p = 0; p < P; ++p) {
+        PHA(7);
+        const int par = p & 1;
+        /* part p's data into the "current" registers, part p + 1 requested */
+        uint32_t cell[kSegsPerWave][kSl];
+        float zz[kSegsPerWave][kSl];
+        int nn[kSegsPerWave];
 #pragma unroll
-        for (int j = 0; j < kBatch2; ++j) {
+        for (int j = 0; j < kSegsPerWave; ++j) {
+            nn[j] = n_n[j];
+#pragma unroll
+            for (int k = 0; k < kSl; ++k) {
+                cell[j][k] = lane + 64 * k < nn[j] ? (key_n[j][k] & kKeyCellMask) : 0xfffu; /* 0xfff: no candidate */
+                zz[j][k] = z_n[j][k];
+            }
+        }
+        request(p + 1, cnt_next);
+        cnt_next = load_counts(p + 2);
+        PHA(5);
+
+        /* hist.  Consecutive candidates of a segment mostly share their cell (a ring crosses a 2 m cell with dozens
+         * of returns), and 64 LDS atomics on one address serialise: only the head of every run of equal cells adds, the
+         * run's length (a cell with several runs in a slice just gets several adds).  The first head to touch a cell in
+         * this part lists it: everything after this phase works on the listed cells only (a few hundred of 3750). */
+#pragma unroll
+        for (int j = 0; j < kSegsPerWave; ++j) {
 #pragma unroll
             for (int k = 0; k < kSl; ++k) {
                 if (64 * k >= nn[j]) break; /* wave-uniform */
-                const bool valid = lane + 64 * k < nn[j];
-                /* lanes holding the same cell find each other with one ballot per key bit (12 bits
-                 * cover 3750 cells; 0xfff is not a cell): constant work however many distinct cells
-                 * the 64 candidates have */
-                const uint32_t cell = cc[j][k];
+                const uint32_t c = cell[j][k];
+                const uint32_t prev = __shfl_up(c, 1);
+                const bool head = c != 0xfffu && (lane == 0 || prev != c);
+                const unsigned long long heads = __ballot(head || c == 0xfffu); /* an empty lane ends a run too */
+                if (head) {
+                    const unsigned long long later = heads & ~((2ull << lane) - 1ull);
+                    const int end = later ? __ffsll((long long)later) - 1 : 64;
+                    atomicAdd(&myhist[c >> 1], (uint32_t)(end - lane) << (16 * (c & 1u)));
+                    const uint32_t bit = 1u << (c & 31u);
+                    if (!(atomicOr(&tbits[c >> 5], bit) & bit)) tlist[atomicAdd(&misc[par], 1u)] = (uint16_t)c;
+                }
+            }
+        }
+        PHA(6);
+        lds_barrier();
+        PHA(0);
+
+        /* listed cells: totals over the waves (hist16[w][c] becomes wave w's offset inside cell c's run) and an
+         * exclusive scan over the list -> every listed cell's run in zbuf (any order of the cells will do) */
+        const int nT = (int)misc[par];
+        if (tid == 0) misc[par ^ 1] = 0u; /* the other parity's length, for the next part (nobody reads it now) */
+        for (int i0 = 0; i0 < nT; i0 += kSumThreads) {
+            const int i = i0 + tid;
+            uint32_t c = 0u, tot = 0u;
+            if (i < nT) {
+                c = tlist[i];
+#pragma unroll
+                for (int w = 0; w < kSumWaves; ++w) {
+                    const uint32_t v = hist16[w * 2 * kHistStride + c];
+                    hist16[w * 2 * kHistStride + c] = (uint16_t)tot;
+                    tot += v;
+                }
+            }
+            uint32_t incl = tot;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t v = __shfl_up(incl, d);
+                if (lane >= d) incl += v;
+            }
+            if (lane == 63) misc[4 + wv] = incl;
+            lds_barrier();
+            uint32_t run = misc[8] + incl - tot;
+            for (int w = 0; w < wv; ++w) run += misc[4 + w];
+            if (i < nT) start[c] = run | (tot << 16);
+            lds_barrier(); /* wave sums and the carry have been read */
+            if (tid == kSumThreads - 1) misc[8] = run + tot; /* carry into the next 256 listed cells */
+        }
+        lds_barrier();
+        if (tid == 0) misc[8] = 0u;
+        PHA(2);
+
+        /* stable placement: slices in slot order (segment by segment, 64 candidates at a time) */
+#pragma unroll
+        for (int j = 0; j < kSegsPerWave; ++j) {
+#pragma unroll
+            for (int k = 0; k < kSl; ++k) {
+                if (64 * k >= nn[j]) break; /* wave-uniform */
+                const uint32_t c = cell[j][k];
+                const bool valid = c != 0xfffu;
+                /* lanes holding the same cell find each other with one ballot per key bit (12 bits cover 3750 cells;
+                 * 0xfff is not a cell) */
                 unsigned long long peers = __ballot(valid);
 #pragma unroll
                 for (int bit = 0; bit < 12; ++bit) {
-                    const bool one = (cell >> bit) & 1u;
+                    const bool one = (c >> bit) & 1u;
                     const unsigned long long bal = __ballot(one);
                     peers &= one ? bal : ~bal;
                 }
                 const unsigned long long lower = peers & ((1ull << lane) - 1ull);
                 if (valid) {
-                    const uint32_t pos = cell_start[cell] + myhist[cell] + (uint32_t)__popcll(lower);
-                    zs[pos] = zz[j][k];
+                    const uint32_t off = (myhist[c >> 1] >> (16 * (c & 1u))) & 0xffffu;
+                    zbuf[(start[c] & 0xffffu) + off + (uint32_t)__popcll(lower)] = zz[j][k];
                 }
-                /* the lowest lane of each peer group advances the wave's cursor for that cell; every
-                 * read above is issued before this write (same wave, program order) */
-                if (valid && lower == 0ull) myhist[cell] += (uint32_t)__popcll(peers);
+                /* the lowest lane of each peer group advances the wave's cursor of that cell; the reads above are
+                 * issued before this update (same wave, program order); two cells of one word may both advance */
+                if (valid && lower == 0ull) atomicAdd(&myhist[c >> 1], (uint32_t)__popcll(peers) << (16 * (c & 1u)));
             }
         }
-    }
-    __threadfence_block();
-    __syncthreads();
-    CS_CLK(4);
+        lds_barrier();
+        PHA(3);
 
-    /* pass 3: in-order float accumulation; thread owns cells tid + 512*j */
-    float sum[kCellsPerThread], cnt[kCellsPerThread];
+        /* in-order sums of the listed cells, one thread per cell; the part's traces are wiped on the way */
+        for (int k = tid; k < kTouchWords; k += kSumThreads) tbits[k] = 0u;
+        for (int i = tid; i < nT; i += kSumThreads) {
+            const uint32_t c = tlist[i];
+            const uint32_t se = start[c];
 #pragma unroll
-    for (int j = 0; j < kCellsPerThread; ++j) {
-        sum[j] = 0.0f;   /* :133-134 */
-        cnt[j] = 0.01f;  /* :135-136 */
-    }
-    const int n_total = (int)cell_start[kCells];
-    float *zchunk = reinterpret_cast<float *>(hist);
-    for (int chunk0 = 0; chunk0 < n_total; chunk0 += kChunk) {
-        const int cn = min(kChunk, n_total - chunk0);
-        for (int i = tid; i < cn; i += kSumThreads) zchunk[i] = zs[chunk0 + i];
-        __syncthreads();
+            for (int w = 0; w < kSumWaves; ++w) hist16[w * 2 * kHistStride + c] = 0;
+            int q = (int)(se & 0xffffu);
+            const int e = q + (int)(se >> 16);
+            float sj = sumv[c], cj = cntv[c];
+            /* the adds of one cell are a serial chain (that IS the reference's order); what can be hidden is the LDS
+             * latency: the next 8 heights are requested before the current 8 are added */
+            if (q + 8 <= e) {
+                float v[8];
 #pragma unroll
-        for (int j = 0; j < kCellsPerThread; ++j) {
-            const int c = tid + j * kSumThreads;
-            if (c < kCells) {
-                const int st = (int)cell_start[c];
-                const int a = max(st, chunk0) - chunk0;
-                const int e = min((int)cell_start[c + 1], chunk0 + cn) - chunk0;
-                float sj = sum[j], cj = cnt[j];
-                int i = a;
-                for (; i + 4 <= e; i += 4) {
-                    const float v0 = zchunk[i], v1 = zchunk[i + 1], v2 = zchunk[i + 2], v3 = zchunk[i + 3];
-                    sj += v0; sj += v1; sj += v2; sj += v3;       /* :198-199 */
-                    cj += 1.0f; cj += 1.0f; cj += 1.0f; cj += 1.0f; /* :205-206 */
+                for (int u = 0; u < 8; ++u) v[u] = zbuf[q + u];
+#pragma unroll 1
+                for (; q + 16 <= e; q += 8) {
+                    float nx[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) nx[u] = zbuf[q + 8 + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        sj += v[u];       /* :198-199 */
+                        cj = cj + 1.0f;   /* :205-206 */
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = nx[u];
                 }
-                for (; i < e; ++i) {
-                    sj += zchunk[i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    sj += v[u];
                     cj = cj + 1.0f;
                 }
-                sum[j] = sj;
-                cnt[j] = cj;
+                q += 8;
             }
+#pragma unroll 1
+            for (; q < e; ++q) {
+                sj += zbuf[q];
+                cj = cj + 1.0f;
+            }
+            sumv[c] = sj;
+            cntv[c] = cj;
         }
-        __syncthreads();
+        lds_barrier(); /* the next part overwrites start and zbuf; hist and tbits are clean */
+        PHA(4);
     }
-    CS_CLK(5);
-#ifdef BEV_CS_CLOCK
-    if (tid == 0 && f == 100)
-        printf("cell_sums f=%d: init %lld pass1 %lld scan %lld pass2 %lld pass3 %lld (x10 ns), %d candidates\n", f,
-               cs_clk[1] - cs_clk[0], cs_clk[2] - cs_clk[1], cs_clk[3] - cs_clk[2], cs_clk[4] - cs_clk[3],
-               cs_clk[5] - cs_clk[4], n_total);
-#endif
+    PHA_PRINT("cell_sums barrier0 - scan place sum request histloop looptop", tid == 0 && blockIdx.x == 100);
+    PH();
     float *avg = b.avg + (size_t)f * kCells;
-#pragma unroll
-    for (int j = 0; j < kCellsPerThread; ++j) {
-        const int c = tid + j * kSumThreads;
-        if (c < kCells) avg[c] = sum[j] / cnt[j]; /* :210 */
-    }
-}
-
-/* ------------------------------------------------------------------------- */
-/* markGroundPoints phase C for the candidates, BatchMultiBevGen.cpp:216-250.  A candidate that is
- * higher than a neighbour cell's average + 0.30 stops being ground: its label is restored and it
- * gets its BEV code back.  kResolveGroups workgroups per frame, each stages the frame's averages in
- * LDS once and takes every 8th candidate row; all strips' loads of a row are issued before the
- * first test, so a thread has up to 2 * kMaxResolveStrips loads in flight. */
-constexpr int kMaxResolveStrips = 12;
-constexpr int kResolveGroups = 8; /* workgroups per frame; each takes every 8th candidate row */
-__global__ __launch_bounds__(kSeg) void k_ground_resolve(BatchPtrs b, Geometry g)
-{
-    __shared__ float avg[kCells];      /* the frame's 75 x 50 averages: 4 look-ups per candidate */
-    __shared__ uint32_t cnt[kMaxSegs]; /* the frame's candidate counts per (row, strip) segment */
-    const int rows = g.G + 1;
-    const int f = blockIdx.x / kResolveGroups, grp = blockIdx.x - f * kResolveGroups;
-    const int tid = threadIdx.x;
-    for (int c = tid; c < kCells; c += kSeg) avg[c] = b.avg[(size_t)f * kCells + c];
-    for (int i = tid; i < g.segs; i += kSeg) cnt[i] = b.ncand[(size_t)f * g.segs + i];
-    __syncthreads();
-
-    /* The kernel usually runs beside the streaming kernels of the next sub-batch, where a memory round trip takes
-     * several microseconds (kernel timeline: 140 us alone, 410 us beside them): a unit (one candidate row x up to 12
-     * strips) has its (cell, z) loads issued BEFORE the previous unit is tested, and the aux loads of the previous
-     * unit's hits are in flight at the same time, so a workgroup pays about one round trip per unit instead of three
-     * (counts, candidates, aux): 320 us beside the streaming kernels. */
-    struct Unit {
-        uint32_t cell[kMaxResolveStrips];
-        float z[kMaxResolveStrips];
-        uint32_t ok; /* bit k: strip s0 + k holds a candidate for this thread */
-        int rr, s0;
-    };
-    const int chunks = (g.strips + kMaxResolveStrips - 1) / kMaxResolveStrips;
-    const int my_rows = rows > grp ? (rows - grp + kResolveGroups - 1) / kResolveGroups : 0;
-    const int n_units = my_rows * chunks;
-    auto issue = [&](int u, Unit &q) {
-        q.ok = 0u;
-        q.rr = 0;
-        q.s0 = 0;
-        if (u >= n_units) return;
-        q.rr = grp + (u / chunks) * kResolveGroups;
-        q.s0 = (u % chunks) * kMaxResolveStrips;
-        const size_t seg0 = (size_t)f * g.segs + (size_t)q.rr * g.strips;
-#pragma unroll
-        for (int k = 0; k < kMaxResolveStrips; ++k) {
-            const int st = q.s0 + k;
-            const bool ok = st < g.strips && (uint32_t)tid < cnt[q.rr * g.strips + (st < g.strips ? st : 0)];
-            const size_t at = (seg0 + st) * kSeg + tid;
-            q.cell[k] = ok ? (uint32_t)b.cand_cellp[at] : 0u; /* cell | kCandPredBit */
-            q.z[k] = ok ? b.cand_z[at] : 0.f;
-            q.ok |= ok ? (1u << k) : 0u;
-        }
-    };
-    auto finish = [&](const Unit &q) {
-        if (q.ok == 0u) return;
-        const size_t seg0 = (size_t)f * g.segs + (size_t)q.rr * g.strips;
-        const size_t row_off = (size_t)f * g.S + (size_t)(q.rr + g.N - g.G - 1) * g.H;
-        /* hits: un-grounded by phase C.  wrong: the walk's provisional label / code (written for its guess) differ. */
-        uint32_t hits = 0u, wrong = 0u;
-#pragma unroll
-        for (int k = 0; k < kMaxResolveStrips; ++k) {
-            if (!((q.ok >> k) & 1u)) continue;
-            const bool hit = above_neighbour_ground(q.z[k], (int)(q.cell[k] & kCandCellMask), avg);
-            const bool pred = (q.cell[k] & kCandPredBit) != 0u;
-            hits |= hit ? (1u << k) : 0u;
-            wrong |= (hit != pred) ? (1u << k) : 0u;
-        }
-        uint2 aux[kMaxResolveStrips];
-#pragma unroll
-        for (int k = 0; k < kMaxResolveStrips; ++k) /* all aux loads of the unit's wrong guesses in flight together */
-            aux[k] = ((wrong >> k) & 1u) ? b.cand_aux[(seg0 + q.s0 + k) * kSeg + tid] : make_uint2(0u, 0u);
-#pragma unroll
-        for (int k = 0; k < kMaxResolveStrips; ++k) {
-            if ((wrong >> k) & 1u) {
-                const size_t idx = row_off + (size_t)(q.s0 + k) * kStripCols + (aux[k].x & 0xffu);
-                const bool hit = (hits >> k) & 1u;
-                /* label @28: the point's own label back, or 0 for ground (BatchMultiBevGen.cpp:245) */
-                reinterpret_cast<uint16_t *>(b.ordered + idx)[14] = hit ? (uint16_t)(aux[k].x >> 8) : (uint16_t)0;
-                b.codes[idx] = hit ? aux[k].y : kSkip;
-            }
-        }
-    };
-    Unit cur, nxt;
-    issue(0, cur);
-    for (int u = 0; u < n_units; ++u) {
-        issue(u + 1, nxt); /* next unit's loads leave before this unit's tests, aux loads and stores */
-        finish(cur);
-        cur = nxt;
-    }
+    for (int c = tid; c < kCells; c += kSumThreads) avg[c] = sumv[c] / cntv[c]; /* :210 */
+    PH_PRINT("cell_sums all-parts", tid == 0 && blockIdx.x == 100);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -780,15 +857,24 @@ __global__ __launch_bounds__(256) void k_cloud_codes(const bev_point_t *__restri
 }
 
 /* ------------------------------------------------------------------------- */
-/* Rasters, BatchMultiBevGen.cpp:271-292 (occupancy, 24 layers) and :340-356
- * (uint8 max height).  Workgroup = (frame, x-band of M/4 rows).  The band's
- * 24-bit layer masks and max heights live in LDS (2 * 56 * 224 * 4 B = 98 KiB);
- * codes are streamed with coalesced 4 B loads; the planes leave with 16 B
- * stores, 1 KiB contiguous per wave-instruction.                             */
+/* markGroundPoints phase C for the candidates (BatchMultiBevGen.cpp:216-250) and both rasters (:271-292 occupancy,
+ * 24 layers; :340-356 uint8 max height), one workgroup per (frame, x-band of the images).
+ *
+ * The band's 24-bit layer masks and max heights live in LDS (two planes of band_rows x M words).  Its inputs:
+ *   - the walk's code lists of this band (one per strip): slots that are not candidates, final codes;
+ *   - the frame's candidates (key + height).  A candidate that is higher than a neighbour cell's average + 0.30 stops
+ *     being ground ("hit"): it keeps / gets back its own label and contributes its BEV code, rebuilt from key and
+ *     height (bev_exact.h).  Every workgroup of the frame reads all keys, but only the candidate's OWNER band (key
+ *     bits 27..30: the band its code falls into) tests it, rasterises it and, where the walk's provisional label was
+ *     a wrong guess, patches the label in the ordered cloud.  Keys that could not carry their bins (escapes) are
+ *     looked at by every band: each reads the point and rasterises it if it falls into its own rows; band 0 patches.
+ * So phase C needs no kernel, list or atomic of its own, and nothing of a frame is handed from one workgroup to
+ * another.  Finished planes leave with 16-byte stores, 1 KiB contiguous per wave-instruction.
+ * When neither image is wanted (bev_mark_ground) the kernel still runs for the labels. */
 int raster_bands_for(int M)
 {
-    for (int bands = kRasterSplit; bands <= 16; bands *= 2)
-        if (M % bands == 0 && (size_t)2 * (M / bands) * M * sizeof(uint32_t) <= (size_t)150 * 1024) return bands;
+    for (int bands = kRasterSplit; bands <= kMaxBands; bands *= 2)
+        if (M % bands == 0 && (size_t)2 * (M / bands) * M * sizeof(uint32_t) <= (size_t)100 * 1024) return bands;
     return 0;
 }
 size_t raster_lds_bytes(const Geometry &g)
@@ -797,58 +883,23 @@ size_t raster_lds_bytes(const Geometry &g)
     return (size_t)2 * (M / g.raster_bands) * M * sizeof(uint32_t);
 }
 
-__global__ __launch_bounds__(kRasterThreads) void k_bev_raster(const uint32_t *__restrict__ codes, size_t code_stride,
-                                                              uint32_t n_codes, uint8_t *__restrict__ multi,
-                                                              uint8_t *__restrict__ single, int M, int L, int nf,
-                                                              int bands)
+/* one code into the band's LDS planes (the code is known to lie in the band) */
+__device__ __forceinline__ void splat_code(uint32_t c, int x0, int M, uint32_t *mask, uint32_t *hmax)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int band_rows = M / bands;
-    const int cells = band_rows * M;
-    uint32_t *mask = lds;
-    uint32_t *hmax = lds + cells;
-    /* the bands of a frame read the same codes: give them to ONE XCD (blocks b and
-     * b+8 share an L2) and adjacent launch slots, so three of the four reads are L2 hits */
-    const int xl = blockIdx.x & 7, jj = blockIdx.x >> 3;
-    const int f = (jj / bands) * 8 + xl, band = jj % bands;
-    if (f >= nf) return;
-    const int x0 = band * band_rows;
-    const int tid = threadIdx.x;
+    const int idx = (code_x(c) - x0) * M + code_y(c);
+    atomicMax(&hmax[idx], (uint32_t)code_h(c));      /* :353-355 */
+    const uint32_t l = code_layer(c);
+    if (l != kNoLayer) atomicOr(&mask[idx], 1u << l); /* :289-291 */
+}
 
-    for (int k = tid; k < 2 * cells; k += kRasterThreads) lds[k] = 0u;
-    __syncthreads();
-
-    const uint32_t *fc = codes + (size_t)f * code_stride;
-    auto splat = [&](uint32_t c) {
-        if (c == kSkip) return;
-        const int x = code_x(c) - x0;
-        if (x < 0 || x >= band_rows) return;
-        const int idx = x * M + code_y(c);
-        atomicMax(&hmax[idx], (uint32_t)code_h(c));      /* :353-355 */
-        const uint32_t l = code_layer(c);
-        if (l != kNoLayer) atomicOr(&mask[idx], 1u << l); /* :289-291 */
-    };
-    /* 16 coalesced loads in flight per thread before the first LDS atomic.  The code scan is what this kernel's time
-     * is made of (phase clocks of one workgroup: zero 1 us, scan 20 us, plane stores 7 us), and it is bound by the four
-     * bands of a frame each reading all of the frame's codes through L2 at ~27 GB/s per CU — not by the LDS atomics
-     * (scan without them: 18.5 us; merging lanes of the same cell with DPP row shifts before the atomics made the
-     * kernel 45 % slower). */
-    constexpr int kU = 16;
-    uint32_t i = tid;
-    for (; i + (kU - 1) * kRasterThreads < n_codes; i += kU * kRasterThreads) {
-        uint32_t c[kU];
-#pragma unroll
-        for (int k = 0; k < kU; ++k) c[k] = fc[i + k * kRasterThreads];
-#pragma unroll
-        for (int k = 0; k < kU; ++k) splat(c[k]);
-    }
-    for (; i < n_codes; i += kRasterThreads) splat(fc[i]);
-    __syncthreads();
-
+/* the band's planes -> the two images (rows x0 .. x0 + band_rows of every layer) */
+__device__ __forceinline__ void store_planes(const uint32_t *mask, const uint32_t *hmax, uint8_t *multi, uint8_t *single,
+                                             int f, int x0, int band_rows, int M, int L, int tid, int nthreads)
+{
     const int chunks_per_row = M / 16;
     const int n_tasks = band_rows * chunks_per_row;
     const size_t plane = (size_t)M * M;
-    for (int task = tid; task < n_tasks; task += kRasterThreads) {
+    for (int task = tid; task < n_tasks; task += nthreads) {
         const int row = task / chunks_per_row, ch = task - row * chunks_per_row;
         const int base = row * M + ch * 16;
         const size_t out_off = (size_t)(x0 + row) * M + (size_t)ch * 16;
@@ -877,6 +928,197 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(const uint32_t *_
             }
         }
     }
+}
+
+constexpr int kRasterWaves = kRasterThreads / 64;
+constexpr int kCandBatch = 6; /* candidate segments whose keys and heights a wave requests at once */
+template <bool kIdentity>
+__global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geometry g, int nf, int want_multi, int want_single)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    __shared__ float avg[kCells];                       /* the frame's 75 x 50 averages: 4 look-ups per candidate */
+    __shared__ int edge_x[kGridRows], edge_y[kGridCols]; /* BEV bin of every ground-grid row's / column's lower edge */
+    __shared__ uint32_t list_end[kMaxStrips + 1];       /* inclusive prefix of this band's code-list lengths */
+    __shared__ uint16_t seg_cnt[kMaxSegs];              /* candidates of the segments this band has to look at ... */
+    __shared__ uint16_t seg_id[kMaxSegs];               /* ... and which segments those are */
+    __shared__ uint32_t n_mine;
+    const int M = g.rp.mat_size, L = g.rp.n_layers, bands = g.raster_bands, band_rows = g.band_rows;
+    const int cells = band_rows * M;
+    uint32_t *mask = lds;
+    uint32_t *hmax = lds + cells;
+    /* the bands of a frame read the same candidate keys: ONE XCD (blocks b and b+8 share an L2), adjacent launch slots */
+    const int xl = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int f = (jj / bands) * 8 + xl, band = jj % bands;
+    if (f >= nf) return;
+    const int x0 = band * band_rows;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    PH_DECL;
+    PH();
+
+    /* round trip 1: list lengths, segment counts, averages; the planes are zeroed meanwhile */
+    uint32_t my_cnt = 0u;
+    if (tid < g.strips) my_cnt = b.ncode[((size_t)f * g.strips + tid) * bands + band];
+    if (tid == 0) n_mine = 0u;
+    for (int c = tid; c < kCells; c += kRasterThreads) avg[c] = b.avg[(size_t)f * kCells + c];
+    if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
+    else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
+    for (int k = tid; k < 2 * cells; k += kRasterThreads) lds[k] = 0u;
+    if (tid < g.strips) list_end[tid + 1] = my_cnt;
+    if (tid == 0) list_end[0] = 0u;
+    lds_barrier();
+    if (tid == 0) /* strips is small (9 for HDL_64E, at most kMaxStrips): a serial prefix */
+        for (int e = 0; e < g.strips; ++e) list_end[e + 1] += list_end[e];
+    /* the candidate segments that hold anything owned by this band (the walk left a band mask beside each count);
+     * their order does not matter */
+    for (int i = tid; i < g.segs; i += kRasterThreads) {
+        const uint32_t v = b.ncand[(size_t)f * g.segs + i];
+        if ((v & 0xffffu) != 0u && ((v >> (16 + band)) & 1u)) {
+            const uint32_t at = atomicAdd(&n_mine, 1u);
+            seg_cnt[at] = (uint16_t)(v & 0xffffu);
+            seg_id[at] = (uint16_t)i;
+        }
+    }
+    lds_barrier();
+    PH();
+
+    /* ---- final codes: this band's lists of all strips as ONE index space, so that every load of the workgroup is
+     * requested at once ---- */
+    {
+        constexpr int kU = 8;
+        const uint32_t total = list_end[g.strips];
+        const uint32_t *fmain = b.code_main + (size_t)f * g.strips * bands * g.code_cap;
+        for (uint32_t i0 = 0; i0 < total; i0 += kU * kRasterThreads) {
+            uint32_t c[kU];
+#pragma unroll
+            for (int k = 0; k < kU; ++k) {
+                const uint32_t i = i0 + (uint32_t)k * kRasterThreads + tid;
+                c[k] = kSkip;
+                if (i < total) {
+                    int e = 0;
+                    if (g.strips <= 16) {
+                        while (list_end[e + 1] <= i) ++e;
+                    } else {
+                        int lo = 0, hi = g.strips - 1; /* first e with list_end[e + 1] > i */
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (list_end[mid + 1] > i) hi = mid; else lo = mid + 1;
+                        }
+                        e = lo;
+                    }
+                    c[k] = fmain[((size_t)e * bands + band) * g.code_cap + (i - list_end[e])];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kU; ++k)
+                if (c[k] != kSkip) splat_code(c[k], x0, M, mask, hmax);
+        }
+    }
+    PH();
+
+    /* ---- candidates: wave w takes segments w, w + waves, ...; kCandBatch segments (x 4 slices of 64) per request ---- */
+    {
+        constexpr int kSl = kSeg / 64;
+        const uint32_t *fkey = b.cand_key + (size_t)f * g.segs * kSeg;
+        const float *fz = b.cand_z + (size_t)f * g.segs * kSeg;
+        const int lo_row = g.N - g.G;
+        const int n_segs = (int)n_mine;
+        for (int s0 = wv; s0 < n_segs; s0 += kRasterWaves * kCandBatch) {
+            uint32_t key[kCandBatch][kSl];
+            float z[kCandBatch][kSl];
+#pragma unroll
+            for (int j = 0; j < kCandBatch; ++j) {
+                const int q = s0 + j * kRasterWaves;
+                const int n = q < n_segs ? (int)seg_cnt[q] : 0;
+                const int sg = q < n_segs ? (int)seg_id[q] : 0;
+#pragma unroll
+                for (int k = 0; k < kSl; ++k) {
+                    const bool have = lane + 64 * k < n;
+                    const size_t at = (size_t)sg * kSeg + lane + 64 * k;
+                    key[j][k] = have ? fkey[at] : 0xffffffffu;
+                    z[j][k] = have ? fz[at] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kCandBatch; ++j) {
+                const int q = s0 + j * kRasterWaves;
+                const int n = q < n_segs ? (int)seg_cnt[q] : 0;
+                const int sg = q < n_segs ? (int)seg_id[q] : 0;
+#pragma unroll
+                for (int k = 0; k < kSl; ++k) {
+                    if (64 * k >= n) break; /* wave-uniform */
+                    const uint32_t kk = key[j][k];
+                    const bool have = lane + 64 * k < n;
+                    const uint32_t owner = (kk >> kKeyOwnerShift) & 15u;
+                    const bool all = owner == kKeyOwnerAll;
+                    if (!have || !(owner == (uint32_t)band || all)) continue;
+                    const int cell = (int)(kk & kKeyCellMask);
+                    const bool hit = above_neighbour_ground(z[j][k], cell, avg);
+                    const bool pred = (kk & kKeyPredBit) != 0u;
+                    const int rr = sg / g.strips, strip = sg - rr * g.strips;
+                    const size_t idx = (size_t)f * g.S + (size_t)(rr + lo_row - 1) * g.H + (size_t)strip * kStripCols +
+                                       ((kk >> kKeyColShift) & 0xffu);
+                    if (hit && !(kk & kKeyNoCodeBit)) {
+                        if (!all) {
+                            splat_code(bev_code_from_bins(edge_x[cell / kGridCols] + (int)((kk >> kKeyDxShift) & 3u),
+                                                          edge_y[cell % kGridCols] + (int)((kk >> kKeyDyShift) & 3u), z[j][k], g.rp),
+                                       x0, M, mask, hmax);
+                        } else { /* cell clamped or bins not next to the cell's edge: x, y from the point itself */
+                            const float4 a = *reinterpret_cast<const float4 *>(b.ordered + idx);
+                            const uint32_t c = bev_code(a.x, a.y, a.z, 1 /* not 0: no kKeyNoCodeBit */, g.rp);
+                            if (c != kSkip && code_x(c) >= x0 && code_x(c) < x0 + band_rows) splat_code(c, x0, M, mask, hmax);
+                        }
+                    }
+                    if (hit != pred && (!all || band == 0)) { /* the walk's provisional label is wrong */
+                        uint16_t label = 0;             /* not un-grounded: label = 0, BatchMultiBevGen.cpp:245 */
+                        if (hit) {                      /* un-grounded: the point's own label back */
+                            if (kk & kKeyLabelM2Bit) label = (uint16_t)(int16_t)-2;
+                            else if (kIdentity) label = reinterpret_cast<const uint16_t *>(b.pts + idx)[14];
+                            else {
+                                /* an EMPTY slot can be a candidate too (a value-initialised point has intensity 0, not
+                                 * -1, so phase A tests it like any other): its label is the zero point's 0 */
+                                const uint32_t w = winner_index(b.winner[idx], b.win_tag, b.win_shift);
+                                if (w != 0u) label = reinterpret_cast<const uint16_t *>(b.pts + b.frames[f].in_offset + (w - 1u))[14];
+                            }
+                        }
+                        reinterpret_cast<uint16_t *>(b.ordered + idx)[14] = label; /* label @28 */
+                    }
+                }
+            }
+        }
+    }
+    lds_barrier();
+    PH();
+    store_planes(mask, hmax, want_multi ? b.multi : nullptr, want_single ? b.single : nullptr, f, x0, band_rows, M, L, tid,
+                 kRasterThreads);
+    PH();
+    PH_PRINT(band == 3 ? "raster3 setup codes cands stores" : "raster0 setup codes cands stores", tid == 0 && (blockIdx.x == 800 - 8 || blockIdx.x == 800 - 32));
+}
+
+/* rasters of ONE arbitrary cloud from a dense code array (bev_multi_bev / bev_single_bev): every band scans all codes */
+__global__ __launch_bounds__(kRasterThreads) void k_bev_raster_dense(const uint32_t *__restrict__ codes, uint32_t n,
+                                                                    uint8_t *__restrict__ multi, uint8_t *__restrict__ single,
+                                                                    int M, int L, int bands)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int band_rows = M / bands, cells = band_rows * M;
+    uint32_t *mask = lds, *hmax = lds + cells;
+    const int band = blockIdx.x, x0 = band * band_rows, tid = threadIdx.x;
+    for (int k = tid; k < 2 * cells; k += kRasterThreads) lds[k] = 0u;
+    __syncthreads();
+    constexpr int kU = 8;
+    for (uint32_t i0 = 0; i0 < n; i0 += kU * kRasterThreads) {
+        uint32_t c[kU];
+#pragma unroll
+        for (int k = 0; k < kU; ++k) {
+            const uint32_t i = i0 + (uint32_t)k * kRasterThreads + tid;
+            c[k] = i < n ? codes[i] : kSkip;
+        }
+#pragma unroll
+        for (int k = 0; k < kU; ++k)
+            if (c[k] != kSkip && code_x(c[k]) >= x0 && code_x(c[k]) < x0 + band_rows) splat_code(c[k], x0, M, mask, hmax);
+    }
+    __syncthreads();
+    store_planes(mask, hmax, multi, single, 0, x0, band_rows, M, L, tid, kRasterThreads);
 }
 
 /* saveAsMat of batch_cloud_manip / cloud_manip (BatchCloudManip.cpp:213-225, CloudManip.cpp:84-95):
@@ -1058,7 +1300,13 @@ hipError_t configure_kernels(const Geometry &g)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cell_sums),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)cell_sums_lds_bytes());
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster),
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)raster_lds_bytes(g));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)raster_lds_bytes(g));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster_dense),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)raster_lds_bytes(g));
 }
 void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, hipStream_t st)
@@ -1072,11 +1320,17 @@ void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t m
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st)
 {
     if (nf == 0) return;
-    const int grid = nf * g.strips;
+    const int grid = xcd_grid(nf, g.strips);
+    /* BEV_WALK_LDS (experiment knob): dynamic LDS the walk's workgroups claim without using it, to cap how many of them
+     * share a CU and leave registers / wave slots for the back end's workgroups of the other sub-batch */
+    static const size_t pad = [] {
+        const char *e = getenv("BEV_WALK_LDS");
+        return e ? (size_t)atoi(e) : (size_t)0;
+    }();
     if (identity)
-        hipLaunchKernelGGL(k_strip_ground<true>, dim3(grid), dim3(kStripThreads), 0, st, b, g);
+        hipLaunchKernelGGL(k_strip_ground<true>, dim3(grid), dim3(kStripThreads), pad, st, b, g, nf);
     else
-        hipLaunchKernelGGL(k_strip_ground<false>, dim3(grid), dim3(kStripThreads), 0, st, b, g);
+        hipLaunchKernelGGL(k_strip_ground<false>, dim3(grid), dim3(kStripThreads), pad, st, b, g, nf);
 }
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {
@@ -1088,19 +1342,23 @@ void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t
     if (nf == 0) return;
     hipLaunchKernelGGL(k_cell_sums, dim3(nf), dim3(kSumThreads), cell_sums_lds_bytes(), st, b, g);
 }
-void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
-{
-    if (nf == 0) return;
-    hipLaunchKernelGGL(k_ground_resolve, dim3(nf * kResolveGroups), dim3(kSeg), 0, st, b, g);
-}
-void launch_bev_raster(const Geometry &g, const uint32_t *codes, size_t code_stride, uint32_t n_codes,
-                       uint8_t *multi, uint8_t *single, bool want_multi, bool want_single, int nf,
+void launch_bev_raster(const Geometry &g, const BatchPtrs &b, bool want_multi, bool want_single, int nf, bool identity,
                        hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_bev_raster, dim3(8 * ((nf + 7) / 8) * g.raster_bands), dim3(kRasterThreads), raster_lds_bytes(g),
-                       st, codes, code_stride, n_codes, want_multi ? multi : nullptr, want_single ? single : nullptr,
-                       g.rp.mat_size, g.rp.n_layers, nf, g.raster_bands);
+    const dim3 grid(8 * ((nf + 7) / 8) * g.raster_bands);
+    if (identity)
+        hipLaunchKernelGGL(k_bev_raster<true>, grid, dim3(kRasterThreads), raster_lds_bytes(g), st, b, g, nf,
+                           want_multi ? 1 : 0, want_single ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_bev_raster<false>, grid, dim3(kRasterThreads), raster_lds_bytes(g), st, b, g, nf,
+                           want_multi ? 1 : 0, want_single ? 1 : 0);
+}
+void launch_bev_raster_dense(const Geometry &g, const uint32_t *codes, uint32_t n_codes, uint8_t *multi, uint8_t *single,
+                             hipStream_t st)
+{
+    hipLaunchKernelGGL(k_bev_raster_dense, dim3(g.raster_bands), dim3(kRasterThreads), raster_lds_bytes(g), st, codes,
+                       n_codes, multi, single, g.rp.mat_size, g.rp.n_layers, g.raster_bands);
 }
 void launch_ground_mat(const Geometry &g, const BatchPtrs &b, int8_t *out, int nf, hipStream_t st)
 {

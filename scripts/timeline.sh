@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 OUT=$R/gpurun_out/timeline; rm -rf $OUT; mkdir -p $OUT
 export BEV_STAGED=${STAGED:-1}
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-profile > $OUT/bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 bench.py --no-build --steps 3 --warmup 1 --no-cpu --no-profile > $OUT/bench.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/timeline/trace/**/*kernel_trace.csv", recursive=True)[0]

@@ -36,6 +36,8 @@ RasterParams raster_params(const bev_params_t *p)
     rp.lidar_to_ground = p->lidar_to_ground;
     rp.mat_size = cvtt_f32((float)(p->max_range * 2) / p->interval);
     rp.n_layers = p->n_layers;
+    rp.bands = 8; /* how the device cuts the images into workgroups; results do not depend on it */
+    rp.band_rows = rp.mat_size / rp.bands > 0 ? rp.mat_size / rp.bands : 1;
     return rp;
 }
 } // namespace
@@ -129,6 +131,29 @@ uint64_t hc_angle_vs_libm(uint64_t n, uint64_t seed)
 }
 
 int hc_ground_cell(float x, float y) { return ground_cell(x, y); }
+
+/* candidate keys decoded / escaped by hc_process_frame since the last reset (test statistics) */
+static uint64_t g_key_decodes = 0, g_key_escapes = 0;
+void hc_key_stats(uint64_t *decodes, uint64_t *escapes, int reset)
+{
+    *decodes = g_key_decodes;
+    *escapes = g_key_escapes;
+    if (reset) g_key_decodes = g_key_escapes = 0;
+}
+/* candidate_key / candidate_code round trip on one point; returns 1 if the key reproduces bev_code (or escapes /
+ * flags "no code" correctly), 0 otherwise */
+int hc_key_roundtrip(const bev_params_t *p, float x, float y, float z, int label)
+{
+    const RasterParams rp = raster_params(p);
+    const uint32_t code = bev_code(x, y, z, label, rp);
+    const uint32_t key = candidate_key(ground_cell(x, y), 17, true, code, label, rp);
+    if ((key & kKeyCellMask) != (uint32_t)ground_cell(x, y) || ((key >> kKeyColShift) & 0xffu) != 17u || !(key & kKeyPredBit)) return 0;
+    if (((key & kKeyLabelM2Bit) != 0u) != (label == -2)) return 0;
+    if (code == kSkip) return (key & kKeyNoCodeBit) ? 1 : 0;
+    if (key & kKeyNoCodeBit) return 0;
+    if (candidate_key_escapes(key)) return 2;
+    return candidate_code(key, z, rp) == code ? 1 : 0;
+}
 
 uint32_t hc_bev_code(const bev_params_t *p, float x, float y, float z, int label)
 {
@@ -349,7 +374,7 @@ void hc_process_frame(const bev_params_t *p, const bev_point_t *in, uint32_t n_i
     ArrayFetch fetch{ordered};
     std::vector<int8_t> g(S);
     std::vector<uint32_t> codes(S);
-    struct Cand { uint32_t slot; float z; uint32_t code; int cell; int16_t label; };
+    struct Cand { uint32_t slot; float z; uint32_t key; int16_t label; };
     std::vector<Cand> cands;
     for (size_t s = 0; s < S; ++s) {
         const int row = (int)(s / H), col = (int)(s % H);
@@ -360,7 +385,10 @@ void hc_process_frame(const bev_params_t *p, const bev_point_t *in, uint32_t n_i
     if (gm_phase_a) memcpy(gm_phase_a, g.data(), S);
     for (size_t s = 0; s < S; ++s) {
         if (g[s] != 1) continue;
-        cands.push_back(Cand{(uint32_t)s, ordered[s].z, codes[s], ground_cell(ordered[s].x, ordered[s].y),
+        /* what the walk hands on per candidate: height + key (bev_exact.h); the column offset is not modelled here */
+        cands.push_back(Cand{(uint32_t)s, ordered[s].z,
+                             candidate_key(ground_cell(ordered[s].x, ordered[s].y), (int)(s % 252), false, codes[s],
+                                           (int)ordered[s].label, rp),
                              ordered[s].label});
         codes[s] = kSkip;
         ordered[s].label = 0;
@@ -369,17 +397,23 @@ void hc_process_frame(const bev_params_t *p, const bev_point_t *in, uint32_t n_i
     /* cell_sums: sequential float sums per cell in candidate (= slot) order */
     std::vector<float> sum(kGridCells, 0.0f), cnt(kGridCells, 0.01f), avg(kGridCells);
     for (const Cand &c : cands) {
-        sum[c.cell] += c.z;
-        cnt[c.cell] = cnt[c.cell] + 1.0f;
+        const int cell = (int)(c.key & kKeyCellMask);
+        sum[cell] += c.z;
+        cnt[cell] = cnt[cell] + 1.0f;
     }
     for (int k = 0; k < kGridCells; ++k) avg[k] = sum[k] / cnt[k];
     if (avg_out) memcpy(avg_out, avg.data(), sizeof(float) * kGridCells);
 
     /* ground_resolve */
     for (const Cand &c : cands) {
-        if (above_neighbour_ground(c.z, c.cell, avg.data())) {
+        if (above_neighbour_ground(c.z, (int)(c.key & kKeyCellMask), avg.data())) {
             ordered[c.slot].label = c.label;
-            codes[c.slot] = c.code;
+            /* the code comes back from key + height, as in k_ground_resolve */
+            if (c.key & kKeyNoCodeBit) codes[c.slot] = kSkip;
+            else if (candidate_key_escapes(c.key))
+                codes[c.slot] = bev_code(ordered[c.slot].x, ordered[c.slot].y, ordered[c.slot].z, 1, rp);
+            else { codes[c.slot] = candidate_code(c.key, c.z, rp); ++g_key_decodes; }
+            if (candidate_key_escapes(c.key)) ++g_key_escapes;
         }
     }
     /* ground_mat final */

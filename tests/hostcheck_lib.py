@@ -23,6 +23,9 @@ def lib():
         l.hc_ground_cell.argtypes = [C.c_float, C.c_float]
         l.hc_bev_code.argtypes = [C.POINTER(BevParams), C.c_float, C.c_float, C.c_float, C.c_int]
         l.hc_bev_code.restype = C.c_uint32
+        l.hc_key_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]
+        l.hc_key_stats.restype = None
+        l.hc_key_roundtrip.argtypes = [C.POINTER(BevParams), C.c_float, C.c_float, C.c_float, C.c_int]
         l.hc_process_frame.argtypes = [C.POINTER(BevParams), vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
         l.hc_process_frame.restype = None
         l.hc_libm_vs_host.argtypes = [C.c_uint64, vp]
@@ -126,3 +129,15 @@ def keyframe_labels(xyz, major):
     out = np.empty((len(xyz), len(major)), np.float32)
     lib().hc_keyframe_labels(xyz.ctypes.data, len(xyz), major.ctypes.data, len(major), out.ctypes.data)
     return out
+
+
+def key_stats(reset=True):
+    """(candidate codes rebuilt from key + height, candidates that took the escape path) in hc_process_frame so far"""
+    d, e = C.c_uint64(), C.c_uint64()
+    lib().hc_key_stats(C.byref(d), C.byref(e), 1 if reset else 0)
+    return int(d.value), int(e.value)
+
+
+def key_roundtrip(p: BevParams, x, y, z, label) -> int:
+    """0: wrong, 1: key + height reproduce bev_code (or flag 'no code'), 2: escape (the point itself is read)"""
+    return int(lib().hc_key_roundtrip(C.byref(p), float(x), float(y), float(z), int(label)))

@@ -32,7 +32,8 @@ def _json_line(stdout):
     return json.loads(lines[0])
 
 
-SMALL = ["--steps", "2", "--warmup", "1", "--frames", "96", "--sub-batch", "32", "--cpu-sample", "8"]
+# two sub-batches of the default size: the front of one overlaps the back of the other, as in the full run
+SMALL = ["--steps", "2", "--warmup", "1", "--frames", "512", "--cpu-sample", "8"]
 
 
 @pytest.mark.gpu
@@ -41,7 +42,7 @@ def test_json_line_has_roofline_and_cpu_baseline():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 1 and d["unit"] == "frames/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["config"]["frames_per_step"] == 96
+    assert d["config"]["frames_per_step"] == 512
     rf, cb = d["roofline"], d["cpu_baseline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["kernel"].startswith("k_")
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["pipeline"]["frac"] < 1
@@ -71,4 +72,4 @@ def test_two_ranks_over_rccl_when_the_box_has_two_gpus():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", *SMALL, "--no-cpu"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
-    assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 * 96 and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 * 512 and d["value"] > 0
