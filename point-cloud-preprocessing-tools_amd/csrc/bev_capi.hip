@@ -46,7 +46,7 @@ struct Lane {
     uint32_t win_gen = 0; /* generation tag of the last sub-batch that used this set's winner table */
     uint32_t *cand_key = nullptr;
     float *cand_z = nullptr;
-    uint32_t *ncand = nullptr;
+    uint32_t *ncand = nullptr, *seg_own = nullptr;
     uint32_t *code_main = nullptr, *ncode = nullptr; /* per-(strip, band) lists of final BEV codes */
     float *avg = nullptr;
     int8_t *gm = nullptr; /* lazily allocated */
@@ -161,8 +161,18 @@ void fill_geometry(const bev_params_t *p, Geometry *g)
     g->strips = (g->H + kStripCols - 1) / kStripCols;
     g->segs = (g->G + 1) * g->strips;
     g->parts = (g->segs + kPartSegs - 1) / kPartSegs;
-    g->raster_bands = raster_bands_for(mat_size_of(p));
-    g->band_rows = g->raster_bands ? mat_size_of(p) / g->raster_bands : 0;
+    {   /* raster bands: M / u rows each, the middle quarter of the image cut four times finer (bev_exact.h) */
+        const int M = mat_size_of(p), u = raster_bands_for(M);
+        const int coarse = u ? M / u : M;
+        const int fine = coarse % 4 == 0 ? coarse / 4 : coarse;
+        const int z0 = (3 * u / 8) * coarse, z1 = M - z0;
+        g->rp.coarse = coarse;
+        g->rp.fine = fine;
+        g->rp.z0 = z0;
+        g->rp.z1 = z1;
+        g->rp.bands = 2 * (z0 / coarse) + (z1 - z0) / fine;
+        g->raster_bands = g->rp.bands;
+    }
     g->code_cap = (uint32_t)g->N * (uint32_t)kStripCols;
     g->rp.max_range_f = (float)p->max_range;
     g->rp.interval = p->interval;
@@ -170,8 +180,6 @@ void fill_geometry(const bev_params_t *p, Geometry *g)
     g->rp.lidar_to_ground = p->lidar_to_ground;
     g->rp.mat_size = mat_size_of(p);
     g->rp.n_layers = p->n_layers;
-    g->rp.band_rows = g->band_rows;
-    g->rp.bands = g->raster_bands;
 }
 
 /* ---- profiling -------------------------------------------------------- */
@@ -306,6 +314,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.cand_key = ln.cand_key;
         b.cand_z = ln.cand_z;
         b.ncand = ln.ncand;
+        b.seg_own = ln.seg_own;
         b.code_main = ln.code_main;
         b.ncode = ln.ncode;
         b.avg = ln.avg;
@@ -530,6 +539,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipMalloc((void **)&ln.cand_key, nb * (size_t)c->geo.segs * kSeg * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.cand_z, nb * (size_t)c->geo.segs * kSeg * sizeof(float)));
         CK(hipMalloc((void **)&ln.ncand, nb * (size_t)c->geo.segs * sizeof(uint32_t)));
+        CK(hipMalloc((void **)&ln.seg_own, nb * (size_t)c->geo.segs * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.code_main, nb * (size_t)c->geo.strips * c->geo.raster_bands * c->geo.code_cap * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.ncode, nb * (size_t)c->geo.strips * c->geo.raster_bands * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.avg, nb * (size_t)bevx::kGridCells * sizeof(float)));
@@ -557,7 +567,7 @@ void bev_destroy(bev_ctx_t *c)
     for (int l = 0; l < kMaxLanes; ++l) {
         Lane &ln = c->lanes[l];
         if (ln.st) (void)hipStreamSynchronize(ln.st);
-        void *ws[] = {ln.winner, ln.cand_key, ln.cand_z, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
+        void *ws[] = {ln.winner, ln.cand_key, ln.cand_z, ln.ncand, ln.seg_own, ln.code_main, ln.ncode, ln.avg, ln.gm};
         for (void *p : ws)
             if (p) (void)hipFree(p);
         if (ln.done) (void)hipEventDestroy(ln.done);

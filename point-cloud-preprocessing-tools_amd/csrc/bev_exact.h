@@ -145,9 +145,29 @@ struct RasterParams {
     float lidar_to_ground; /* :269 */
     int mat_size;        /* :267 */
     int n_layers;        /* :268 */
-    int band_rows;       /* x bins per raster band (mat_size / bands): how the rasters are cut into workgroups, not part of the result */
-    int bands;
+    /* how the rasters are cut into x bands = workgroups (no influence on the result): coarse bands of `coarse` rows
+     * outside [z0, z1), fine ones of `fine` rows inside — most returns lie within a few tens of metres of the sensor,
+     * i.e. in the middle rows of the image, and uniform bands left two workgroups with 85 % of a frame's codes */
+    int bands, coarse, fine, z0, z1;
 };
+BEVX_HD int raster_band_of(int x, const RasterParams &rp)
+{
+    if (x < rp.z0) return x / rp.coarse;
+    if (x < rp.z1) return rp.z0 / rp.coarse + (x - rp.z0) / rp.fine;
+    return rp.z0 / rp.coarse + (rp.z1 - rp.z0) / rp.fine + (x - rp.z1) / rp.coarse;
+}
+BEVX_HD int raster_band_x0(int band, const RasterParams &rp)
+{
+    const int n0 = rp.z0 / rp.coarse, n1 = (rp.z1 - rp.z0) / rp.fine;
+    if (band < n0) return band * rp.coarse;
+    if (band < n0 + n1) return rp.z0 + (band - n0) * rp.fine;
+    return rp.z1 + (band - n0 - n1) * rp.coarse;
+}
+BEVX_HD int raster_band_rows(int band, const RasterParams &rp)
+{
+    const int n0 = rp.z0 / rp.coarse, n1 = (rp.z1 - rp.z0) / rp.fine;
+    return (band >= n0 && band < n0 + n1) ? rp.fine : rp.coarse;
+}
 
 /* (int)round((double)v + 0.5), half away from zero, without doubles.  d = v + 0.5 in double:
  *   v >= 0            : d is exact, round(d) = floor(d + 0.5) = floor(v) + 1
@@ -208,9 +228,9 @@ BEVX_HD uint32_t code_layer(uint32_t c) { return (c >> 26) & 31u; }
  *   bit  25      the point has no BEV code whatever phase C says (label 0 on input, or outside the raster)
  *   bit  26      the point's input label is -2 (what every producer writes, MulranPointCloudSelect.cpp:126): phase C
  *                can put it back without fetching the input point
- *   bits 27..30  owner: the raster band (x band of the BEV images) whose workgroup tests this candidate in phase C —
+ *   bits 27..31  owner: the raster band (x band of the BEV images) whose workgroup tests this candidate in phase C —
  *                the band its code falls into, so that the workgroup can rasterise it into its own planes; candidates
- *                without a code are dealt out by cell row; 15 = escape: every band's workgroup looks at the point
+ *                without a code are dealt out by cell row; 31 = escape: every band's workgroup looks at the point
  * A 2 m cell spans two or three 1 m bins, so together with the height the key reproduces the point's whole code
  * (layer and clamped height are functions of z alone).  Encoding and decoding are exact inverses by construction —
  * no assumption that the float roundings of x + 75 and x + 112 agree: when they do not, or the cell was clamped, the
@@ -224,7 +244,7 @@ constexpr uint32_t kKeyNoCodeBit = 1u << 25;
 constexpr uint32_t kKeyLabelM2Bit = 1u << 26;
 constexpr uint32_t kKeyEscape = 3u;
 constexpr int kKeyOwnerShift = 27;
-constexpr uint32_t kKeyOwnerAll = 15u;
+constexpr uint32_t kKeyOwnerAll = 31u;
 
 /* BEV bin of the lower edge of ground-grid row / column s (the edge is 2 * s - offset, exact in float) */
 BEVX_HD int cell_edge_bin(int s, float grid_offset, const RasterParams &rp)
@@ -240,7 +260,7 @@ BEVX_HD uint32_t candidate_key(int cell, int col_in_strip, bool pred, uint32_t c
     const int dx = (int)(code & 511u) - cell_edge_bin(cell / kGridCols, 75.0f, rp);
     const int dy = (int)((code >> 9) & 511u) - cell_edge_bin(cell % kGridCols, 50.0f, rp);
     const bool ok = dx >= 0 && dx < (int)kKeyEscape && dy >= 0 && dy < (int)kKeyEscape;
-    const uint32_t owner = ok ? (code & 511u) / (uint32_t)rp.band_rows : kKeyOwnerAll;
+    const uint32_t owner = ok ? (uint32_t)raster_band_of((int)(code & 511u), rp) : kKeyOwnerAll;
     return key | ((ok ? (uint32_t)dx : kKeyEscape) << kKeyDxShift) | ((ok ? (uint32_t)dy : kKeyEscape) << kKeyDyShift) |
            (owner << kKeyOwnerShift);
 }

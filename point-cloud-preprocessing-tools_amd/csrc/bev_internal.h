@@ -28,7 +28,7 @@ constexpr int kSegsPerWave = 4;                              /* segments a wave 
 constexpr int kPartSegs = kSumWaves * kSegsPerWave;          /* segments per part: 16 (4,096 candidates at most) */
 constexpr int kRasterThreads = 512;
 constexpr int kRasterSplit = 8;   /* x-bands per frame in the raster kernel at the reference's 224 x 224 (see raster_bands_for) */
-constexpr int kMaxBands = 16;     /* raster_bands_for never returns more */
+constexpr int kMaxBands = 32;     /* coarse + fine raster bands (see RasterParams) */
 constexpr int kMaxStrips = 264;   /* ceil(65535 / kStripCols) rounded up */
 
 /* per-frame launch metadata, copied H2D once per sub-batch */
@@ -56,8 +56,7 @@ struct Geometry {
     int strips;        /* ceil(H / kStripCols): column strips of the walk kernel */
     int segs;          /* (G + 1) * strips: candidate segments per frame, row-major */
     int parts;         /* ceil(segs / kPartSegs): parts k_cell_sums works through, in slot order */
-    int raster_bands;  /* x-bands per frame in the raster kernel: a band's two LDS planes must fit one CU */
-    int band_rows;     /* mat_size / raster_bands */
+    int raster_bands;  /* x-bands per frame in the raster kernel (= rp.bands: coarse ones outside, fine ones in the middle) */
     uint32_t code_cap; /* N * kStripCols: capacity of one (strip, band) code list */
     bevx::RasterParams rp;
 };
@@ -73,6 +72,7 @@ struct BatchPtrs {
     uint32_t *cand_key;          /* [nf][segs][kSeg] */
     float *cand_z;               /* [nf][segs][kSeg] */
     uint32_t *ncand;             /* [nf][segs] */
+    uint32_t *seg_own;           /* [nf][segs]: bit b set = the segment holds a candidate owned by raster band b */
     uint32_t *code_main;         /* [nf][strips][bands][code_cap] */
     uint32_t *ncode;             /* [nf][strips][bands] */
     float *avg;                  /* [nf][3750] */

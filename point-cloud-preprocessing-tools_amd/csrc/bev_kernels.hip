@@ -304,9 +304,10 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     __shared__ float4 edge[3][kWaves][4];                  /* rows r, r-1, (r-2): lanes 0, 1, 62, 63 of every wave */
     __shared__ uint32_t wave_cnt[2][kWaves];               /* per-wave candidate counts of the row being written */
     __shared__ uint32_t wave_own[2][kWaves];               /* ... and the raster bands that own them (bit per band) */
-    __shared__ uint32_t band_cnt[2][kMaxBands][kWaves];    /* per-wave code counts of that row, per raster band */
-    __shared__ uint32_t band_base[2][kMaxBands];           /* entries already in this strip's code list of each band */
-    if (tid < kMaxBands) band_base[0][tid] = 0u;
+    __shared__ uint32_t band_cursor[kMaxBands];            /* entries already in this strip's code list of each band */
+    __shared__ uint8_t band_tab[512];                      /* x bin -> raster band */
+    if (tid < kMaxBands) band_cursor[tid] = 0u;
+    for (int x = tid; x < g.rp.mat_size; x += kStripThreads) band_tab[x] = (uint8_t)raster_band_of(x, g.rp);
 
     /* Winner words are loaded UNCONDITIONALLY from a clamped address and decoded only when they are used, two rows
      * later: a predicated load whose result is decoded on the spot makes the compiler branch around the load and wait
@@ -359,8 +360,6 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     float zref = __uint_as_float(0x7fc00000u); /* height of the column's last candidate taken for ground (NaN: none yet) */
     unsigned long long m_ready = 0;     /* candidate ballot of row r-2 */
     uint32_t own_ready = 0;             /* row r-2: OR over this wave's candidates of (1 << owner band) */
-    unsigned long long cm_ready = 0;    /* row r-2: ballot of the lanes whose code goes to the same band as this lane's */
-    uint32_t bc_ready = 0;              /* row r-2: lane b < bands holds this wave's code count of band b */
 
     const size_t cand_base = (size_t)f * g.segs * kSeg;
     uint32_t *fncand = b.ncand + (size_t)f * g.segs;
@@ -389,7 +388,6 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
             wave_cnt[par][wv] = (uint32_t)__popcll(m_ready);
             wave_own[par][wv] = own_ready;
         }
-        if (lane < bands) band_cnt[par][lane][wv] = bc_ready;
         lds_barrier();
 
         /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
@@ -438,25 +436,11 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         if (cand1) {
             const int cell = ground_cell(__uint_as_float(p1.lo.w[0]), __uint_as_float(p1.lo.w[1]));
             p1.key = candidate_key(cell, tid - 2, p1.pred, p1.code, (int)(int16_t)(p1.hi.w[3] & 0xffffu), g.rp);
-            const uint32_t owner = (p1.key >> kKeyOwnerShift) & 15u;
-            own_new = owner == kKeyOwnerAll ? 0xffffu : (1u << owner);
+            const uint32_t owner = (p1.key >> kKeyOwnerShift) & 31u;
+            own_new = owner == kKeyOwnerAll ? 0xffffffffu : (1u << owner);
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) own_new |= __shfl_xor(own_new, d);
-        /* BEV codes of row r-1.  A slot that is not a candidate has its final label, so its code is final too: it goes
-         * to this strip's list of the raster band its x bin falls into.  Candidates' codes travel in their keys. */
-        unsigned long long cm_new = 0;
-        uint32_t bc_new = 0;
-        {
-            const bool has = outcol && !cand1 && p1.code != kSkip;
-            const int band = has ? code_x(p1.code) / g.band_rows : -1;
-            for (int bb = 0; bb < bands; ++bb) {
-                const unsigned long long m = __ballot(band == bb);
-                if (band == bb) cm_new = m;
-                if (lane == bb) bc_new = (uint32_t)__popcll(m);
-            }
-        }
-
         /* ---- write out row r-2 (its per-wave counts were published before the barrier) ---- */
         if (r >= 2) {
             const int q = r - 2;
@@ -478,23 +462,25 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
                     store_ws(&b.cand_key[at], p2.key);
                     store_ws(&b.cand_z[at], __uint_as_float(p2.lo.w[2]));
                 }
-                if (tid == 2) fncand[seg] = total | (own << 16); /* count (<= 252) | owner-band mask */
+                if (tid == 2) {
+                    fncand[seg] = total;
+                    b.seg_own[(size_t)f * g.segs + seg] = own; /* bit per raster band that owns a candidate of the segment */
+                }
             }
-            const bool has = outcol && !is_cand && p2.code != kSkip;
-            if (has) {
-                const int band = code_x(p2.code) / g.band_rows;
-                uint32_t before = 0;
-#pragma unroll
-                for (int w = 0; w < kWaves; ++w)
-                    if (w < wv) before += band_cnt[par][band][w];
-                const uint32_t pos = band_base[par][band] + before + (uint32_t)__popcll(cm_ready & ((1ull << lane) - 1ull));
-                store_ws(&flist[(size_t)band * g.code_cap + pos], p2.code);
-            }
-            if (tid < bands) {
-                uint32_t total = 0;
-#pragma unroll
-                for (int w = 0; w < kWaves; ++w) total += band_cnt[par][tid][w];
-                band_base[par ^ 1][tid] = band_base[par][tid] + total;
+            /* BEV code of the slot.  A slot that is not a candidate has its final label, so its code is final too: it
+             * is appended to this strip's list of the raster band its x bin falls into (the order inside a list does
+             * not matter: an LDS cursor per band).  Candidates' codes travel in their keys.  A lane whose left
+             * neighbour appends the very same code skips (near the sensor dozens of consecutive returns share a bin). */
+            {
+                bool has = outcol && !is_cand && p2.code != kSkip;
+                const uint32_t left_code = __shfl_up(p2.code, 1);
+                const bool left_has = __shfl_up(has ? 1 : 0, 1) != 0;
+                if (lane > 0 && left_has && left_code == p2.code) has = false;
+                if (has) {
+                    const int band = band_tab[code_x(p2.code)];
+                    const uint32_t pos = atomicAdd(&band_cursor[band], 1u);
+                    store_ws(&flist[(size_t)band * g.code_cap + pos], p2.code);
+                }
             }
             if (outcol) {
                 Half hi = p2.hi;
@@ -506,16 +492,12 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
                 store_stream(dst + 1, hi);
                 if (b.gm) b.gm[idx] = (int8_t)p2.gflag;
             }
-        } else if (tid < bands) {
-            band_base[par ^ 1][tid] = band_base[par][tid];
         }
 
         /* ---- shift the pipeline ---- */
         p2 = p1;
         m_ready = m_new;
         own_ready = own_new;
-        cm_ready = cm_new;
-        bc_ready = bc_new;
         p1.lo = cur_lo;
         p1.hi = cur_hi;
         p1.status = s_r;
@@ -535,7 +517,7 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         if (r0 + 5 < N + 2) row_step(std::integral_constant<int, 5>{}, r0 + 5);
     }
     lds_barrier();
-    if (tid < bands) b.ncode[((size_t)f * g.strips + strip) * bands + tid] = band_base[(N + 2) & 1][tid];
+    if (tid < bands) b.ncode[((size_t)f * g.strips + strip) * bands + tid] = band_cursor[tid];
 }
 
 /* getOrderedCloud alone (bev_order_cloud): no ground work. */
@@ -627,7 +609,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     /* software pipeline: counts two parts ahead, keys + heights one part ahead */
     auto load_counts = [&](int p) -> uint32_t { /* lane j < kSegsPerWave: count of this wave's segment j of part p */
         const int t = p * kPartSegs + wv * kSegsPerWave + lane;
-        return (p < P && lane < kSegsPerWave && t < T) ? (fn[t] & 0xffffu) : 0u; /* | band mask << 16 */
+        return (p < P && lane < kSegsPerWave && t < T) ? fn[t] : 0u;
     };
     uint32_t key_n[kSegsPerWave][kSl]; /* next part (raw keys; lanes past the segment's count hold garbage) */
     float z_n[kSegsPerWave][kSl];
@@ -871,16 +853,15 @@ __global__ __launch_bounds__(256) void k_cloud_codes(const bev_point_t *__restri
  * So phase C needs no kernel, list or atomic of its own, and nothing of a frame is handed from one workgroup to
  * another.  Finished planes leave with 16-byte stores, 1 KiB contiguous per wave-instruction.
  * When neither image is wanted (bev_mark_ground) the kernel still runs for the labels. */
-int raster_bands_for(int M)
+int raster_bands_for(int M) /* uniform bands whose two LDS planes fit; the coarse band height is M / this */
 {
-    for (int bands = kRasterSplit; bands <= kMaxBands; bands *= 2)
+    for (int bands = kRasterSplit; bands <= 16; bands *= 2)
         if (M % bands == 0 && (size_t)2 * (M / bands) * M * sizeof(uint32_t) <= (size_t)100 * 1024) return bands;
     return 0;
 }
 size_t raster_lds_bytes(const Geometry &g)
 {
-    const int M = g.rp.mat_size;
-    return (size_t)2 * (M / g.raster_bands) * M * sizeof(uint32_t);
+    return (size_t)2 * g.rp.coarse * g.rp.mat_size * sizeof(uint32_t);
 }
 
 /* one code into the band's LDS planes (the code is known to lie in the band) */
@@ -940,17 +921,18 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
     __shared__ int edge_x[kGridRows], edge_y[kGridCols]; /* BEV bin of every ground-grid row's / column's lower edge */
     __shared__ uint32_t list_end[kMaxStrips + 1];       /* inclusive prefix of this band's code-list lengths */
     __shared__ uint16_t seg_cnt[kMaxSegs];              /* candidates of the segments this band has to look at ... */
-    __shared__ uint16_t seg_id[kMaxSegs];               /* ... and which segments those are */
+    __shared__ uint16_t seg_id[kMaxSegs];               /* ... which segments those are ... */
+    __shared__ uint32_t seg_slot0[kMaxSegs];            /* ... and the slot of their strip's first column */
     __shared__ uint32_t n_mine;
-    const int M = g.rp.mat_size, L = g.rp.n_layers, bands = g.raster_bands, band_rows = g.band_rows;
-    const int cells = band_rows * M;
-    uint32_t *mask = lds;
-    uint32_t *hmax = lds + cells;
+    const int M = g.rp.mat_size, L = g.rp.n_layers, bands = g.raster_bands;
     /* the bands of a frame read the same candidate keys: ONE XCD (blocks b and b+8 share an L2), adjacent launch slots */
     const int xl = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int f = (jj / bands) * 8 + xl, band = jj % bands;
     if (f >= nf) return;
-    const int x0 = band * band_rows;
+    const int x0 = raster_band_x0(band, g.rp), band_rows = raster_band_rows(band, g.rp);
+    const int cells = band_rows * M;
+    uint32_t *mask = lds;
+    uint32_t *hmax = lds + cells;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     PH_DECL;
     PH();
@@ -971,11 +953,13 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
     /* the candidate segments that hold anything owned by this band (the walk left a band mask beside each count);
      * their order does not matter */
     for (int i = tid; i < g.segs; i += kRasterThreads) {
-        const uint32_t v = b.ncand[(size_t)f * g.segs + i];
-        if ((v & 0xffffu) != 0u && ((v >> (16 + band)) & 1u)) {
+        const uint32_t v = b.ncand[(size_t)f * g.segs + i], own = b.seg_own[(size_t)f * g.segs + i];
+        if (v != 0u && ((own >> band) & 1u)) {
             const uint32_t at = atomicAdd(&n_mine, 1u);
-            seg_cnt[at] = (uint16_t)(v & 0xffffu);
+            seg_cnt[at] = (uint16_t)v;
             seg_id[at] = (uint16_t)i;
+            const int rr = i / g.strips, strip = i - rr * g.strips;
+            seg_slot0[at] = (uint32_t)((rr + g.N - g.G - 1) * g.H + strip * kStripCols);
         }
     }
     lds_barrier();
@@ -987,6 +971,9 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
         constexpr int kU = 8;
         const uint32_t total = list_end[g.strips];
         const uint32_t *fmain = b.code_main + (size_t)f * g.strips * bands * g.code_cap;
+        uint32_t ends[16]; /* ends[j] = first index of strip j's list (j >= 1) */
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ends[j] = __builtin_amdgcn_readfirstlane(j <= g.strips ? list_end[j] : 0u);
         for (uint32_t i0 = 0; i0 < total; i0 += kU * kRasterThreads) {
             uint32_t c[kU];
 #pragma unroll
@@ -995,8 +982,14 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
                 c[k] = kSkip;
                 if (i < total) {
                     int e = 0;
-                    if (g.strips <= 16) {
-                        while (list_end[e + 1] <= i) ++e;
+                    uint32_t e0 = 0u;
+                    if (g.strips <= 16) { /* the list ends are wave-uniform: scalar compares, no dependent LDS reads */
+#pragma unroll
+                        for (int j = 1; j < 16; ++j) {
+                            const bool past = j < g.strips && i >= ends[j];
+                            e += past ? 1 : 0;
+                            e0 = past ? ends[j] : e0;
+                        }
                     } else {
                         int lo = 0, hi = g.strips - 1; /* first e with list_end[e + 1] > i */
                         while (lo < hi) {
@@ -1004,8 +997,9 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
                             if (list_end[mid + 1] > i) hi = mid; else lo = mid + 1;
                         }
                         e = lo;
+                        e0 = list_end[e];
                     }
-                    c[k] = fmain[((size_t)e * bands + band) * g.code_cap + (i - list_end[e])];
+                    c[k] = fmain[((size_t)e * bands + band) * g.code_cap + (i - e0)];
                 }
             }
 #pragma unroll
@@ -1020,7 +1014,6 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
         constexpr int kSl = kSeg / 64;
         const uint32_t *fkey = b.cand_key + (size_t)f * g.segs * kSeg;
         const float *fz = b.cand_z + (size_t)f * g.segs * kSeg;
-        const int lo_row = g.N - g.G;
         const int n_segs = (int)n_mine;
         for (int s0 = wv; s0 < n_segs; s0 += kRasterWaves * kCandBatch) {
             uint32_t key[kCandBatch][kSl];
@@ -1028,35 +1021,37 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
 #pragma unroll
             for (int j = 0; j < kCandBatch; ++j) {
                 const int q = s0 + j * kRasterWaves;
-                const int n = q < n_segs ? (int)seg_cnt[q] : 0;
+                const int n = q < n_segs ? (int)seg_cnt[q] : 0;   /* wave-uniform */
                 const int sg = q < n_segs ? (int)seg_id[q] : 0;
 #pragma unroll
-                for (int k = 0; k < kSl; ++k) {
-                    const bool have = lane + 64 * k < n;
+                for (int k = 0; k < kSl; ++k) { /* whole slices, nothing but the loads inside the uniform test (see k_cell_sums) */
                     const size_t at = (size_t)sg * kSeg + lane + 64 * k;
-                    key[j][k] = have ? fkey[at] : 0xffffffffu;
-                    z[j][k] = have ? fz[at] : 0.f;
+                    key[j][k] = 0xffffffffu;
+                    z[j][k] = 0.f;
+                    if (64 * k < __builtin_amdgcn_readfirstlane(n)) {
+                        key[j][k] = fkey[at];
+                        z[j][k] = fz[at];
+                    }
                 }
             }
 #pragma unroll
             for (int j = 0; j < kCandBatch; ++j) {
                 const int q = s0 + j * kRasterWaves;
                 const int n = q < n_segs ? (int)seg_cnt[q] : 0;
-                const int sg = q < n_segs ? (int)seg_id[q] : 0;
 #pragma unroll
                 for (int k = 0; k < kSl; ++k) {
                     if (64 * k >= n) break; /* wave-uniform */
                     const uint32_t kk = key[j][k];
                     const bool have = lane + 64 * k < n;
-                    const uint32_t owner = (kk >> kKeyOwnerShift) & 15u;
+                    const uint32_t owner = (kk >> kKeyOwnerShift) & 31u;
                     const bool all = owner == kKeyOwnerAll;
-                    if (!have || !(owner == (uint32_t)band || all)) continue;
+                    const bool mine = have && (owner == (uint32_t)band || all);
+                    if (!__ballot(mine)) continue; /* wave-uniform: nothing of this slice belongs to the band */
+                    if (!mine) continue;
                     const int cell = (int)(kk & kKeyCellMask);
                     const bool hit = above_neighbour_ground(z[j][k], cell, avg);
                     const bool pred = (kk & kKeyPredBit) != 0u;
-                    const int rr = sg / g.strips, strip = sg - rr * g.strips;
-                    const size_t idx = (size_t)f * g.S + (size_t)(rr + lo_row - 1) * g.H + (size_t)strip * kStripCols +
-                                       ((kk >> kKeyColShift) & 0xffu);
+                    const size_t idx = (size_t)f * g.S + seg_slot0[q] + ((kk >> kKeyColShift) & 0xffu);
                     if (hit && !(kk & kKeyNoCodeBit)) {
                         if (!all) {
                             splat_code(bev_code_from_bins(edge_x[cell / kGridCols] + (int)((kk >> kKeyDxShift) & 3u),
@@ -1091,18 +1086,19 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
     store_planes(mask, hmax, want_multi ? b.multi : nullptr, want_single ? b.single : nullptr, f, x0, band_rows, M, L, tid,
                  kRasterThreads);
     PH();
-    PH_PRINT(band == 3 ? "raster3 setup codes cands stores" : "raster0 setup codes cands stores", tid == 0 && (blockIdx.x == 800 - 8 || blockIdx.x == 800 - 32));
+    PH_PRINT(band == 7 ? "raster7 setup codes cands stores" : "raster1 setup codes cands stores", tid == 0 && f == 100 && (band == 7 || band == 1));
 }
 
 /* rasters of ONE arbitrary cloud from a dense code array (bev_multi_bev / bev_single_bev): every band scans all codes */
 __global__ __launch_bounds__(kRasterThreads) void k_bev_raster_dense(const uint32_t *__restrict__ codes, uint32_t n,
                                                                     uint8_t *__restrict__ multi, uint8_t *__restrict__ single,
-                                                                    int M, int L, int bands)
+                                                                    RasterParams rp)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int band_rows = M / bands, cells = band_rows * M;
+    const int M = rp.mat_size, L = rp.n_layers;
+    const int band = blockIdx.x, x0 = raster_band_x0(band, rp), band_rows = raster_band_rows(band, rp), tid = threadIdx.x;
+    const int cells = band_rows * M;
     uint32_t *mask = lds, *hmax = lds + cells;
-    const int band = blockIdx.x, x0 = band * band_rows, tid = threadIdx.x;
     for (int k = tid; k < 2 * cells; k += kRasterThreads) lds[k] = 0u;
     __syncthreads();
     constexpr int kU = 8;
@@ -1358,7 +1354,7 @@ void launch_bev_raster_dense(const Geometry &g, const uint32_t *codes, uint32_t 
                              hipStream_t st)
 {
     hipLaunchKernelGGL(k_bev_raster_dense, dim3(g.raster_bands), dim3(kRasterThreads), raster_lds_bytes(g), st, codes,
-                       n_codes, multi, single, g.rp.mat_size, g.rp.n_layers, g.raster_bands);
+                       n_codes, multi, single, g.rp);
 }
 void launch_ground_mat(const Geometry &g, const BatchPtrs &b, int8_t *out, int nf, hipStream_t st)
 {

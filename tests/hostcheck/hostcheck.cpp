@@ -36,8 +36,12 @@ RasterParams raster_params(const bev_params_t *p)
     rp.lidar_to_ground = p->lidar_to_ground;
     rp.mat_size = cvtt_f32((float)(p->max_range * 2) / p->interval);
     rp.n_layers = p->n_layers;
-    rp.bands = 8; /* how the device cuts the images into workgroups; results do not depend on it */
-    rp.band_rows = rp.mat_size / rp.bands > 0 ? rp.mat_size / rp.bands : 1;
+    /* how the device cuts the images into workgroups (bev_capi.hip fill_geometry); results do not depend on it */
+    rp.coarse = rp.mat_size >= 8 ? rp.mat_size / 8 : 1;
+    rp.fine = rp.coarse % 4 == 0 ? rp.coarse / 4 : rp.coarse;
+    rp.z0 = 3 * rp.coarse;
+    rp.z1 = rp.mat_size - rp.z0;
+    rp.bands = 2 * (rp.z0 / rp.coarse) + (rp.z1 - rp.z0) / rp.fine;
     return rp;
 }
 } // namespace
