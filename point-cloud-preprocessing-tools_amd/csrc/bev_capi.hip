@@ -46,7 +46,7 @@ struct Lane {
     uint32_t win_gen = 0; /* generation tag of the last sub-batch that used this set's winner table */
     uint32_t *cand_key = nullptr;
     float *cand_z = nullptr;
-    uint32_t *ncand = nullptr, *seg_own = nullptr;
+    uint32_t *ncand = nullptr;
     uint32_t *code_main = nullptr, *ncode = nullptr; /* per-(strip, band) lists of final BEV codes */
     float *avg = nullptr;
     int8_t *gm = nullptr; /* lazily allocated */
@@ -173,7 +173,8 @@ void fill_geometry(const bev_params_t *p, Geometry *g)
         g->rp.bands = 2 * (z0 / coarse) + (z1 - z0) / fine;
         g->raster_bands = g->rp.bands;
     }
-    g->code_cap = (uint32_t)g->N * (uint32_t)kStripCols;
+    g->emitters = g->strips + kResolveParts;
+    g->code_cap = std::max((uint32_t)g->N * (uint32_t)kStripCols, (uint32_t)((g->segs + kResolveParts - 1) / kResolveParts + 1) * (uint32_t)kSeg);
     g->rp.max_range_f = (float)p->max_range;
     g->rp.interval = p->interval;
     g->rp.height_res = p->height_res;
@@ -314,7 +315,6 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.cand_key = ln.cand_key;
         b.cand_z = ln.cand_z;
         b.ncand = ln.ncand;
-        b.seg_own = ln.seg_own;
         b.code_main = ln.code_main;
         b.ncode = ln.ncode;
         b.avg = ln.avg;
@@ -370,9 +370,13 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             ProfScope ps(c, K_GROUND_MAT, nb, st);
             launch_ground_mat(g, b, d_gm + (size_t)f0 * S, nb, st);
         }
-        {   /* phase C for the candidates (labels) + both rasters */
+        {   /* phase C for the candidates: labels, codes of the un-grounded ones */
+            ProfScope ps(c, K_GROUND_RESOLVE, nb, st);
+            launch_ground_resolve(g, b, nb, identity, st);
+        }
+        if (d_multi || d_single) {
             ProfScope ps(c, K_BEV_RASTER, nb, st);
-            launch_bev_raster(g, b, d_multi != nullptr, d_single != nullptr, nb, identity, st);
+            launch_bev_raster(g, b, d_multi != nullptr, d_single != nullptr, nb, st);
         }
         HIPCK(c, hipEventRecord(ln.back_done, st));
         c->last_sub_frames = nb;
@@ -539,9 +543,8 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipMalloc((void **)&ln.cand_key, nb * (size_t)c->geo.segs * kSeg * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.cand_z, nb * (size_t)c->geo.segs * kSeg * sizeof(float)));
         CK(hipMalloc((void **)&ln.ncand, nb * (size_t)c->geo.segs * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.seg_own, nb * (size_t)c->geo.segs * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.code_main, nb * (size_t)c->geo.strips * c->geo.raster_bands * c->geo.code_cap * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.ncode, nb * (size_t)c->geo.strips * c->geo.raster_bands * sizeof(uint32_t)));
+        CK(hipMalloc((void **)&ln.code_main, nb * (size_t)c->geo.emitters * c->geo.raster_bands * c->geo.code_cap * sizeof(uint32_t)));
+        CK(hipMalloc((void **)&ln.ncode, nb * (size_t)c->geo.emitters * c->geo.raster_bands * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.avg, nb * (size_t)bevx::kGridCells * sizeof(float)));
     }
     c->winner = c->lanes[0].winner;
@@ -567,7 +570,7 @@ void bev_destroy(bev_ctx_t *c)
     for (int l = 0; l < kMaxLanes; ++l) {
         Lane &ln = c->lanes[l];
         if (ln.st) (void)hipStreamSynchronize(ln.st);
-        void *ws[] = {ln.winner, ln.cand_key, ln.cand_z, ln.ncand, ln.seg_own, ln.code_main, ln.ncode, ln.avg, ln.gm};
+        void *ws[] = {ln.winner, ln.cand_key, ln.cand_z, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
         for (void *p : ws)
             if (p) (void)hipFree(p);
         if (ln.done) (void)hipEventDestroy(ln.done);

@@ -228,9 +228,6 @@ BEVX_HD uint32_t code_layer(uint32_t c) { return (c >> 26) & 31u; }
  *   bit  25      the point has no BEV code whatever phase C says (label 0 on input, or outside the raster)
  *   bit  26      the point's input label is -2 (what every producer writes, MulranPointCloudSelect.cpp:126): phase C
  *                can put it back without fetching the input point
- *   bits 27..31  owner: the raster band (x band of the BEV images) whose workgroup tests this candidate in phase C —
- *                the band its code falls into, so that the workgroup can rasterise it into its own planes; candidates
- *                without a code are dealt out by cell row; 31 = escape: every band's workgroup looks at the point
  * A 2 m cell spans two or three 1 m bins, so together with the height the key reproduces the point's whole code
  * (layer and clamped height are functions of z alone).  Encoding and decoding are exact inverses by construction —
  * no assumption that the float roundings of x + 75 and x + 112 agree: when they do not, or the cell was clamped, the
@@ -243,8 +240,6 @@ constexpr int kKeyDxShift = 21, kKeyDyShift = 23;
 constexpr uint32_t kKeyNoCodeBit = 1u << 25;
 constexpr uint32_t kKeyLabelM2Bit = 1u << 26;
 constexpr uint32_t kKeyEscape = 3u;
-constexpr int kKeyOwnerShift = 27;
-constexpr uint32_t kKeyOwnerAll = 31u;
 
 /* BEV bin of the lower edge of ground-grid row / column s (the edge is 2 * s - offset, exact in float) */
 BEVX_HD int cell_edge_bin(int s, float grid_offset, const RasterParams &rp)
@@ -255,14 +250,11 @@ BEVX_HD uint32_t candidate_key(int cell, int col_in_strip, bool pred, uint32_t c
 {
     uint32_t key = (uint32_t)cell | ((uint32_t)col_in_strip << kKeyColShift) | (pred ? kKeyPredBit : 0u) |
                    (label == -2 ? kKeyLabelM2Bit : 0u);
-    if (code == kSkip) /* only its label can change: any one band will do */
-        return key | kKeyNoCodeBit | ((uint32_t)((cell / kGridCols) * rp.bands / kGridRows) << kKeyOwnerShift);
+    if (code == kSkip) return key | kKeyNoCodeBit;
     const int dx = (int)(code & 511u) - cell_edge_bin(cell / kGridCols, 75.0f, rp);
     const int dy = (int)((code >> 9) & 511u) - cell_edge_bin(cell % kGridCols, 50.0f, rp);
     const bool ok = dx >= 0 && dx < (int)kKeyEscape && dy >= 0 && dy < (int)kKeyEscape;
-    const uint32_t owner = ok ? (uint32_t)raster_band_of((int)(code & 511u), rp) : kKeyOwnerAll;
-    return key | ((ok ? (uint32_t)dx : kKeyEscape) << kKeyDxShift) | ((ok ? (uint32_t)dy : kKeyEscape) << kKeyDyShift) |
-           (owner << kKeyOwnerShift);
+    return key | ((ok ? (uint32_t)dx : kKeyEscape) << kKeyDxShift) | ((ok ? (uint32_t)dy : kKeyEscape) << kKeyDyShift);
 }
 /* the code of a candidate whose key is not an escape and has no kKeyNoCodeBit */
 BEVX_HD uint32_t candidate_code(uint32_t key, float z, const RasterParams &rp)

@@ -26,6 +26,8 @@ constexpr int kSumWaves = 4;      /* waves of the per-frame cell-sum workgroup: 
 constexpr int kSumThreads = kSumWaves * 64;
 constexpr int kSegsPerWave = 4;                              /* segments a wave keeps in registers per part */
 constexpr int kPartSegs = kSumWaves * kSegsPerWave;          /* segments per part: 16 (4,096 candidates at most) */
+constexpr int kResolveThreads = 256;
+constexpr int kResolveParts = 4;  /* workgroups per frame in k_ground_resolve, each with its own code lists */
 constexpr int kRasterThreads = 512;
 constexpr int kRasterSplit = 8;   /* x-bands per frame in the raster kernel at the reference's 224 x 224 (see raster_bands_for) */
 constexpr int kMaxBands = 32;     /* coarse + fine raster bands (see RasterParams) */
@@ -42,11 +44,11 @@ struct FrameDesc {
  *   cand_key u32 / cand_z f32  [nf][segs][kSeg]   candidates, one segment per (row, strip), compacted in column order;
  *                                                  segments in row-major order => concatenation = slot order
  *   ncand u32                  [nf][segs]
- *   code_main u32              [nf][strips][bands][N * kStripCols]   BEV codes of the slots that are NOT candidates
+ *   code_main u32              [nf][emitters][bands][code_cap]   BEV codes of the slots that are NOT candidates
  *                                                  (final when the walk writes them), one list per raster band, appended
  *                                                  row by row by the strip's workgroup (no atomics)
- *   ncode u32                  [nf][strips][bands]
- * Candidates reach the rasters through their keys: k_bev_raster tests them (phase C) and rasterises the un-grounded ones. */
+ *   ncode u32                  [nf][emitters][bands]
+ *   (k_ground_resolve appends the codes of the candidates phase C un-grounds to lists of the same kind, one set per part) */
 static_assert(sizeof(bev_point_t) == 32, "bev_point_t must be 32 bytes");
 
 struct Geometry {
@@ -57,7 +59,8 @@ struct Geometry {
     int segs;          /* (G + 1) * strips: candidate segments per frame, row-major */
     int parts;         /* ceil(segs / kPartSegs): parts k_cell_sums works through, in slot order */
     int raster_bands;  /* x-bands per frame in the raster kernel (= rp.bands: coarse ones outside, fine ones in the middle) */
-    uint32_t code_cap; /* N * kStripCols: capacity of one (strip, band) code list */
+    int emitters;      /* strips + kResolveParts: writers of code lists per frame (the walk's strips, the resolve's parts) */
+    uint32_t code_cap; /* capacity of one (emitter, band) code list: max(N * kStripCols, candidates of a resolve part) */
     bevx::RasterParams rp;
 };
 
@@ -72,9 +75,8 @@ struct BatchPtrs {
     uint32_t *cand_key;          /* [nf][segs][kSeg] */
     float *cand_z;               /* [nf][segs][kSeg] */
     uint32_t *ncand;             /* [nf][segs] */
-    uint32_t *seg_own;           /* [nf][segs]: bit b set = the segment holds a candidate owned by raster band b */
-    uint32_t *code_main;         /* [nf][strips][bands][code_cap] */
-    uint32_t *ncode;             /* [nf][strips][bands] */
+    uint32_t *code_main;         /* [nf][emitters][bands][code_cap] */
+    uint32_t *ncode;             /* [nf][emitters][bands] */
     float *avg;                  /* [nf][3750] */
     int8_t *gm;                  /* [nf][S] or nullptr: phase-A ground_mat */
     uint8_t *multi;              /* [nf][L*M*M] */
@@ -85,6 +87,7 @@ enum KernelId {
     K_ORDER_SCAN = 0,
     K_GATHER_GROUND,
     K_CELL_SUMS,
+    K_GROUND_RESOLVE,
     K_BEV_RASTER,
     K_GATHER_ONLY,
     K_GROUND_MAT,
@@ -105,10 +108,9 @@ void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t m
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st);
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
 void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
-/* phase C for the candidates (labels) + the rasters of a sub-batch from its code lists and candidates; runs even when no
- * image is wanted (labels) */
-void launch_bev_raster(const Geometry &g, const BatchPtrs &b, bool want_multi, bool want_single, int nf, bool identity,
-                       hipStream_t st);
+void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st);
+/* the rasters of a sub-batch from its code lists */
+void launch_bev_raster(const Geometry &g, const BatchPtrs &b, bool want_multi, bool want_single, int nf, hipStream_t st);
 /* rasters of ONE arbitrary cloud from a dense code array (bev_multi_bev / bev_single_bev) */
 void launch_bev_raster_dense(const Geometry &g, const uint32_t *codes, uint32_t n_codes, uint8_t *multi, uint8_t *single,
                              hipStream_t st);

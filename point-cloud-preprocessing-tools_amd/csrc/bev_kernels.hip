@@ -57,7 +57,7 @@ using namespace bevx;
 namespace bevk {
 
 static const char *const kNames[K_COUNT] = {
-    "k_order_scan", "k_strip_ground", "k_cell_sums", "k_bev_raster",
+    "k_order_scan", "k_strip_ground", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project", "k_transform",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
@@ -127,6 +127,7 @@ __device__ __forceinline__ uint32_t winner_index(uint32_t w, uint32_t tag, int s
 /* ------------------------------------------------------------------------- */
 /* getOrderedCloud, BatchMultiBevGen.cpp:102-116: bounds test + slot index;
  * "last point in input order wins" == max input index per slot.            */
+constexpr int kSeenBits = 11, kSeenCodes = 1 << kSeenBits; /* the walk's memo of listed BEV codes: 8 KB of LDS */
 constexpr int kScanPerThread = 4;
 constexpr int kScanIdxBits = 10; /* 256 * kScanPerThread = 1024 points per block */
 constexpr int kScanRowBins = 128; /* rows the LDS regrouping below can bin (more rows: plain path) */
@@ -303,10 +304,11 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     constexpr int kWaves = kStripThreads / 64;
     __shared__ float4 edge[3][kWaves][4];                  /* rows r, r-1, (r-2): lanes 0, 1, 62, 63 of every wave */
     __shared__ uint32_t wave_cnt[2][kWaves];               /* per-wave candidate counts of the row being written */
-    __shared__ uint32_t wave_own[2][kWaves];               /* ... and the raster bands that own them (bit per band) */
     __shared__ uint32_t band_cursor[kMaxBands];            /* entries already in this strip's code list of each band */
     __shared__ uint8_t band_tab[512];                      /* x bin -> raster band */
+    __shared__ uint32_t seen[kSeenCodes];                  /* direct-mapped memo of codes this strip has already listed */
     if (tid < kMaxBands) band_cursor[tid] = 0u;
+    for (int k = tid; k < kSeenCodes; k += kStripThreads) seen[k] = kSkip;
     for (int x = tid; x < g.rp.mat_size; x += kStripThreads) band_tab[x] = (uint8_t)raster_band_of(x, g.rp);
 
     /* Winner words are loaded UNCONDITIONALLY from a clamped address and decoded only when they are used, two rows
@@ -359,11 +361,10 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     PendingRow p1{}, p2{};              /* rows r-1 (ground flag still open) and r-2 (ready to write) */
     float zref = __uint_as_float(0x7fc00000u); /* height of the column's last candidate taken for ground (NaN: none yet) */
     unsigned long long m_ready = 0;     /* candidate ballot of row r-2 */
-    uint32_t own_ready = 0;             /* row r-2: OR over this wave's candidates of (1 << owner band) */
 
     const size_t cand_base = (size_t)f * g.segs * kSeg;
     uint32_t *fncand = b.ncand + (size_t)f * g.segs;
-    uint32_t *flist = b.code_main + ((size_t)f * g.strips + strip) * bands * (size_t)g.code_cap;
+    uint32_t *flist = b.code_main + ((size_t)f * g.emitters + strip) * bands * (size_t)g.code_cap;
 
     /* one row; I = r mod 6 at compile time */
     auto row_step = [&](auto I, const int r) {
@@ -384,10 +385,7 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         const XYZI cur{__uint_as_float(cur_lo.w[0]), __uint_as_float(cur_lo.w[1]), __uint_as_float(cur_lo.w[2]),
                        __uint_as_float(cur_hi.w[0])};
         if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
-        if (lane == 0) {
-            wave_cnt[par][wv] = (uint32_t)__popcll(m_ready);
-            wave_own[par][wv] = own_ready;
-        }
+        if (lane == 0) wave_cnt[par][wv] = (uint32_t)__popcll(m_ready);
         lds_barrier();
 
         /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
@@ -430,30 +428,23 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
             p1.pred = cand1 && (zq - zref >= 0.3f); /* false while zref is NaN */
             if (cand1 && !p1.pred) zref = zq;
         }
-        /* the candidate's key, and which raster bands own candidates of this (row, strip) segment: k_bev_raster's
-         * workgroup of band b only reads segments whose mask has bit b (an escape key is everybody's) */
-        uint32_t own_new = 0u;
         if (cand1) {
             const int cell = ground_cell(__uint_as_float(p1.lo.w[0]), __uint_as_float(p1.lo.w[1]));
             p1.key = candidate_key(cell, tid - 2, p1.pred, p1.code, (int)(int16_t)(p1.hi.w[3] & 0xffffu), g.rp);
-            const uint32_t owner = (p1.key >> kKeyOwnerShift) & 31u;
-            own_new = owner == kKeyOwnerAll ? 0xffffffffu : (1u << owner);
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) own_new |= __shfl_xor(own_new, d);
+
         /* ---- write out row r-2 (its per-wave counts were published before the barrier) ---- */
         if (r >= 2) {
             const int q = r - 2;
             const bool is_cand = outcol && p2.gflag == 1;
             const int rr = q - (lo_row - 1);        /* only rows lo-1 .. N-1 can hold candidates */
             if (rr >= 0) {
-                uint32_t before = 0, total = 0, own = 0;
+                uint32_t before = 0, total = 0;
 #pragma unroll
                 for (int w = 0; w < kWaves; ++w) {
                     const uint32_t c = wave_cnt[par][w];
                     if (w < wv) before += c;
                     total += c;
-                    own |= wave_own[par][w];
                 }
                 const size_t seg = (size_t)rr * g.strips + strip;
                 if (is_cand) {
@@ -462,10 +453,7 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
                     store_ws(&b.cand_key[at], p2.key);
                     store_ws(&b.cand_z[at], __uint_as_float(p2.lo.w[2]));
                 }
-                if (tid == 2) {
-                    fncand[seg] = total;
-                    b.seg_own[(size_t)f * g.segs + seg] = own; /* bit per raster band that owns a candidate of the segment */
-                }
+                if (tid == 2) fncand[seg] = total;
             }
             /* BEV code of the slot.  A slot that is not a candidate has its final label, so its code is final too: it
              * is appended to this strip's list of the raster band its x bin falls into (the order inside a list does
@@ -476,6 +464,14 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
                 const uint32_t left_code = __shfl_up(p2.code, 1);
                 const bool left_has = __shfl_up(has ? 1 : 0, 1) != 0;
                 if (lane > 0 && left_has && left_code == p2.code) has = false;
+                /* ... and so does one whose code this strip has listed before and still remembers (rings hit the same
+                 * cells at the same heights again and again: a HDL_64E frame lists 74 k codes of which 24 k are
+                 * distinct).  The rasters are idempotent, so a stale or racing memo entry only costs a duplicate. */
+                if (has) {
+                    const uint32_t slot = (p2.code * 0x9E3779B1u) >> (32 - kSeenBits);
+                    if (seen[slot] == p2.code) has = false;
+                    else seen[slot] = p2.code;
+                }
                 if (has) {
                     const int band = band_tab[code_x(p2.code)];
                     const uint32_t pos = atomicAdd(&band_cursor[band], 1u);
@@ -497,7 +493,6 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         /* ---- shift the pipeline ---- */
         p2 = p1;
         m_ready = m_new;
-        own_ready = own_new;
         p1.lo = cur_lo;
         p1.hi = cur_hi;
         p1.status = s_r;
@@ -517,7 +512,7 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         if (r0 + 5 < N + 2) row_step(std::integral_constant<int, 5>{}, r0 + 5);
     }
     lds_barrier();
-    if (tid < bands) b.ncode[((size_t)f * g.strips + strip) * bands + tid] = band_cursor[tid];
+    if (tid < bands) b.ncode[((size_t)f * g.emitters + strip) * bands + tid] = band_cursor[tid];
 }
 
 /* getOrderedCloud alone (bev_order_cloud): no ground work. */
@@ -839,20 +834,116 @@ __global__ __launch_bounds__(256) void k_cloud_codes(const bev_point_t *__restri
 }
 
 /* ------------------------------------------------------------------------- */
-/* markGroundPoints phase C for the candidates (BatchMultiBevGen.cpp:216-250) and both rasters (:271-292 occupancy,
- * 24 layers; :340-356 uint8 max height), one workgroup per (frame, x-band of the images).
- *
- * The band's 24-bit layer masks and max heights live in LDS (two planes of band_rows x M words).  Its inputs:
- *   - the walk's code lists of this band (one per strip): slots that are not candidates, final codes;
- *   - the frame's candidates (key + height).  A candidate that is higher than a neighbour cell's average + 0.30 stops
- *     being ground ("hit"): it keeps / gets back its own label and contributes its BEV code, rebuilt from key and
- *     height (bev_exact.h).  Every workgroup of the frame reads all keys, but only the candidate's OWNER band (key
- *     bits 27..30: the band its code falls into) tests it, rasterises it and, where the walk's provisional label was
- *     a wrong guess, patches the label in the ordered cloud.  Keys that could not carry their bins (escapes) are
- *     looked at by every band: each reads the point and rasterises it if it falls into its own rows; band 0 patches.
- * So phase C needs no kernel, list or atomic of its own, and nothing of a frame is handed from one workgroup to
- * another.  Finished planes leave with 16-byte stores, 1 KiB contiguous per wave-instruction.
- * When neither image is wanted (bev_mark_ground) the kernel still runs for the labels. */
+/* markGroundPoints phase C for the candidates, BatchMultiBevGen.cpp:216-250.  A candidate that is higher than a
+ * neighbour cell's average + 0.30 stops being ground ("hit"): it keeps / gets back its own label, and its BEV code —
+ * rebuilt from key and height, bev_exact.h — is appended to a code list of the raster band it falls into, exactly like
+ * the walk's lists (an LDS cursor per band, no global atomics): k_bev_raster reads both kinds the same way.  The walk
+ * wrote each candidate's label for its guess (key bit kKeyPredBit); only wrong guesses are patched.
+ * kResolveParts workgroups per frame, each takes a contiguous quarter of the segments; a wave requests kResolveBatch
+ * segments (x 4 slices of 64 candidates) at a time. */
+constexpr int kResolveBatch = 4;
+template <bool kIdentity>
+__global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b, Geometry g)
+{
+    __shared__ float avg[kCells];                        /* the frame's 75 x 50 averages: 4 look-ups per candidate */
+    __shared__ int edge_x[kGridRows], edge_y[kGridCols]; /* BEV bin of every ground-grid row's / column's lower edge */
+    __shared__ uint32_t band_cursor[kMaxBands];
+    __shared__ uint8_t band_tab[512];                    /* x bin -> raster band */
+    __shared__ uint16_t cnt[kMaxSegs / kResolveParts + 8];
+    const int f = blockIdx.x / kResolveParts, part = blockIdx.x - f * kResolveParts;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int T = g.segs;
+    const int t0 = (int)((long long)T * part / kResolveParts), t1 = (int)((long long)T * (part + 1) / kResolveParts);
+    for (int i = tid; i < t1 - t0; i += kResolveThreads) cnt[i] = (uint16_t)b.ncand[(size_t)f * T + t0 + i];
+    for (int c = tid; c < kCells; c += kResolveThreads) avg[c] = b.avg[(size_t)f * kCells + c];
+    if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
+    else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
+    if (tid < kMaxBands) band_cursor[tid] = 0u;
+    for (int x = tid; x < g.rp.mat_size; x += kResolveThreads) band_tab[x] = (uint8_t)raster_band_of(x, g.rp);
+    lds_barrier();
+
+    constexpr int kSl = kSeg / 64;
+    constexpr int kWaves = kResolveThreads / 64;
+    const int bands = g.raster_bands, lo_row = g.N - g.G;
+    const uint32_t *fkey = b.cand_key + (size_t)f * T * kSeg;
+    const float *fz = b.cand_z + (size_t)f * T * kSeg;
+    uint32_t *flist = b.code_main + ((size_t)f * g.emitters + g.strips + part) * bands * (size_t)g.code_cap;
+    for (int s0 = t0 + wv; s0 < t1; s0 += kWaves * kResolveBatch) {
+        uint32_t key[kResolveBatch][kSl];
+        float z[kResolveBatch][kSl];
+#pragma unroll
+        for (int j = 0; j < kResolveBatch; ++j) {
+            const int sg = s0 + j * kWaves;
+            const int n = sg < t1 ? (int)cnt[sg - t0] : 0; /* wave-uniform */
+#pragma unroll
+            for (int k = 0; k < kSl; ++k) { /* whole slices, nothing but the loads inside the uniform test (see k_cell_sums) */
+                const size_t at = (size_t)(sg < t1 ? sg : t0) * kSeg + lane + 64 * k;
+                key[j][k] = 0u;
+                z[j][k] = 0.f;
+                if (64 * k < __builtin_amdgcn_readfirstlane(n)) {
+                    key[j][k] = fkey[at];
+                    z[j][k] = fz[at];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kResolveBatch; ++j) {
+            const int sg = s0 + j * kWaves;
+            const int n = sg < t1 ? (int)cnt[sg - t0] : 0;
+            const int rr = sg / g.strips, strip = sg - rr * g.strips;
+            const size_t slot0 = (size_t)f * g.S + (size_t)(rr + lo_row - 1) * g.H + (size_t)strip * kStripCols;
+#pragma unroll
+            for (int k = 0; k < kSl; ++k) {
+                if (64 * k >= n) break; /* wave-uniform */
+                const uint32_t kk = key[j][k];
+                const bool have = lane + 64 * k < n;
+                const int cell = (int)(kk & kKeyCellMask);
+                const bool hit = have && above_neighbour_ground(z[j][k], cell, avg);
+                const bool pred = (kk & kKeyPredBit) != 0u;
+                const bool wrong = have && hit != pred;
+                if (!__ballot(hit || wrong)) continue; /* wave-uniform */
+                const size_t idx = slot0 + ((kk >> kKeyColShift) & 0xffu);
+                if (hit && !(kk & kKeyNoCodeBit)) {
+                    uint32_t code;
+                    if (!candidate_key_escapes(kk)) {
+                        code = bev_code_from_bins(edge_x[cell / kGridCols] + (int)((kk >> kKeyDxShift) & 3u),
+                                                  edge_y[cell % kGridCols] + (int)((kk >> kKeyDyShift) & 3u), z[j][k], g.rp);
+                    } else { /* cell clamped or bins not next to the cell's edge: x, y from the point itself */
+                        const float4 a = *reinterpret_cast<const float4 *>(b.ordered + idx);
+                        code = bev_code(a.x, a.y, a.z, 1 /* not 0: no kKeyNoCodeBit */, g.rp);
+                    }
+                    if (code != kSkip) {
+                        const int band = band_tab[code_x(code)];
+                        flist[(size_t)band * g.code_cap + atomicAdd(&band_cursor[band], 1u)] = code;
+                    }
+                }
+                if (wrong) { /* the walk's provisional label differs */
+                    uint16_t label = 0;             /* not un-grounded: label = 0, BatchMultiBevGen.cpp:245 */
+                    if (hit) {                      /* un-grounded: the point's own label back */
+                        if (kk & kKeyLabelM2Bit) label = (uint16_t)(int16_t)-2;
+                        else if (kIdentity) label = reinterpret_cast<const uint16_t *>(b.pts + idx)[14];
+                        else {
+                            /* an EMPTY slot can be a candidate too (a value-initialised point has intensity 0, not -1,
+                             * so phase A tests it like any other): its label is the zero point's 0 */
+                            const uint32_t w = winner_index(b.winner[idx], b.win_tag, b.win_shift);
+                            if (w != 0u) label = reinterpret_cast<const uint16_t *>(b.pts + b.frames[f].in_offset + (w - 1u))[14];
+                        }
+                    }
+                    reinterpret_cast<uint16_t *>(b.ordered + idx)[14] = label; /* label @28 */
+                }
+            }
+        }
+    }
+    lds_barrier();
+    if (tid < bands) b.ncode[((size_t)f * g.emitters + g.strips + part) * bands + tid] = band_cursor[tid];
+}
+
+/* ------------------------------------------------------------------------- */
+/* Both rasters (BatchMultiBevGen.cpp:271-292 occupancy, 24 layers; :340-356 uint8 max height), one workgroup per
+ * (frame, x-band of the images).  The band's 24-bit layer masks and max heights live in LDS (two planes of rows x M
+ * words); its input are this band's code lists: one per strip from the walk (slots that are not candidates) and one
+ * per part from k_ground_resolve (un-grounded candidates).  Finished planes leave with 16-byte stores, 1 KiB
+ * contiguous per wave-instruction. */
 int raster_bands_for(int M) /* uniform bands whose two LDS planes fit; the coarse band height is M / this */
 {
     for (int bands = kRasterSplit; bands <= 16; bands *= 2)
@@ -911,21 +1002,12 @@ __device__ __forceinline__ void store_planes(const uint32_t *mask, const uint32_
     }
 }
 
-constexpr int kRasterWaves = kRasterThreads / 64;
-constexpr int kCandBatch = 6; /* candidate segments whose keys and heights a wave requests at once */
-template <bool kIdentity>
 __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geometry g, int nf, int want_multi, int want_single)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    __shared__ float avg[kCells];                       /* the frame's 75 x 50 averages: 4 look-ups per candidate */
-    __shared__ int edge_x[kGridRows], edge_y[kGridCols]; /* BEV bin of every ground-grid row's / column's lower edge */
-    __shared__ uint32_t list_end[kMaxStrips + 1];       /* inclusive prefix of this band's code-list lengths */
-    __shared__ uint16_t seg_cnt[kMaxSegs];              /* candidates of the segments this band has to look at ... */
-    __shared__ uint16_t seg_id[kMaxSegs];               /* ... which segments those are ... */
-    __shared__ uint32_t seg_slot0[kMaxSegs];            /* ... and the slot of their strip's first column */
-    __shared__ uint32_t n_mine;
-    const int M = g.rp.mat_size, L = g.rp.n_layers, bands = g.raster_bands;
-    /* the bands of a frame read the same candidate keys: ONE XCD (blocks b and b+8 share an L2), adjacent launch slots */
+    __shared__ uint32_t list_end[kMaxStrips + kResolveParts + 1]; /* inclusive prefix of this band's code-list lengths */
+    const int M = g.rp.mat_size, L = g.rp.n_layers, bands = g.raster_bands, E = g.emitters;
+    /* the bands of a frame on ONE XCD (blocks b and b+8 share an L2), adjacent launch slots */
     const int xl = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int f = (jj / bands) * 8 + xl, band = jj % bands;
     if (f >= nf) return;
@@ -933,47 +1015,30 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
     const int cells = band_rows * M;
     uint32_t *mask = lds;
     uint32_t *hmax = lds + cells;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
     PH_DECL;
     PH();
 
-    /* round trip 1: list lengths, segment counts, averages; the planes are zeroed meanwhile */
+    /* round trip 1: the list lengths; the planes are zeroed meanwhile */
     uint32_t my_cnt = 0u;
-    if (tid < g.strips) my_cnt = b.ncode[((size_t)f * g.strips + tid) * bands + band];
-    if (tid == 0) n_mine = 0u;
-    for (int c = tid; c < kCells; c += kRasterThreads) avg[c] = b.avg[(size_t)f * kCells + c];
-    if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
-    else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
+    if (tid < E) my_cnt = b.ncode[((size_t)f * E + tid) * bands + band];
     for (int k = tid; k < 2 * cells; k += kRasterThreads) lds[k] = 0u;
-    if (tid < g.strips) list_end[tid + 1] = my_cnt;
+    if (tid < E) list_end[tid + 1] = my_cnt;
     if (tid == 0) list_end[0] = 0u;
     lds_barrier();
-    if (tid == 0) /* strips is small (9 for HDL_64E, at most kMaxStrips): a serial prefix */
-        for (int e = 0; e < g.strips; ++e) list_end[e + 1] += list_end[e];
-    /* the candidate segments that hold anything owned by this band (the walk left a band mask beside each count);
-     * their order does not matter */
-    for (int i = tid; i < g.segs; i += kRasterThreads) {
-        const uint32_t v = b.ncand[(size_t)f * g.segs + i], own = b.seg_own[(size_t)f * g.segs + i];
-        if (v != 0u && ((own >> band) & 1u)) {
-            const uint32_t at = atomicAdd(&n_mine, 1u);
-            seg_cnt[at] = (uint16_t)v;
-            seg_id[at] = (uint16_t)i;
-            const int rr = i / g.strips, strip = i - rr * g.strips;
-            seg_slot0[at] = (uint32_t)((rr + g.N - g.G - 1) * g.H + strip * kStripCols);
-        }
-    }
+    if (tid == 0) /* few lists (13 for HDL_64E): a serial prefix */
+        for (int e = 0; e < E; ++e) list_end[e + 1] += list_end[e];
     lds_barrier();
     PH();
 
-    /* ---- final codes: this band's lists of all strips as ONE index space, so that every load of the workgroup is
-     * requested at once ---- */
+    /* this band's lists as ONE index space, so that every load of the workgroup is requested at once */
     {
         constexpr int kU = 8;
-        const uint32_t total = list_end[g.strips];
-        const uint32_t *fmain = b.code_main + (size_t)f * g.strips * bands * g.code_cap;
-        uint32_t ends[16]; /* ends[j] = first index of strip j's list (j >= 1) */
+        const uint32_t total = list_end[E];
+        const uint32_t *fmain = b.code_main + (size_t)f * E * bands * g.code_cap;
+        uint32_t ends[16]; /* ends[j] = first index of list j (j >= 1) */
 #pragma unroll
-        for (int j = 0; j < 16; ++j) ends[j] = __builtin_amdgcn_readfirstlane(j <= g.strips ? list_end[j] : 0u);
+        for (int j = 0; j < 16; ++j) ends[j] = __builtin_amdgcn_readfirstlane(j <= E ? list_end[j] : 0u);
         for (uint32_t i0 = 0; i0 < total; i0 += kU * kRasterThreads) {
             uint32_t c[kU];
 #pragma unroll
@@ -983,15 +1048,15 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
                 if (i < total) {
                     int e = 0;
                     uint32_t e0 = 0u;
-                    if (g.strips <= 16) { /* the list ends are wave-uniform: scalar compares, no dependent LDS reads */
+                    if (E <= 16) { /* the list ends are wave-uniform: scalar compares, no dependent LDS reads */
 #pragma unroll
                         for (int j = 1; j < 16; ++j) {
-                            const bool past = j < g.strips && i >= ends[j];
+                            const bool past = j < E && i >= ends[j];
                             e += past ? 1 : 0;
                             e0 = past ? ends[j] : e0;
                         }
                     } else {
-                        int lo = 0, hi = g.strips - 1; /* first e with list_end[e + 1] > i */
+                        int lo = 0, hi = E - 1; /* first e with list_end[e + 1] > i */
                         while (lo < hi) {
                             const int mid = (lo + hi) >> 1;
                             if (list_end[mid + 1] > i) hi = mid; else lo = mid + 1;
@@ -1007,86 +1072,12 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
                 if (c[k] != kSkip) splat_code(c[k], x0, M, mask, hmax);
         }
     }
-    PH();
-
-    /* ---- candidates: wave w takes segments w, w + waves, ...; kCandBatch segments (x 4 slices of 64) per request ---- */
-    {
-        constexpr int kSl = kSeg / 64;
-        const uint32_t *fkey = b.cand_key + (size_t)f * g.segs * kSeg;
-        const float *fz = b.cand_z + (size_t)f * g.segs * kSeg;
-        const int n_segs = (int)n_mine;
-        for (int s0 = wv; s0 < n_segs; s0 += kRasterWaves * kCandBatch) {
-            uint32_t key[kCandBatch][kSl];
-            float z[kCandBatch][kSl];
-#pragma unroll
-            for (int j = 0; j < kCandBatch; ++j) {
-                const int q = s0 + j * kRasterWaves;
-                const int n = q < n_segs ? (int)seg_cnt[q] : 0;   /* wave-uniform */
-                const int sg = q < n_segs ? (int)seg_id[q] : 0;
-#pragma unroll
-                for (int k = 0; k < kSl; ++k) { /* whole slices, nothing but the loads inside the uniform test (see k_cell_sums) */
-                    const size_t at = (size_t)sg * kSeg + lane + 64 * k;
-                    key[j][k] = 0xffffffffu;
-                    z[j][k] = 0.f;
-                    if (64 * k < __builtin_amdgcn_readfirstlane(n)) {
-                        key[j][k] = fkey[at];
-                        z[j][k] = fz[at];
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < kCandBatch; ++j) {
-                const int q = s0 + j * kRasterWaves;
-                const int n = q < n_segs ? (int)seg_cnt[q] : 0;
-#pragma unroll
-                for (int k = 0; k < kSl; ++k) {
-                    if (64 * k >= n) break; /* wave-uniform */
-                    const uint32_t kk = key[j][k];
-                    const bool have = lane + 64 * k < n;
-                    const uint32_t owner = (kk >> kKeyOwnerShift) & 31u;
-                    const bool all = owner == kKeyOwnerAll;
-                    const bool mine = have && (owner == (uint32_t)band || all);
-                    if (!__ballot(mine)) continue; /* wave-uniform: nothing of this slice belongs to the band */
-                    if (!mine) continue;
-                    const int cell = (int)(kk & kKeyCellMask);
-                    const bool hit = above_neighbour_ground(z[j][k], cell, avg);
-                    const bool pred = (kk & kKeyPredBit) != 0u;
-                    const size_t idx = (size_t)f * g.S + seg_slot0[q] + ((kk >> kKeyColShift) & 0xffu);
-                    if (hit && !(kk & kKeyNoCodeBit)) {
-                        if (!all) {
-                            splat_code(bev_code_from_bins(edge_x[cell / kGridCols] + (int)((kk >> kKeyDxShift) & 3u),
-                                                          edge_y[cell % kGridCols] + (int)((kk >> kKeyDyShift) & 3u), z[j][k], g.rp),
-                                       x0, M, mask, hmax);
-                        } else { /* cell clamped or bins not next to the cell's edge: x, y from the point itself */
-                            const float4 a = *reinterpret_cast<const float4 *>(b.ordered + idx);
-                            const uint32_t c = bev_code(a.x, a.y, a.z, 1 /* not 0: no kKeyNoCodeBit */, g.rp);
-                            if (c != kSkip && code_x(c) >= x0 && code_x(c) < x0 + band_rows) splat_code(c, x0, M, mask, hmax);
-                        }
-                    }
-                    if (hit != pred && (!all || band == 0)) { /* the walk's provisional label is wrong */
-                        uint16_t label = 0;             /* not un-grounded: label = 0, BatchMultiBevGen.cpp:245 */
-                        if (hit) {                      /* un-grounded: the point's own label back */
-                            if (kk & kKeyLabelM2Bit) label = (uint16_t)(int16_t)-2;
-                            else if (kIdentity) label = reinterpret_cast<const uint16_t *>(b.pts + idx)[14];
-                            else {
-                                /* an EMPTY slot can be a candidate too (a value-initialised point has intensity 0, not
-                                 * -1, so phase A tests it like any other): its label is the zero point's 0 */
-                                const uint32_t w = winner_index(b.winner[idx], b.win_tag, b.win_shift);
-                                if (w != 0u) label = reinterpret_cast<const uint16_t *>(b.pts + b.frames[f].in_offset + (w - 1u))[14];
-                            }
-                        }
-                        reinterpret_cast<uint16_t *>(b.ordered + idx)[14] = label; /* label @28 */
-                    }
-                }
-            }
-        }
-    }
     lds_barrier();
     PH();
     store_planes(mask, hmax, want_multi ? b.multi : nullptr, want_single ? b.single : nullptr, f, x0, band_rows, M, L, tid,
                  kRasterThreads);
     PH();
-    PH_PRINT(band == 7 ? "raster7 setup codes cands stores" : "raster1 setup codes cands stores", tid == 0 && f == 100 && (band == 7 || band == 1));
+    PH_PRINT(band == 7 ? "raster7 setup codes stores" : "raster1 setup codes stores", tid == 0 && f == 100 && (band == 7 || band == 1));
 }
 
 /* rasters of ONE arbitrary cloud from a dense code array (bev_multi_bev / bev_single_bev): every band scans all codes */
@@ -1296,10 +1287,7 @@ hipError_t configure_kernels(const Geometry &g)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cell_sums),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)cell_sums_lds_bytes());
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)raster_lds_bytes(g));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)raster_lds_bytes(g));
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster_dense),
@@ -1338,17 +1326,19 @@ void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t
     if (nf == 0) return;
     hipLaunchKernelGGL(k_cell_sums, dim3(nf), dim3(kSumThreads), cell_sums_lds_bytes(), st, b, g);
 }
-void launch_bev_raster(const Geometry &g, const BatchPtrs &b, bool want_multi, bool want_single, int nf, bool identity,
-                       hipStream_t st)
+void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st)
 {
     if (nf == 0) return;
-    const dim3 grid(8 * ((nf + 7) / 8) * g.raster_bands);
     if (identity)
-        hipLaunchKernelGGL(k_bev_raster<true>, grid, dim3(kRasterThreads), raster_lds_bytes(g), st, b, g, nf,
-                           want_multi ? 1 : 0, want_single ? 1 : 0);
+        hipLaunchKernelGGL(k_ground_resolve<true>, dim3(nf * kResolveParts), dim3(kResolveThreads), 0, st, b, g);
     else
-        hipLaunchKernelGGL(k_bev_raster<false>, grid, dim3(kRasterThreads), raster_lds_bytes(g), st, b, g, nf,
-                           want_multi ? 1 : 0, want_single ? 1 : 0);
+        hipLaunchKernelGGL(k_ground_resolve<false>, dim3(nf * kResolveParts), dim3(kResolveThreads), 0, st, b, g);
+}
+void launch_bev_raster(const Geometry &g, const BatchPtrs &b, bool want_multi, bool want_single, int nf, hipStream_t st)
+{
+    if (nf == 0) return;
+    hipLaunchKernelGGL(k_bev_raster, dim3(8 * ((nf + 7) / 8) * g.raster_bands), dim3(kRasterThreads), raster_lds_bytes(g), st, b,
+                       g, nf, want_multi ? 1 : 0, want_single ? 1 : 0);
 }
 void launch_bev_raster_dense(const Geometry &g, const uint32_t *codes, uint32_t n_codes, uint8_t *multi, uint8_t *single,
                              hipStream_t st)
