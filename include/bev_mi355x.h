@@ -236,6 +236,11 @@ int bev_profile_get(bev_ctx_t *ctx, bev_kernel_stat_t *out, int cap);
  * n_frames * 3750 floats (ground_grid_avg_heights after BatchMultiBevGen.cpp:210), first_frame counted
  * from the start of that sub-batch. */
 int bev_debug_get_cell_avg(bev_ctx_t *ctx, int first_frame, int n_frames, float *out);
+/* Test hook: how the frames of the LAST sub-batch reached their slots (getOrderedCloud, BatchMultiBevGen.cpp:94-117).
+ * out[4 * i .. 4 * i + 3] = { T, mode, consumed, failed } of frame first_frame + i: mode 0 = order scan over all points,
+ * 1 = the first T points were read in place (sorted prefix, verified: consumed == T, failed == 0), 2 = read in place,
+ * verification failed, done again the general way.  Results never depend on the mode. */
+int bev_debug_get_frame_info(bev_ctx_t *ctx, int first_frame, int n_frames, uint32_t *out);
 /* Evaluates the phase-A angle predicate (BatchMultiBevGen.cpp:169-179) on the
  * device for n (dx,dy,dz) triples given as HOST arrays; out[i] = 1 if GROUND. */
 int bev_debug_angle_predicate(bev_ctx_t *ctx, const float *dx, const float *dy,

@@ -42,6 +42,8 @@ struct Lane {
     hipStream_t st = nullptr;
     hipEvent_t done = nullptr;
     hipEvent_t front_done = nullptr, back_done = nullptr; /* staged mode: workspace hand-over between the two stages */
+    FrameInfo *info = nullptr;  /* per frame: how its points reach their slots (k_probe / k_verdict) */
+    uint32_t *est = nullptr;    /* stream frames: estimated input position of every (row, strip)'s first slot */
     uint32_t *winner = nullptr;
     uint32_t win_gen = 0; /* generation tag of the last sub-batch that used this set's winner table */
     uint32_t *cand_key = nullptr;
@@ -70,6 +72,7 @@ struct bev_ctx {
     int n_lanes = 1;
     int n_lanes_active = 1; /* <= n_lanes; bev_set_lanes */
     bool staged = true;     /* two-stage pipeline, see run_pipeline; BEV_STAGED=0 falls back to free-running lanes */
+    bool allow_stream = false; /* BEV_STREAM=1: sorted-prefix frames are read in place (k_probe), see bev_create */
     hipEvent_t fork_ev = nullptr;
     hipEvent_t stagger_ev = nullptr; /* recorded on a lane after its bandwidth-bound kernels */
     bool staggered[kMaxLanes] = {false, false, false, false};
@@ -77,6 +80,7 @@ struct bev_ctx {
     uint32_t *codes = nullptr;
     size_t codes_elems = 0;
     float *last_avg = nullptr;
+    FrameInfo *last_info = nullptr;
 
     /* frame descriptors: ring of pinned host + device arrays */
     FrameDesc *h_desc[kDescRing] = {nullptr, nullptr, nullptr, nullptr};
@@ -309,6 +313,8 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         BatchPtrs b{};
         b.pts = identity ? d_pts + (size_t)f0 * S : d_pts;
         b.frames = identity ? nullptr : c->d_desc[ds] + f0;
+        b.info = identity ? nullptr : ln.info;
+        b.est = ln.est;
         b.winner = ln.winner;
         b.win_shift = c->win_shift;
         b.ordered = d_ordered + (size_t)f0 * S;
@@ -324,7 +330,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
 
         if (identity) {
             ProfScope ps(c, K_GATHER_GROUND, nb, st);
-            launch_gather_ground(g, b, nb, true, st);
+            launch_gather_ground(g, b, nb, 1, kFrameGeneral, st);
         } else {
             uint32_t max_pts = 0;
             for (int f = 0; f < nb; ++f) max_pts = std::max(max_pts, c->h_desc[ds][f0 + f].n_pts);
@@ -336,13 +342,24 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             }
             if (max_gen) ++ln.win_gen;
             b.win_tag = ln.win_gen;
+            {   /* which frames are sorted up to a tail and can be read in place */
+                ProfScope ps(c, K_PROBE, nb, st);
+                launch_probe(g, b, nb, c->allow_stream, st);
+            }
             {
                 ProfScope ps(c, K_ORDER_SCAN, nb, st);
-                launch_order_scan(g, b, nb, max_pts, st);
+                launch_order_scan(g, b, nb, max_pts, 0, st);
             }
             {
                 ProfScope ps(c, K_GATHER_GROUND, nb, st);
-                launch_gather_ground(g, b, nb, false, st);
+                launch_gather_ground(g, b, nb, 0, kFrameGeneral, st);
+                if (c->allow_stream) {
+                    launch_gather_ground(g, b, nb, 2, kFrameStream, st);
+                    /* stream frames that failed their verification: once more, the general way (normally none) */
+                    launch_verdict(b, nb, st);
+                    launch_order_scan(g, b, nb, max_pts, 1, st);
+                    launch_gather_ground(g, b, nb, 0, kFrameRedo, st);
+                }
             }
         }
         /* One-time stagger: a lane's FIRST sub-batch starts only after the previous lane has issued its
@@ -381,6 +398,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         HIPCK(c, hipEventRecord(ln.back_done, st));
         c->last_sub_frames = nb;
         c->last_avg = ln.avg;
+        c->last_info = identity ? nullptr : ln.info;
         HIPCK(c, hipGetLastError());
     }
     /* join: the main stream continues after every lane */
@@ -519,6 +537,11 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         int nl = e ? atoi(e) : 2;
         c->n_lanes = std::max(1, std::min(kMaxLanes, nl));
         c->n_lanes_active = c->n_lanes;
+        /* Reading sorted frames in place is complete and verified (tests/test_gpu_stream.py) but does not pay yet: the
+         * stream walk needs 170 VGPRs (two workgroups per CU instead of four) and measures 4.4 us per frame against
+         * 0.9 + 2.4 us for order scan + gather walk; it is opt-in until it does. */
+        const char *sm = getenv("BEV_STREAM");
+        c->allow_stream = sm && atoi(sm) != 0;
         const char *sg = getenv("BEV_STAGED");
         c->staged = (!sg || atoi(sg) != 0) && c->n_lanes >= 2;
     }
@@ -538,6 +561,9 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ln.front_done, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ln.back_done, hipEventDisableTiming));
+        CK(hipMalloc((void **)&ln.info, nb * sizeof(FrameInfo)));
+        CK(hipMemset(ln.info, 0, nb * sizeof(FrameInfo)));
+        CK(hipMalloc((void **)&ln.est, nb * (size_t)c->geo.N * c->geo.strips * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.winner, nb * S * sizeof(uint32_t)));
         CK(hipMemset(ln.winner, 0, nb * S * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.cand_key, nb * (size_t)c->geo.segs * kSeg * sizeof(uint32_t)));
@@ -570,7 +596,7 @@ void bev_destroy(bev_ctx_t *c)
     for (int l = 0; l < kMaxLanes; ++l) {
         Lane &ln = c->lanes[l];
         if (ln.st) (void)hipStreamSynchronize(ln.st);
-        void *ws[] = {ln.winner, ln.cand_key, ln.cand_z, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
+        void *ws[] = {ln.info, ln.est, ln.winner, ln.cand_key, ln.cand_z, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
         for (void *p : ws)
             if (p) (void)hipFree(p);
         if (ln.done) (void)hipEventDestroy(ln.done);
@@ -813,7 +839,7 @@ int bev_order_cloud(bev_ctx_t *c, const bev_point_t *pts, uint32_t n_pts, bev_po
     HIPCK(c, hipMemsetAsync(c->winner, 0, S * sizeof(uint32_t), c->stream));
     {
         ProfScope ps(c, K_ORDER_SCAN, 1);
-        launch_order_scan(g, b, 1, n_pts, c->stream);
+        launch_order_scan(g, b, 1, n_pts, 0, c->stream); /* b.info == nullptr: the whole cloud */
     }
     {
         ProfScope ps(c, K_GATHER_ONLY, 1);
@@ -1084,6 +1110,16 @@ int bev_debug_get_cell_avg(bev_ctx_t *c, int first_frame, int n_frames, float *o
     if (!c->last_avg) return BEV_ERR_INVALID_ARG;
     HIPCK(c, hipMemcpy(out, c->last_avg + (size_t)first_frame * bevx::kGridCells,
                        (size_t)n_frames * bevx::kGridCells * sizeof(float), hipMemcpyDeviceToHost));
+    return BEV_OK;
+}
+
+int bev_debug_get_frame_info(bev_ctx_t *c, int first_frame, int n_frames, uint32_t *out)
+{
+    if (!c || !out || first_frame < 0 || n_frames < 0 || first_frame + n_frames > c->last_sub_frames || !c->last_info)
+        return BEV_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpy(out, c->last_info + first_frame, (size_t)n_frames * sizeof(FrameInfo), hipMemcpyDeviceToHost));
     return BEV_OK;
 }
 

@@ -40,6 +40,25 @@ struct FrameDesc {
     uint32_t _pad;
 };
 
+/* How a frame's points reach their slots (getOrderedCloud, BatchMultiBevGen.cpp:94-117), decided per frame on the device:
+ *   kFrameGeneral  any input: order scan over all points (winner table), the walk gathers through it;
+ *   kFrameStream   the input's first T points are in strictly ascending slot order (a sweep written row by row, the
+ *                  usual output of a selector): the walk reads them in place, row by row, and only the tail [T, n)
+ *                  goes through the order scan; the walk VERIFIES the order of everything it consumes and counts it;
+ *   kFrameRedo     a stream frame whose verification failed: done again the general way (results never depend on
+ *                  what k_probe guessed). */
+enum : uint32_t { kFrameGeneral = 0, kFrameStream = 1, kFrameRedo = 2 };
+struct FrameInfo {
+    uint32_t T;        /* length of the prefix taken for sorted */
+    uint32_t mode;
+    uint32_t consumed; /* prefix points the stream walk has found in their own (row, strip) window */
+    uint32_t failed;   /* != 0: a consumed point was not above its predecessor, or could not be checked */
+};
+constexpr int kProbeStride = 127;   /* k_probe looks at every 127th point (odd: no resonance with firing orders of 2^k beams) */
+constexpr int kMaxSamples = 8192;   /* => stream mode for frames of up to 2^20 points; longer ones go the general way */
+constexpr int kStreamSlack = 16;    /* positions a (row, strip) window starts before / ends after the estimate */
+constexpr int kStreamMinPrefix = 2048;
+
 /* Workspace streams between the kernels of one sub-batch (see bev_exact.h for the candidate key):
  *   cand_key u32 / cand_z f32  [nf][segs][kSeg]   candidates, one segment per (row, strip), compacted in column order;
  *                                                  segments in row-major order => concatenation = slot order
@@ -68,6 +87,8 @@ struct Geometry {
 struct BatchPtrs {
     const bev_point_t *pts;      /* packed input points (or ordered cloud in identity mode) */
     const FrameDesc *frames;
+    FrameInfo *info;             /* [nf] (nullptr: every frame general) */
+    uint32_t *est;               /* [nf][N][strips]: stream frames: estimated input position of slot (r, first column of strip - 2) */
     uint32_t *winner;            /* [nf][S]  (win_tag << win_shift) | index+1 of the last input point per slot */
     uint32_t win_tag;            /* generation of this sub-batch in its workspace set (0: table was cleared) */
     int win_shift;               /* bits of index+1 */
@@ -96,6 +117,7 @@ enum KernelId {
     K_FLOAT_BEV,
     K_PROJECT,
     K_TRANSFORM,
+    K_PROBE,
     K_COUNT
 };
 const char *kernel_name(int id);
@@ -103,9 +125,13 @@ const char *kernel_name(int id);
 int raster_bands_for(int mat_size);
 
 /* launchers (bev_kernels.hip) — all asynchronous on `st` */
-void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, hipStream_t st);
-/* the column walk; identity: b.pts already is the ordered cloud (bev_mark_ground) */
-void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st);
+/* pass 0: general frames whole, stream frames from their T on; pass 1: redo frames whole */
+void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, int pass, hipStream_t st);
+/* the column walk.  source 0: through the winner table, frames of mode `mode`; 1: identity, b.pts already is the ordered
+ * cloud (bev_mark_ground); 2: stream frames */
+void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int source, uint32_t mode, hipStream_t st);
+void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st);
+void launch_verdict(const BatchPtrs &b, int nf, hipStream_t st);
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
 void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st);

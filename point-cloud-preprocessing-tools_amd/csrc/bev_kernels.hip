@@ -59,6 +59,7 @@ namespace bevk {
 static const char *const kNames[K_COUNT] = {
     "k_order_scan", "k_strip_ground", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project", "k_transform",
+    "k_probe",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
 
@@ -125,6 +126,81 @@ __device__ __forceinline__ uint32_t winner_index(uint32_t w, uint32_t tag, int s
 }
 
 /* ------------------------------------------------------------------------- */
+/* k_probe: which frames can be read in place.  getOrderedCloud (BatchMultiBevGen.cpp:102-116) scatters the input
+ * point by point; when the input already IS in slot order — a sweep written row by row — the scatter is the identity
+ * on positions, and reading the input a second time just to learn that (the order scan) is the largest avoidable
+ * stream of the path.  One workgroup per frame looks at every 128th point: the leading samples that are in range and
+ * strictly ascending bound a prefix [0, T) that is TAKEN for sorted; for every (row, strip) the position of its first
+ * slot inside that prefix is estimated by interpolation between the two samples around it.  Nothing here is trusted:
+ * the stream walk verifies every point it consumes and a frame that fails is redone the general way. */
+__global__ __launch_bounds__(256) void k_probe(BatchPtrs b, Geometry g, int allow_stream)
+{
+    __shared__ uint32_t samp[kMaxSamples]; /* slot of sample k (position k * kProbeStride) */
+    __shared__ uint32_t first_bad;
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const FrameDesc fd = b.frames[f];
+    const uint32_t n = fd.n_pts;
+    const bev_point_t *fp = b.pts + fd.in_offset;
+    const uint32_t ns = n ? (n - 1u) / kProbeStride + 1u : 0u;
+    const bool can = allow_stream && n >= (uint32_t)kStreamMinPrefix && ns <= (uint32_t)kMaxSamples;
+    if (tid == 0) first_bad = can ? ns : 0u;
+    __syncthreads();
+    if (can) {
+        for (uint32_t k = tid; k < ns; k += 256u) {
+            const size_t i = (size_t)k * kProbeStride;
+            const uint32_t rc = reinterpret_cast<const uint32_t *>(fp + i)[5]; /* row | col << 16 */
+            const uint32_t row = rc & 0xffffu, col = rc >> 16;
+            uint32_t sl = (row < (uint32_t)g.N && col < (uint32_t)g.H) ? row * (uint32_t)g.H + col : 0xffffffffu;
+            if (i + 1 < n) { /* the sample's successor too (mostly the same line): catches column-major orders at once */
+                const uint32_t rc1 = reinterpret_cast<const uint32_t *>(fp + i + 1)[5];
+                const uint32_t row1 = rc1 & 0xffffu, col1 = rc1 >> 16;
+                if (!(row1 < (uint32_t)g.N && col1 < (uint32_t)g.H) || row1 * (uint32_t)g.H + col1 <= sl) sl = 0xffffffffu;
+            }
+            samp[k] = sl;
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < ns; k += 256u) /* first sample that is out of range or not above its predecessor */
+            if (samp[k] == 0xffffffffu || (k > 0u && samp[k] <= samp[k - 1u])) atomicMin(&first_bad, k);
+        __syncthreads();
+    }
+    const uint32_t m = first_bad;                                      /* samples 0 .. m-1 ascend */
+    const uint32_t T = m ? (m - 1u) * kProbeStride + 1u : 0u;          /* the last of them is position T - 1 */
+    const bool stream = can && T >= (uint32_t)kStreamMinPrefix && 2u * T >= n;
+    if (tid == 0) b.info[f] = FrameInfo{stream ? T : 0u, stream ? kFrameStream : kFrameGeneral, 0u, 0u};
+    if (!stream) return;
+    uint32_t *fest = b.est + (size_t)f * g.N * g.strips;
+    for (int i = tid; i < g.N * g.strips; i += 256) {
+        const int r = i / g.strips, st = i - r * g.strips;
+        const long long want = (long long)r * g.H + (long long)st * kStripCols - 2; /* first slot of the strip's window */
+        uint32_t est = 0u;
+        if (want > (long long)samp[0]) {
+            uint32_t lo = 0u, hi = m - 1u; /* largest k with samp[k] <= want */
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if ((long long)samp[mid] <= want) lo = mid; else hi = mid - 1u;
+            }
+            const uint32_t s0 = samp[lo];
+            if (lo + 1u < m) {
+                const uint32_t s1 = samp[lo + 1u];
+                est = lo * kProbeStride + (uint32_t)(((unsigned long long)(want - s0) * kProbeStride) / (s1 - s0));
+            } else {
+                est = T; /* beyond the last sample: nothing of the prefix lies there */
+            }
+        }
+        fest[i] = est < T ? est : T;
+    }
+}
+
+/* after the stream walk: a frame whose consumed points do not add up to its prefix, or with a failed check, is redone */
+__global__ __launch_bounds__(256) void k_verdict(FrameInfo *info, int nf)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= nf) return;
+    FrameInfo fi = info[f];
+    if (fi.mode == kFrameStream && (fi.failed != 0u || fi.consumed != fi.T)) info[f].mode = kFrameRedo;
+}
+
+/* ------------------------------------------------------------------------- */
 /* getOrderedCloud, BatchMultiBevGen.cpp:102-116: bounds test + slot index;
  * "last point in input order wins" == max input index per slot.            */
 constexpr int kSeenBits = 11, kSeenCodes = 1 << kSeenBits; /* the walk's memo of listed BEV codes: 8 KB of LDS */
@@ -133,25 +209,43 @@ constexpr int kScanIdxBits = 10; /* 256 * kScanPerThread = 1024 points per block
 constexpr int kScanRowBins = 128; /* rows the LDS regrouping below can bin (more rows: plain path) */
 __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restrict__ pts,
                                                     const FrameDesc *__restrict__ frames,
+                                                    const FrameInfo *__restrict__ info, int pass,
                                                     uint32_t *__restrict__ winner, int N, int H, int S,
                                                     uint32_t tag_bits)
 {
     const int f = blockIdx.y;
     const FrameDesc fd = frames[f];
-    const uint32_t base = blockIdx.x * (256u * kScanPerThread) + threadIdx.x;
-    if (blockIdx.x * (256u * kScanPerThread) >= fd.n_pts) return;
+    const uint32_t block0 = blockIdx.x * (256u * kScanPerThread);
+    const uint32_t base = block0 + threadIdx.x;
+    if (block0 >= fd.n_pts) return;
+    /* which points of this frame this pass scatters: [first, n) */
+    uint32_t first = 0u;
+    if (info) {
+        const FrameInfo fi = info[f];
+        if (pass == 0) {
+            if (fi.mode == kFrameStream) first = fi.T; /* the prefix is read in place by the stream walk */
+        } else if (fi.mode != kFrameRedo) {
+            return;
+        }
+    } else if (pass != 0) {
+        return;
+    }
+    if (block0 + 256u * kScanPerThread <= first) return;
     const bev_point_t *fp = pts + fd.in_offset;
     uint32_t slot[kScanPerThread];
     bool spread = false; /* does any wave-instruction's worth of 64 points straddle far-apart slots? */
+    uint32_t rcw[kScanPerThread];
 #pragma unroll
-    for (int k = 0; k < kScanPerThread; ++k) { /* all loads in flight before the first atomic */
+    for (int k = 0; k < kScanPerThread; ++k) { /* all loads in flight before anything is decoded: clamped address, no branch */
         const uint32_t i = base + 256u * k;
-        slot[k] = 0xffffffffu;
-        if (i < fd.n_pts) {
-            const uint32_t rc = load_once(reinterpret_cast<const uint32_t *>(fp + i) + 5); /* row | col << 16 */
-            const uint32_t row = rc & 0xffffu, col = rc >> 16;
-            if (row < (uint32_t)N && col < (uint32_t)H) slot[k] = row * (uint32_t)H + col; /* :106-111 ("< 0" is dead: u16) */
-        }
+        rcw[k] = load_once(reinterpret_cast<const uint32_t *>(fp + (i < fd.n_pts ? i : fd.n_pts - 1u)) + 5); /* row | col << 16 */
+    }
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        const uint32_t i = base + 256u * k;
+        const uint32_t row = rcw[k] & 0xffffu, col = rcw[k] >> 16;
+        slot[k] = (i >= first && i < fd.n_pts && row < (uint32_t)N && col < (uint32_t)H) ? row * (uint32_t)H + col
+                                                                                         : 0xffffffffu; /* :106-111 ("< 0" is dead: u16) */
     }
     uint32_t *fw = winner + (size_t)f * S;
 #pragma unroll
@@ -279,12 +373,16 @@ struct PendingRow {
 template <class T>
 __device__ __forceinline__ void store_ws(T *p, T v) { *p = v; }
 
-template <bool kIdentity>
-__global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geometry g, int nf)
+enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcStream = 2 };
+constexpr int kWinLen = kStripThreads + 2 * kStreamSlack; /* positions of a stream window */
+template <int kSrc>
+__global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
+    constexpr bool kIdentity = kSrc == kSrcIdentity, kStream = kSrc == kSrcStream;
     /* the strips of a frame share halo columns and the lines at their seams: one XCD (one L2) per frame */
     int f, strip;
     if (!map_block_xcd(blockIdx.x, nf, g.strips, f, strip)) return;
+    if (!kIdentity && b.info && b.info[f].mode != want_mode) return; /* another launch of this kernel has the frame */
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int N = g.N, H = g.H, lo_row = g.N - g.G;
     const size_t frame_off = (size_t)f * g.S;
@@ -307,9 +405,18 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     __shared__ uint32_t band_cursor[kMaxBands];            /* entries already in this strip's code list of each band */
     __shared__ uint8_t band_tab[512];                      /* x bin -> raster band */
     __shared__ uint32_t seen[kSeenCodes];                  /* direct-mapped memo of codes this strip has already listed */
+    /* stream source: the row's points by column offset (two rows), the row each entry belongs to, and the slot of every
+     * window position for the order check */
+    __shared__ uint4 rowbuf[kStream ? 2 : 1][kStream ? kStripThreads : 1][2];
+    __shared__ uint16_t rowtag[kStream ? 2 : 1][kStream ? kStripThreads : 1];
+    __shared__ uint32_t wslot[kStream ? 2 : 1][kStream ? kWinLen : 1];
     if (tid < kMaxBands) band_cursor[tid] = 0u;
     for (int k = tid; k < kSeenCodes; k += kStripThreads) seen[k] = kSkip;
     for (int x = tid; x < g.rp.mat_size; x += kStripThreads) band_tab[x] = (uint8_t)raster_band_of(x, g.rp);
+    if (kStream) {
+        rowtag[0][tid] = 0;
+        rowtag[1][tid] = 0;
+    }
 
     /* Winner words are loaded UNCONDITIONALLY from a clamped address and decoded only when they are used, two rows
      * later: a predicated load whose result is decoded on the spot makes the compiler branch around the load and wait
@@ -337,14 +444,18 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         hi = src[1];
     };
 
-    /* software pipeline: while row r is handled, the points of rows r+1 and r+2 and the raw winner words of rows r+3
-     * and r+4 are in flight.  The stages live in small arrays indexed by r mod 3 / r mod 2 and the row loop is unrolled
-     * six times with compile-time indices: rotating the stages through variables instead ("next = next2") makes the
-     * compiler copy registers that a load is still writing, and wait for that load — the newest one — every row. */
-    Half plo[3], phi[3];   /* point of row r at [r % 3] */
+    /* software pipeline: while row r is handled, the points of rows r+1 .. r+kDepth and the raw winner words of the
+     * kDepth rows after those are in flight.  gfx950 counts loads and stores on ONE counter (vmcnt) and they complete
+     * out of order with respect to each other, so with stores pending the compiler waits for "everything" before a
+     * loaded value is used; what the second stage still buys is that row r+2's loads are issued before row r's stores.
+     * The stages live in small arrays indexed by r mod 3 / r mod 2 and the row loop is unrolled with compile-time
+     * indices: rotating the stages through variables instead ("next = next2") makes the compiler copy registers that a
+     * load is still writing, and wait for that load — the newest one — every row. */
+    constexpr int kDepth = kStream ? 1 : 2; /* the stream source has its own window in flight and fewer registers to spare */
+    Half plo[3], phi[3];   /* point of row r at [r % (kDepth + 1)] */
     bool pfull[3];         /* the slot of that row holds a point (else: the dummy was loaded) */
     uint32_t wraw[2];      /* raw winner word of row r at [r % 2] */
-    {
+    if (kDepth == 2) {
         const uint32_t r0 = load_winner_raw(0), r1 = load_winner_raw(1);
         wraw[0] = load_winner_raw(2);
         wraw[1] = load_winner_raw(3);
@@ -355,6 +466,116 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         load_point(w0, plo[0], phi[0]);
         load_point(w1, plo[1], phi[1]);
         plo[2] = phi[2] = Half{{0, 0, 0, 0}};
+    } else {
+        wraw[0] = load_winner_raw(0);
+        wraw[1] = load_winner_raw(1);
+        const uint32_t w0 = winner_of(0, wraw[0]);
+        pfull[0] = w0 != 0u;
+        pfull[1] = pfull[2] = false;
+        load_point(w0, plo[0], phi[0]);
+        plo[1] = phi[1] = plo[2] = phi[2] = Half{{0, 0, 0, 0}};
+    }
+
+    /* ---- stream source (k_probe took the first T input points for sorted) ----
+     * Row r's points of this strip's 256 virtual columns are consecutive in the input; they start near est[r][strip]
+     * (interpolated from sampled points).  Every thread loads ONE window position (position est - slack + tid; 32
+     * threads a second one, the window's last 32; in the last strip 36 more read the row's first positions for the two
+     * wrap-around halo columns), coalesced and in place, and drops the point into the LDS row at the offset its own
+     * (row, col) says.  One row later the owner of each column picks its point up there — unless the winner table,
+     * which now holds only the tail [T, n), says a later point has overwritten the slot.
+     * Verification (results must not depend on the guess): a thread that has found a point of the strip's OWN columns
+     * counts it and checks that the window position before it lies in the prefix and has a smaller slot.  When every
+     * one of a frame's T prefix points has been counted exactly once and no check has failed, the prefix is strictly
+     * ascending, every point was where its owner looked, and the result is what getOrderedCloud's scatter gives;
+     * otherwise k_verdict sends the frame through the general kernels again. */
+    const uint32_t T = kStream ? b.info[f].T : 0u;
+    const uint32_t *fest = kStream ? b.est + (size_t)f * N * g.strips : nullptr;
+    const bool last_strip = strip == g.strips - 1;
+    Half w1lo{{0, 0, 0, 0}}, w1hi{{0, 0, 0, 0}}, w2lo{{0, 0, 0, 0}}, w2hi{{0, 0, 0, 0}}; /* window positions of the next row */
+    uint32_t est_nx = 0u, est0_nx = 0u;   /* estimates of the row after the one in flight (scalar loads, one row ahead) */
+    uint32_t w_est = 0u, w_est0 = 0u;     /* estimates the window in flight was loaded with */
+    uint32_t consumed = 0u, failed = 0u;
+    uint32_t pend[2] = {0u, 0u};          /* last scatter, per load: bit 0 consumed a point, bits 1.. its window index + 1, bit 31: it is position 0 */
+    auto stream_pos = [&](uint32_t est, uint32_t est0, bool second, bool &ok) -> uint32_t {
+        long long q;
+        if (!second) q = (long long)est - kStreamSlack + tid;
+        else if (tid < 2 * kStreamSlack) q = (long long)est - kStreamSlack + kStripThreads + tid;
+        else q = (long long)est0 - (kStreamSlack - 2) + (tid - 2 * kStreamSlack); /* the row's first positions (wrap halo) */
+        ok = q >= 0 && q < (long long)T && (!second || tid < 2 * kStreamSlack || (last_strip && tid < 64));
+        return ok ? (uint32_t)q : 0u;
+    };
+    auto stream_issue = [&](int r) { /* loads of row r's window; T >= 1 in stream mode, so position 0 is always there */
+        if (!kStream) return;
+        w_est = est_nx;
+        w_est0 = est0_nx;
+        bool ok1, ok2;
+        const uint32_t q1 = stream_pos(w_est, w_est0, false, ok1);
+        const Half *s1 = reinterpret_cast<const Half *>(fpts + q1);
+        w1lo = s1[0];
+        w1hi = s1[1];
+        if (wv == 0) { /* the window's last 32 positions and the wrap halo's 32: one wave (uniform branch, loads only) */
+            const uint32_t q2 = stream_pos(w_est, w_est0, true, ok2);
+            const Half *s2 = reinterpret_cast<const Half *>(fpts + q2);
+            w2lo = s2[0];
+            w2hi = s2[1];
+        }
+        const int rn = r + 1 < N ? r + 1 : N - 1;
+        est_nx = fest[rn * g.strips + strip];
+        est0_nx = fest[rn * g.strips];
+    };
+    auto stream_scatter = [&](int r) { /* the window in flight belongs to row r: into the LDS row r & 1 */
+        if (!kStream) return;
+        const int pr = r & 1;
+        const long long row0 = (long long)r * H, first = row0 + (long long)strip * kStripCols - 2;
+        pend[0] = pend[1] = 0u;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k == 1 && wv != 0) break; /* wave-uniform */
+            bool ok;
+            const uint32_t q = stream_pos(w_est, w_est0, k == 1, ok);
+            const Half &lo = k ? w2lo : w1lo, &hi = k ? w2hi : w1hi;
+            const uint32_t row = hi.w[1] & 0xffffu, col = hi.w[1] >> 16;
+            const bool valid = ok && r < N && row < (uint32_t)N && col < (uint32_t)H;
+            const long long flat = (long long)row * H + col;
+            const bool in_window = k == 0 || tid < 2 * kStreamSlack;
+            if (in_window) wslot[pr][k ? kStripThreads + tid : tid] = valid ? (uint32_t)flat : 0xffffffffu;
+            if (!valid) continue;
+            const long long off = flat - first;                       /* column offset in this strip's row */
+            const long long offw = flat - row0 + (H - ((long long)strip * kStripCols - 2)); /* ... as a wrap-around halo column */
+            if (off >= 0 && off < kStripThreads) {
+                rowbuf[pr][off][0] = make_uint4(lo.w[0], lo.w[1], lo.w[2], lo.w[3]);
+                rowbuf[pr][off][1] = make_uint4(hi.w[0], hi.w[1], hi.w[2], hi.w[3]);
+                rowtag[pr][off] = (uint16_t)(r + 1);
+                if (in_window && off >= 2 && off < 2 + kStripCols && (long long)strip * kStripCols + off - 2 < H) { /* an own column */
+                    ++consumed;
+                    pend[k] = 1u | ((uint32_t)((k ? kStripThreads + tid : tid) + 1) << 1) | (q == 0u ? 0x80000000u : 0u);
+                }
+            }
+            if (flat >= row0 && flat < row0 + 2 && offw >= 0 && offw < kStripThreads) {
+                rowbuf[pr][offw][0] = make_uint4(lo.w[0], lo.w[1], lo.w[2], lo.w[3]);
+                rowbuf[pr][offw][1] = make_uint4(hi.w[0], hi.w[1], hi.w[2], hi.w[3]);
+                rowtag[pr][offw] = (uint16_t)(r + 1);
+            }
+        }
+    };
+    auto stream_check = [&](int r) { /* after the barrier that follows row r's scatter */
+        if (!kStream) return;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!(pend[k] & 1u) || (pend[k] & 0x80000000u)) continue; /* nothing consumed / the very first input point */
+            const uint32_t j = ((pend[k] >> 1) & 0x3fffffffu) - 1u;
+            if (j == 0u) { failed = 1u; continue; } /* its predecessor is outside the window */
+            const uint32_t a = wslot[r & 1][j - 1u], c = wslot[r & 1][j];
+            if (a == 0xffffffffu || a >= c) failed = 1u;
+        }
+    };
+    if (kStream) { /* prologue: row 0's window into its LDS row, row 1's window in flight */
+        est_nx = fest[strip];
+        est0_nx = fest[0];
+        stream_issue(0);
+        stream_scatter(0);
+        stream_issue(1);
+        lds_barrier();
     }
 
     XYZI prev{0.f, 0.f, 0.f, 0.f}, prevprev{0.f, 0.f, 0.f, 0.f};
@@ -366,21 +587,33 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     uint32_t *fncand = b.ncand + (size_t)f * g.segs;
     uint32_t *flist = b.code_main + ((size_t)f * g.emitters + strip) * bands * (size_t)g.code_cap;
 
-    /* one row; I = r mod 6 at compile time */
+    /* one row; I = r mod 6 (r mod 2 at depth 1) at compile time */
     auto row_step = [&](auto I, const int r) {
-        constexpr int i3 = decltype(I)::value % 3, i2 = decltype(I)::value % 2, n3 = (decltype(I)::value + 2) % 3;
+        constexpr int ic = decltype(I)::value % (kDepth + 1);              /* stage holding row r */
+        constexpr int in = (decltype(I)::value + kDepth) % (kDepth + 1);   /* stage that takes row r + kDepth */
+        constexpr int wu = (decltype(I)::value + kDepth) % 2, wl = decltype(I)::value % 2; /* winner word used / reloaded */
         const int par = r & 1;
-        Half cur_lo = plo[i3], cur_hi = phi[i3];
-        if (!pfull[i3]) { /* untouched slot: value-initialised, BatchMultiBevGen.cpp:98 */
+        Half cur_lo = plo[ic], cur_hi = phi[ic];
+        if (!pfull[ic]) { /* untouched slot: value-initialised, BatchMultiBevGen.cpp:98 */
             cur_lo = Half{{0, 0, 0, 0}};
             cur_hi = Half{{0, 0, 0, 0}};
+            if (kStream && r < N && rowtag[par][tid] == (uint16_t)(r + 1)) { /* ... unless the prefix holds the slot's point */
+                const uint4 a = rowbuf[par][tid][0], c = rowbuf[par][tid][1];
+                cur_lo = Half{{a.x, a.y, a.z, a.w}};
+                cur_hi = Half{{c.x, c.y, c.z, c.w}};
+            }
+        }
+        if (kStream) {
+            stream_check(r);        /* row r's window: scattered one step ago, a barrier since */
+            stream_scatter(r + 1);  /* row r + 1's window has arrived: into the other LDS row */
+            stream_issue(r + 2);
         }
         {
-            const uint32_t w2 = winner_of(r + 2, wraw[i2]);
-            pfull[n3] = w2 != 0u;
-            load_point(w2, plo[n3], phi[n3]);
+            const uint32_t wn = winner_of(r + kDepth, wraw[wu]);
+            pfull[in] = wn != 0u;
+            load_point(wn, plo[in], phi[in]);
         }
-        wraw[i2] = load_winner_raw(r + 4);
+        wraw[wl] = load_winner_raw(r + 2 * kDepth);
 
         const XYZI cur{__uint_as_float(cur_lo.w[0]), __uint_as_float(cur_lo.w[1]), __uint_as_float(cur_lo.w[2]),
                        __uint_as_float(cur_hi.w[0])};
@@ -503,16 +736,34 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         prev = cur;
     };
     /* two extra iterations drain the pipeline */
-    for (int r0 = 0; r0 < N + 2; r0 += 6) {
-        row_step(std::integral_constant<int, 0>{}, r0);
-        if (r0 + 1 < N + 2) row_step(std::integral_constant<int, 1>{}, r0 + 1);
-        if (r0 + 2 < N + 2) row_step(std::integral_constant<int, 2>{}, r0 + 2);
-        if (r0 + 3 < N + 2) row_step(std::integral_constant<int, 3>{}, r0 + 3);
-        if (r0 + 4 < N + 2) row_step(std::integral_constant<int, 4>{}, r0 + 4);
-        if (r0 + 5 < N + 2) row_step(std::integral_constant<int, 5>{}, r0 + 5);
+    if (kDepth == 2) {
+        for (int r0 = 0; r0 < N + 2; r0 += 6) {
+            row_step(std::integral_constant<int, 0>{}, r0);
+            if (r0 + 1 < N + 2) row_step(std::integral_constant<int, 1>{}, r0 + 1);
+            if (r0 + 2 < N + 2) row_step(std::integral_constant<int, 2>{}, r0 + 2);
+            if (r0 + 3 < N + 2) row_step(std::integral_constant<int, 3>{}, r0 + 3);
+            if (r0 + 4 < N + 2) row_step(std::integral_constant<int, 4>{}, r0 + 4);
+            if (r0 + 5 < N + 2) row_step(std::integral_constant<int, 5>{}, r0 + 5);
+        }
+    } else {
+        for (int r0 = 0; r0 < N + 2; r0 += 2) {
+            row_step(std::integral_constant<int, 0>{}, r0);
+            if (r0 + 1 < N + 2) row_step(std::integral_constant<int, 1>{}, r0 + 1);
+        }
     }
     lds_barrier();
     if (tid < bands) b.ncode[((size_t)f * g.emitters + strip) * bands + tid] = band_cursor[tid];
+    if (kStream) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            consumed += __shfl_xor(consumed, d);
+            failed |= __shfl_xor(failed, d);
+        }
+        if (lane == 0) {
+            atomicAdd(&b.info[f].consumed, consumed);
+            if (failed) atomicOr(&b.info[f].failed, 1u);
+        }
+    }
 }
 
 /* getOrderedCloud alone (bev_order_cloud): no ground work. */
@@ -1293,28 +1544,34 @@ hipError_t configure_kernels(const Geometry &g)
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster_dense),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)raster_lds_bytes(g));
 }
-void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, hipStream_t st)
+void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, int pass, hipStream_t st)
 {
     if (max_pts == 0 || nf == 0) return;
     const unsigned per_block = 256u * kScanPerThread;
     dim3 grid((max_pts + per_block - 1u) / per_block, (unsigned)nf);
-    hipLaunchKernelGGL(k_order_scan, grid, dim3(256), 0, st, b.pts, b.frames, b.winner, g.N, g.H, g.S,
+    hipLaunchKernelGGL(k_order_scan, grid, dim3(256), 0, st, b.pts, b.frames, b.info, pass, b.winner, g.N, g.H, g.S,
                        b.win_tag << b.win_shift);
 }
-void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st)
+void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int source, uint32_t mode, hipStream_t st)
 {
     if (nf == 0) return;
     const int grid = xcd_grid(nf, g.strips);
-    /* BEV_WALK_LDS (experiment knob): dynamic LDS the walk's workgroups claim without using it, to cap how many of them
-     * share a CU and leave registers / wave slots for the back end's workgroups of the other sub-batch */
-    static const size_t pad = [] {
-        const char *e = getenv("BEV_WALK_LDS");
-        return e ? (size_t)atoi(e) : (size_t)0;
-    }();
-    if (identity)
-        hipLaunchKernelGGL(k_strip_ground<true>, dim3(grid), dim3(kStripThreads), pad, st, b, g, nf);
+    if (source == kSrcIdentity)
+        hipLaunchKernelGGL(k_strip_ground<kSrcIdentity>, dim3(grid), dim3(kStripThreads), 0, st, b, g, nf, mode);
+    else if (source == kSrcStream)
+        hipLaunchKernelGGL(k_strip_ground<kSrcStream>, dim3(grid), dim3(kStripThreads), 0, st, b, g, nf, mode);
     else
-        hipLaunchKernelGGL(k_strip_ground<false>, dim3(grid), dim3(kStripThreads), pad, st, b, g, nf);
+        hipLaunchKernelGGL(k_strip_ground<kSrcGather>, dim3(grid), dim3(kStripThreads), 0, st, b, g, nf, mode);
+}
+void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st)
+{
+    if (nf == 0) return;
+    hipLaunchKernelGGL(k_probe, dim3(nf), dim3(256), 0, st, b, g, allow_stream ? 1 : 0);
+}
+void launch_verdict(const BatchPtrs &b, int nf, hipStream_t st)
+{
+    if (nf == 0) return;
+    hipLaunchKernelGGL(k_verdict, dim3((nf + 255) / 256), dim3(256), 0, st, b.info, nf);
 }
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {

@@ -1,0 +1,114 @@
+"""GPU: frames whose points are already in slot order are read in place (k_probe / stream walk) instead of being
+scattered through the winner table (getOrderedCloud, BatchMultiBevGen.cpp:102-116).  The path is a GUESS that is
+verified on the device; these tests check (a) that sorted sweeps really take it, (b) that inputs which only look sorted
+at the sampled positions are caught and redone the general way, and (c) that the results equal the oracle either way."""
+import numpy as np
+import pytest
+
+import bev_amd
+import oracle_lib as orc
+from bev_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _stream_on(monkeypatch):
+    """the in-place path is opt-in (BEV_STREAM=1, read by bev_create) until it is faster than the general one"""
+    monkeypatch.setenv("BEV_STREAM", "1")
+
+
+def _run(p, ctx, frames):
+    ordered, multi, single, gm = ctx.process_batch(frames, want_ground_mat=True)
+    info = ctx.frame_info(0, min(len(frames), max(1, ctx.max_batch // 2)) if len(frames) <= ctx.max_batch // 2 else 1)
+    sp = orc.sensor_from_params(p)
+    for i, pts in enumerate(frames):
+        o_ord, o_gm, o_multi, o_single = orc.process_frame(sp, pts)
+        assert ordered[i].tobytes() == o_ord.tobytes(), f"frame {i}: ordered cloud / labels differ"
+        assert np.array_equal(gm[i], o_gm) and np.array_equal(multi[i], o_multi) and np.array_equal(single[i], o_single), i
+    return info
+
+
+@pytest.mark.parametrize("sensor", ["HDL_64E", "HDL_32E", "OS1_64"])
+def test_sorted_sweeps_are_read_in_place(sensor):
+    p = bev_amd.params_for_sensor(sensor)
+    frames = [synth.sweep(p, 70 + i, keep=k, n_dup=d) for i, (k, d) in enumerate([(0.98, 5000), (1.0, 0), (0.6, 300), (0.9, 0)])]
+    ctx = bev_amd.BevContext(p, device=0, max_batch=8, max_points=max(len(f) for f in frames))
+    try:
+        info = _run(p, ctx, frames)
+        for i, fr in enumerate(frames):
+            T, mode, consumed, failed = (int(v) for v in info[i])
+            assert mode == 1 and failed == 0 and consumed == T, (i, info[i])
+            assert len(fr) - T < 5000 + 2 * 128 + 1  # everything but the appended duplicates (and < 128 points before them)
+    finally:
+        ctx.close()
+
+
+def test_unsorted_frames_go_the_general_way():
+    p = bev_amd.params_for_sensor("OS1_64")
+    frames = [synth.firing_order(p, 3), synth.adversarial(p, 60000, 1, False), synth.sweep(p, 4)[:1500]]
+    ctx = bev_amd.BevContext(p, device=0, max_batch=8, max_points=70000)
+    try:
+        info = _run(p, ctx, frames)
+        assert [int(m) for m in info[:, 1]] == [0, 0, 0]
+    finally:
+        ctx.close()
+
+
+def test_inputs_that_only_look_sorted_are_caught_and_redone():
+    """The probe samples every 128th point; everything in between is verified by the walk.  Each frame below is a
+    sorted sweep with one defect hidden from the samples."""
+    p = bev_amd.params_for_sensor("HDL_64E")
+    base = synth.sweep(p, 90, keep=0.97, n_dup=0)
+    H = p.horizon_scan
+
+    def swapped(i, j):
+        f = base.copy()
+        f[[i, j]] = f[[j, i]]
+        return f
+
+    def dup_slot(i):  # two consecutive prefix points in the same slot: the later one must win
+        f = base.copy()
+        f[i + 1]["row"], f[i + 1]["col"] = f[i]["row"], f[i]["col"]
+        return f
+
+    def oob(i):
+        f = base.copy()
+        f[i]["row"] = 200
+        return f
+
+    def shifted_block(i, n, d):  # n points claim columns d further right: a gap and an overlap inside the prefix
+        f = base.copy()
+        f["col"][i:i + n] = np.minimum(f["col"][i:i + n] + d, H - 1)
+        return f
+
+    frames = [swapped(1001, 1002), swapped(50001, 50300), dup_slot(70001), oob(33333), shifted_block(90001, 40, 7),
+              swapped(3, 4), base]
+    ctx = bev_amd.BevContext(p, device=0, max_batch=16, max_points=len(base))
+    try:
+        info = _run(p, ctx, frames)
+        modes = [int(m) for m in info[:, 1]]
+        assert modes[-1] == 1                       # the clean sweep is read in place
+        assert all(m == 2 for m in modes[:-1]), modes  # every defect is caught, the frame redone
+    finally:
+        ctx.close()
+
+
+def test_stream_and_general_frames_mixed_in_one_sub_batch_and_the_knob():
+    import os
+    p = bev_amd.params_for_sensor("HDL_32E")
+    frames = [synth.sweep(p, 1), synth.firing_order(p, 2), synth.sweep(p, 3, keep=0.5, n_dup=9000), np.empty(0, bev_amd.POINT_DTYPE),
+              synth.sweep(p, 5)]
+    ctx = bev_amd.BevContext(p, device=0, max_batch=16, max_points=max(len(f) for f in frames))
+    try:
+        info = _run(p, ctx, frames)
+        assert [int(m) for m in info[:, 1]] == [1, 0, 1, 0, 1]
+    finally:
+        ctx.close()
+    os.environ["BEV_STREAM"] = "0"
+    ctx = bev_amd.BevContext(p, device=0, max_batch=16, max_points=max(len(f) for f in frames))
+    try:
+        info = _run(p, ctx, frames)
+        assert [int(m) for m in info[:, 1]] == [0, 0, 0, 0, 0]
+    finally:
+        ctx.close()
