@@ -185,6 +185,8 @@ void fill_geometry(const bev_params_t *p, Geometry *g)
     g->rp.lidar_to_ground = p->lidar_to_ground;
     g->rp.mat_size = mat_size_of(p);
     g->rp.n_layers = p->n_layers;
+    g->rp.inv_interval = bevx::exact_reciprocal(p->interval);
+    g->rp.inv_height_res = bevx::exact_reciprocal(p->height_res);
 }
 
 /* ---- profiling -------------------------------------------------------- */

@@ -149,7 +149,23 @@ struct RasterParams {
      * outside [z0, z1), fine ones of `fine` rows inside — most returns lie within a few tens of metres of the sensor,
      * i.e. in the middle rows of the image, and uniform bands left two workgroups with 85 % of a frame's codes */
     int bands, coarse, fine, z0, z1;
+    /* interval / height_res are powers of two in every configuration of the reference (1.0; 0.25, 0.5, 1.0): dividing
+     * by 2^k and multiplying by 2^-k are the same correctly rounded operation, and the multiply is ten instructions
+     * shorter on the device.  0 = not a power of two: divide. */
+    float inv_interval, inv_height_res;
 };
+/* 1 / v if v is a power of two (then x / v == x * (1 / v) bit for bit, for every x), else 0 */
+BEVX_HD float exact_reciprocal(float v)
+{
+    union { float f; uint32_t u; } c;
+    c.f = v;
+    const uint32_t e = (c.u >> 23) & 0xffu;
+    if ((c.u & 0x807fffffu) != 0u || e == 0u || e >= 253u) return 0.0f; /* sign / mantissa set, subnormal, or 1 / v not normal */
+    c.u = (254u - e) << 23;
+    return c.f;
+}
+BEVX_HD float div_interval(float a, const RasterParams &rp) { return rp.inv_interval != 0.0f ? a * rp.inv_interval : a / rp.interval; }
+BEVX_HD float div_height_res(float a, const RasterParams &rp) { return rp.inv_height_res != 0.0f ? a * rp.inv_height_res : a / rp.height_res; }
 BEVX_HD int raster_band_of(int x, const RasterParams &rp)
 {
     if (x < rp.z0) return x / rp.coarse;
@@ -187,6 +203,10 @@ BEVX_HD int bev_bin(float p, float max_range_f, float interval)
     const float shifted = (p + max_range_f) / interval;    /* float, BatchMultiBevGen.cpp:279 */
     return round_half_up_bin(shifted);
 }
+BEVX_HD int bev_bin_rp(float p, const RasterParams &rp) /* the same with the reciprocal where it is exact */
+{
+    return round_half_up_bin(div_interval(p + rp.max_range_f, rp));
+}
 /* (int)((double)(z + 2.0f) * 4.0): scaling by 4 is exact in float too */
 BEVX_HD int height_times4(float t)
 {
@@ -197,7 +217,7 @@ BEVX_HD int height_times4(float t)
 /* the part of the code that depends on the height only (layer, clamped height), for bins already known to be in range */
 BEVX_HD uint32_t bev_code_from_bins(int x, int y, float pz, const RasterParams &rp)
 {
-    int layer = cvtt_f32(roundf(pz / rp.height_res + rp.lidar_to_ground)); /* :281 */
+    int layer = cvtt_f32(roundf(div_height_res(pz, rp) + rp.lidar_to_ground)); /* :281 */
     int h = height_times4(pz + rp.lidar_to_ground);                    /* :345 */
     h = h < 0 ? 0 : (h > 255 ? 255 : h);                               /* :346 */
     uint32_t l = (layer >= 0 && layer < rp.n_layers) ? (uint32_t)layer : kNoLayer;
@@ -206,8 +226,8 @@ BEVX_HD uint32_t bev_code_from_bins(int x, int y, float pz, const RasterParams &
 BEVX_HD uint32_t bev_code(float px, float py, float pz, int label, const RasterParams &rp)
 {
     if (label == 0) return kSkip;                                      /* :285, :349 */
-    int x = bev_bin(px, rp.max_range_f, rp.interval);                  /* :279, :343 */
-    int y = bev_bin(py, rp.max_range_f, rp.interval);                  /* :280, :344 */
+    int x = bev_bin_rp(px, rp);                                        /* :279, :343 */
+    int y = bev_bin_rp(py, rp);                                        /* :280, :344 */
     if (x < 0 || x >= rp.mat_size || y < 0 || y >= rp.mat_size) return kSkip;
     return bev_code_from_bins(x, y, pz, rp);
 }
@@ -244,17 +264,23 @@ constexpr uint32_t kKeyEscape = 3u;
 /* BEV bin of the lower edge of ground-grid row / column s (the edge is 2 * s - offset, exact in float) */
 BEVX_HD int cell_edge_bin(int s, float grid_offset, const RasterParams &rp)
 {
-    return bev_bin((float)(2 * s) - grid_offset, rp.max_range_f, rp.interval);
+    return bev_bin_rp((float)(2 * s) - grid_offset, rp);
 }
-BEVX_HD uint32_t candidate_key(int cell, int col_in_strip, bool pred, uint32_t code, int label, const RasterParams &rp)
+/* edge_x / edge_y: cell_edge_bin of the cell's row / column (tables in LDS on the device) */
+BEVX_HD uint32_t candidate_key_edges(int cell, int col_in_strip, bool pred, uint32_t code, int label, int edge_x, int edge_y)
 {
     uint32_t key = (uint32_t)cell | ((uint32_t)col_in_strip << kKeyColShift) | (pred ? kKeyPredBit : 0u) |
                    (label == -2 ? kKeyLabelM2Bit : 0u);
     if (code == kSkip) return key | kKeyNoCodeBit;
-    const int dx = (int)(code & 511u) - cell_edge_bin(cell / kGridCols, 75.0f, rp);
-    const int dy = (int)((code >> 9) & 511u) - cell_edge_bin(cell % kGridCols, 50.0f, rp);
+    const int dx = (int)(code & 511u) - edge_x;
+    const int dy = (int)((code >> 9) & 511u) - edge_y;
     const bool ok = dx >= 0 && dx < (int)kKeyEscape && dy >= 0 && dy < (int)kKeyEscape;
     return key | ((ok ? (uint32_t)dx : kKeyEscape) << kKeyDxShift) | ((ok ? (uint32_t)dy : kKeyEscape) << kKeyDyShift);
+}
+BEVX_HD uint32_t candidate_key(int cell, int col_in_strip, bool pred, uint32_t code, int label, const RasterParams &rp)
+{
+    return candidate_key_edges(cell, col_in_strip, pred, code, label, cell_edge_bin(cell / kGridCols, 75.0f, rp),
+                               cell_edge_bin(cell % kGridCols, 50.0f, rp));
 }
 /* the code of a candidate whose key is not an escape and has no kKeyNoCodeBit */
 BEVX_HD uint32_t candidate_code(uint32_t key, float z, const RasterParams &rp)

@@ -405,6 +405,7 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     __shared__ uint32_t band_cursor[kMaxBands];            /* entries already in this strip's code list of each band */
     __shared__ uint8_t band_tab[512];                      /* x bin -> raster band */
     __shared__ uint32_t seen[kSeenCodes];                  /* direct-mapped memo of codes this strip has already listed */
+    __shared__ int edge_x[kGridRows], edge_y[kGridCols];   /* BEV bin of every ground-grid row's / column's lower edge */
     /* stream source: the row's points by column offset (two rows), the row each entry belongs to, and the slot of every
      * window position for the order check */
     __shared__ uint4 rowbuf[kStream ? 2 : 1][kStream ? kStripThreads : 1][2];
@@ -413,6 +414,8 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
     if (tid < kMaxBands) band_cursor[tid] = 0u;
     for (int k = tid; k < kSeenCodes; k += kStripThreads) seen[k] = kSkip;
     for (int x = tid; x < g.rp.mat_size; x += kStripThreads) band_tab[x] = (uint8_t)raster_band_of(x, g.rp);
+    if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
+    else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
     if (kStream) {
         rowtag[0][tid] = 0;
         rowtag[1][tid] = 0;
@@ -663,7 +666,8 @@ __global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geo
         }
         if (cand1) {
             const int cell = ground_cell(__uint_as_float(p1.lo.w[0]), __uint_as_float(p1.lo.w[1]));
-            p1.key = candidate_key(cell, tid - 2, p1.pred, p1.code, (int)(int16_t)(p1.hi.w[3] & 0xffffu), g.rp);
+            p1.key = candidate_key_edges(cell, tid - 2, p1.pred, p1.code, (int)(int16_t)(p1.hi.w[3] & 0xffffu),
+                                         edge_x[cell / kGridCols], edge_y[cell % kGridCols]);
         }
 
         /* ---- write out row r-2 (its per-wave counts were published before the barrier) ---- */
@@ -909,26 +913,35 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
         cnt_next = load_counts(p + 2);
         PHA(5);
 
-        /* hist.  Consecutive candidates of a segment mostly share their cell (a ring crosses a 2 m cell with dozens
-         * of returns), and 64 LDS atomics on one address serialise: only the head of every run of equal cells adds, the
-         * run's length (a cell with several runs in a slice just gets several adds).  The first head to touch a cell in
-         * this part lists it: everything after this phase works on the listed cells only (a few hundred of 3750). */
+        /* hist.  Lanes of a 64-slice that hold the same cell find each other with one ballot per key bit (12 bits cover
+         * 3750 cells; 0xfff is not a cell): constant work however many distinct cells the slice has.  Every lane keeps
+         * its rank inside its group, the group's size and whether it leads the group in the spare bits of its cell
+         * register (cell | rank << 12 | size << 18 | leader << 25), so the placement below needs no second look.
+         * Only leaders touch the histogram (64 LDS atomics on one address would serialise).  The first leader to touch
+         * a cell in this part lists it: everything after this phase works on the listed cells only. */
 #pragma unroll
         for (int j = 0; j < kSegsPerWave; ++j) {
 #pragma unroll
             for (int k = 0; k < kSl; ++k) {
                 if (64 * k >= nn[j]) break; /* wave-uniform */
                 const uint32_t c = cell[j][k];
-                const uint32_t prev = __shfl_up(c, 1);
-                const bool head = c != 0xfffu && (lane == 0 || prev != c);
-                const unsigned long long heads = __ballot(head || c == 0xfffu); /* an empty lane ends a run too */
-                if (head) {
-                    const unsigned long long later = heads & ~((2ull << lane) - 1ull);
-                    const int end = later ? __ffsll((long long)later) - 1 : 64;
-                    atomicAdd(&myhist[c >> 1], (uint32_t)(end - lane) << (16 * (c & 1u)));
+                const bool valid = c != 0xfffu;
+                unsigned long long peers = __ballot(valid);
+#pragma unroll
+                for (int bit = 0; bit < 12; ++bit) {
+                    const bool one = (c >> bit) & 1u;
+                    const unsigned long long bal = __ballot(one);
+                    peers &= one ? bal : ~bal;
+                }
+                const unsigned long long lower = peers & ((1ull << lane) - 1ull);
+                const uint32_t size = (uint32_t)__popcll(peers), rank = (uint32_t)__popcll(lower);
+                const bool leader = valid && lower == 0ull;
+                if (leader) {
+                    atomicAdd(&myhist[c >> 1], size << (16 * (c & 1u)));
                     const uint32_t bit = 1u << (c & 31u);
                     if (!(atomicOr(&tbits[c >> 5], bit) & bit)) tlist[atomicAdd(&misc[par], 1u)] = (uint16_t)c;
                 }
+                if (valid) cell[j][k] = c | (rank << 12) | (size << 18) | (leader ? 1u << 25 : 0u);
             }
         }
         PHA(6);
@@ -969,31 +982,22 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
         if (tid == 0) misc[8] = 0u;
         PHA(2);
 
-        /* stable placement: slices in slot order (segment by segment, 64 candidates at a time) */
+        /* stable placement: slices in slot order (segment by segment, 64 candidates at a time); position = the cell's
+         * run start + this wave's cursor inside the run + the lane's rank in its group; the group's leader then
+         * advances the cursor (the reads are issued before that update: same wave, program order; two cells of one
+         * word may both advance: atomic) */
 #pragma unroll
         for (int j = 0; j < kSegsPerWave; ++j) {
 #pragma unroll
             for (int k = 0; k < kSl; ++k) {
                 if (64 * k >= nn[j]) break; /* wave-uniform */
-                const uint32_t c = cell[j][k];
-                const bool valid = c != 0xfffu;
-                /* lanes holding the same cell find each other with one ballot per key bit (12 bits cover 3750 cells;
-                 * 0xfff is not a cell) */
-                unsigned long long peers = __ballot(valid);
-#pragma unroll
-                for (int bit = 0; bit < 12; ++bit) {
-                    const bool one = (c >> bit) & 1u;
-                    const unsigned long long bal = __ballot(one);
-                    peers &= one ? bal : ~bal;
-                }
-                const unsigned long long lower = peers & ((1ull << lane) - 1ull);
-                if (valid) {
+                const uint32_t v = cell[j][k];
+                const uint32_t c = v & 0xfffu;
+                if (c != 0xfffu) {
                     const uint32_t off = (myhist[c >> 1] >> (16 * (c & 1u))) & 0xffffu;
-                    zbuf[(start[c] & 0xffffu) + off + (uint32_t)__popcll(lower)] = zz[j][k];
+                    zbuf[(start[c] & 0xffffu) + off + ((v >> 12) & 63u)] = zz[j][k];
+                    if (v & (1u << 25)) atomicAdd(&myhist[c >> 1], ((v >> 18) & 127u) << (16 * (c & 1u)));
                 }
-                /* the lowest lane of each peer group advances the wave's cursor of that cell; the reads above are
-                 * issued before this update (same wave, program order); two cells of one word may both advance */
-                if (valid && lower == 0ull) atomicAdd(&myhist[c >> 1], (uint32_t)__popcll(peers) << (16 * (c & 1u)));
             }
         }
         lds_barrier();

@@ -36,6 +36,8 @@ RasterParams raster_params(const bev_params_t *p)
     rp.lidar_to_ground = p->lidar_to_ground;
     rp.mat_size = cvtt_f32((float)(p->max_range * 2) / p->interval);
     rp.n_layers = p->n_layers;
+    rp.inv_interval = exact_reciprocal(p->interval);
+    rp.inv_height_res = exact_reciprocal(p->height_res);
     /* how the device cuts the images into workgroups (bev_capi.hip fill_geometry); results do not depend on it */
     rp.coarse = rp.mat_size >= 8 ? rp.mat_size / 8 : 1;
     rp.fine = rp.coarse % 4 == 0 ? rp.coarse / 4 : rp.coarse;
@@ -135,6 +137,33 @@ uint64_t hc_angle_vs_libm(uint64_t n, uint64_t seed)
 }
 
 int hc_ground_cell(float x, float y) { return ground_cell(x, y); }
+
+/* exact_reciprocal (bev_exact.h): for every power of two v it accepts, x / v == x * (1 / v) bit for bit over `samples`
+ * pseudo-random bit patterns of x per v plus the extremes; everything that is not a power of two is refused.
+ * Returns the number of violations. */
+uint64_t hc_exact_reciprocal_check(uint64_t samples)
+{
+    uint64_t bad = 0;
+    for (uint32_t e = 0; e < 256; ++e) {
+        const float v = bits_to_float(e << 23);
+        const float inv = exact_reciprocal(v);
+        if (e == 0 || e >= 253) { bad += inv != 0.0f; continue; }
+        if (inv == 0.0f || v * inv != 1.0f) { ++bad; continue; }
+        uint64_t z = 0x9e3779b97f4a7c15ULL * (e + 1);
+        for (uint64_t k = 0; k < samples + 8; ++k) {
+            z += 0x9e3779b97f4a7c15ULL;
+            uint64_t h = z; h = (h ^ (h >> 30)) * 0xbf58476d1ce4e5b9ULL; h = (h ^ (h >> 27)) * 0x94d049bb133111ebULL; h ^= h >> 31;
+            static const uint32_t ext[8] = {0u, 0x80000000u, 1u, 0x007fffffu, 0x00800000u, 0x7f7fffffu, 0x7f800000u, 0x7fc00000u};
+            const float x = bits_to_float(k < 8 ? ext[k] : (uint32_t)h);
+            const float a = x / v, b = x * inv;
+            uint32_t ua, ub; std::memcpy(&ua, &a, 4); std::memcpy(&ub, &b, 4);
+            if (ua != ub && !(a != a && b != b)) ++bad;
+        }
+    }
+    const float no[] = {3.0f, 0.3f, -1.0f, -0.5f, 1.5f, 0.0f, 1e-40f, 6.0f};
+    for (float v : no) bad += exact_reciprocal(v) != 0.0f;
+    return bad;
+}
 
 /* candidate keys decoded / escaped by hc_process_frame since the last reset (test statistics) */
 static uint64_t g_key_decodes = 0, g_key_escapes = 0;

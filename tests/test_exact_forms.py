@@ -11,3 +11,11 @@ def test_float_only_forms_equal_the_literal_expressions_for_every_float():
     hc.lib().hc_exhaustive_exact_forms(out)
     names = ["x + 75.0f / y + 50.0f", "floor(n / 2.0)", "round(v + 0.5) bin", "(z + 2) * 4 height", "d > 0.30"]
     assert {n: int(v) for n, v in zip(names, out)} == {n: 0 for n in names}
+
+
+def test_exact_reciprocal_is_a_division():
+    """bev_exact.h replaces `/ interval` and `/ HEIGHT_RES` (BatchMultiBevGen.cpp:279-281) by a multiplication when the
+    divisor is a power of two: the same correctly rounded operation for every dividend, subnormal and overflowing
+    results included; any other divisor keeps the division."""
+    import hostcheck_lib as hc
+    assert hc.lib().hc_exact_reciprocal_check(200000) == 0
