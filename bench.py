@@ -199,11 +199,13 @@ def main() -> int:
     # ---- per-kernel HIP-event durations of the roofline pass (this rank)
     mean_pts = total_pts / count
     b_frame = bev_amd.algorithmic_bytes_per_frame(p, mean_pts)  # 32P + 32S + L*M*M + M*M
-    # which part of B_frame each kernel is the one to move (DESIGN.md "Kernels")
-    own_bytes = {
-        "k_strip_ground": 32.0 * mean_pts + 32.0 * S,        # the one read of the points that is counted + the ordered cloud
-        "k_bev_raster": float(L * M * M + M * M),
-    }
+    # which part of B_frame each kernel is the one to move (DESIGN.md "Kernels"): the input is counted ONCE, for the kernel
+    # whose read of it cannot be avoided — the column walk when P ~ S (it gathers every point it writes), the order scan
+    # when P >> S (oxford_concat: 2 M points into 33,792 slots; the walk then only gathers the S winners)
+    if args.workload == "oxford_concat":
+        own_bytes = {"k_order_scan": 32.0 * mean_pts, "k_strip_ground": 32.0 * S, "k_bev_raster": float(L * M * M + M * M)}
+    else:
+        own_bytes = {"k_strip_ground": 32.0 * mean_pts + 32.0 * S, "k_bev_raster": float(L * M * M + M * M)}
     roofline = None
     kernels = []
     kernels_pipelined = [{"name": s["name"], "launches": s["launches"], "avg_launch_ms": s["total_ms"] / s["launches"],

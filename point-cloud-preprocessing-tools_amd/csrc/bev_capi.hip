@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 
+#include <roctracer/roctx.h>
+
 #include "bev_internal.h"
 #include "bev_libm.h"
 
@@ -54,6 +56,67 @@ struct Lane {
     int8_t *gm = nullptr; /* lazily allocated */
 };
 
+} // namespace
+
+/* Device -> host side of bev_process_batch.  Copies into pageable host memory block the calling thread, so the
+ * downloads of chunk k run on their own thread and stream while the main thread uploads and launches chunk k + 1:
+ * PCIe is used in both directions at once.  The thread lives as long as the context (it used to be created and joined
+ * by every call). */
+struct bev_ctx;
+namespace {
+struct Downloader {
+    struct Task {
+        int f0, nb, half;
+        bev_point_t *const *ordered_out;
+        uint8_t *const *multi_out;
+        uint8_t *const *single_out;
+        int8_t *const *gm_out;
+        int half_frames;
+    };
+    bev_ctx *c = nullptr;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Task> queue;
+    bool closing = false;
+    int finished = 0; /* chunks of the current call whose outputs are in the caller's buffers */
+    hipError_t err = hipSuccess;
+    std::thread th;
+
+    void run();
+    void start(bev_ctx *ctx)
+    {
+        c = ctx;
+        th = std::thread([this] { run(); });
+    }
+    void begin_call()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        finished = 0;
+        err = hipSuccess;
+    }
+    void push(Task t)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            queue.push_back(t);
+        }
+        cv.notify_all();
+    }
+    void wait_finished(int n)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return finished >= n; });
+    }
+    void close()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            closing = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
 } // namespace
 
 struct bev_ctx {
@@ -99,6 +162,7 @@ struct bev_ctx {
     int8_t *st_gm = nullptr;
     bool staging_ready = false;
     hipStream_t dl_stream = nullptr;             /* device -> host copies of bev_process_batch (own host thread) */
+    Downloader *downloader = nullptr;            /* that thread, started with the staging buffers */
     hipEvent_t out_ready[2] = {nullptr, nullptr}; /* per half of the output staging: its chunk has been computed */
     /* KITTI projection workspace, one allocation made on first use and grown on demand */
     void *kitti_buf = nullptr;
@@ -115,6 +179,52 @@ struct bev_ctx {
     int last_sub_frames = 0;
     std::string last_error;
 };
+
+namespace {
+void Downloader::run()
+{
+    (void)hipSetDevice(c->device);
+    const size_t S = (size_t)c->geo.S;
+    for (;;) {
+        Task t;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return closing || !queue.empty(); });
+            if (queue.empty()) return;
+            t = queue.front();
+            queue.pop_front();
+        }
+        hipError_t e = hipStreamWaitEvent(c->dl_stream, c->out_ready[t.half], 0);
+        const size_t base = (size_t)t.half * t.half_frames;
+        auto copy = [&](void *dst, const void *src, size_t n) {
+            if (e == hipSuccess && dst) e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->dl_stream);
+        };
+        /* frames whose destination buffers follow each other in host memory (rows of one array) leave in ONE copy:
+         * three small copies per frame otherwise cost the link ~15 % in call overhead */
+        auto copy_runs = [&](auto *const *dst, const unsigned char *src, size_t bytes) {
+            for (int f = 0; f < t.nb;) {
+                int e2 = f + 1;
+                auto *d0 = reinterpret_cast<unsigned char *>(dst[t.f0 + f]);
+                while (e2 < t.nb && d0 && reinterpret_cast<unsigned char *>(dst[t.f0 + e2]) == d0 + (size_t)(e2 - f) * bytes) ++e2;
+                if (!d0) e2 = f + 1;
+                copy(d0, src + (base + f) * bytes, (size_t)(e2 - f) * bytes);
+                f = e2;
+            }
+        };
+        copy_runs(t.ordered_out, reinterpret_cast<const unsigned char *>(c->st_ordered), S * sizeof(bev_point_t));
+        if (t.multi_out) copy_runs(t.multi_out, c->st_multi, c->multi_bytes);
+        if (t.single_out) copy_runs(t.single_out, c->st_single, c->single_bytes);
+        if (t.gm_out) copy_runs(t.gm_out, reinterpret_cast<const unsigned char *>(c->st_gm), S);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->dl_stream);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (e != hipSuccess && err == hipSuccess) err = e;
+            ++finished;
+        }
+        cv.notify_all();
+    }
+}
+} // namespace
 
 namespace {
 
@@ -205,6 +315,13 @@ int prof_flush(bev_ctx *c)
     return BEV_OK;
 }
 
+/* roctx range on the calling host thread (rocprofv3 --marker-trace): the counterpart of the reference's timer around
+ * its per-frame region (BatchMultiBevGen.cpp:724,732,749-752), here around what the host enqueues per sub-batch stage */
+struct RoctxRange {
+    explicit RoctxRange(const char *name) { roctxRangePush(name); }
+    ~RoctxRange() { roctxRangePop(); }
+};
+
 struct ProfScope {
     bev_ctx *c;
     ProfSlot *s = nullptr;
@@ -256,7 +373,8 @@ int ensure_gm(bev_ctx *c)
 /* The whole pipeline on device pointers.  `identity`: d_pts already holds
  * ordered clouds (n_frames * S points) and the order stage is skipped.       */
 int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint64_t *h_offsets, bool identity,
-                 bev_point_t *d_ordered, uint8_t *d_multi, uint8_t *d_single, int8_t *d_gm, bool fork = true)
+                 bev_point_t *d_ordered, uint8_t *d_multi, uint8_t *d_single, int8_t *d_gm, bool fork = true,
+                 int sub_frames = 0 /* frames per sub-batch; 0: max_batch */)
 {
     if (n_frames == 0) return BEV_OK;
     const Geometry &g = c->geo;
@@ -290,7 +408,8 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
     /* fork: every lane starts after whatever the caller already queued on the main stream (the staged
      * host->device copies of the host-buffer entry points).  The device-resident entry point has nothing
      * on the main stream to wait for, so its lanes free-run from call to call and stay staggered. */
-    const int n_sub = (n_frames + c->max_batch - 1) / c->max_batch;
+    const int sub_size = sub_frames > 0 ? std::min(sub_frames, c->max_batch) : c->max_batch;
+    const int n_sub = (n_frames + sub_size - 1) / sub_size;
     const int lanes_used = std::min(c->n_lanes_active, n_sub);
     if (fork) {
         HIPCK(c, hipEventRecord(c->fork_ev, c->stream));
@@ -300,8 +419,8 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
     }
 
     int sub = 0;
-    for (int f0 = 0; f0 < n_frames; f0 += c->max_batch, ++sub) {
-        const int nb = std::min(c->max_batch, n_frames - f0);
+    for (int f0 = 0; f0 < n_frames; f0 += sub_size, ++sub) {
+        const int nb = std::min(sub_size, n_frames - f0);
         Lane &ln = c->lanes[sub % lanes_used];
         /* staged mode: lanes are only workspace sets; the bandwidth-bound front (order scan + column walk) of
          * every sub-batch runs on one stream, the latency-bound back (cell sums, resolve, rasters) on another,
@@ -331,9 +450,11 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.single = d_single ? d_single + (size_t)f0 * c->single_bytes : nullptr;
 
         if (identity) {
+            RoctxRange rr("bev:front (identity walk)");
             ProfScope ps(c, K_GATHER_GROUND, nb, st);
             launch_gather_ground(g, b, nb, 1, kFrameGeneral, st);
         } else {
+            RoctxRange rr("bev:front (probe, order scan, column walk)");
             uint32_t max_pts = 0;
             for (int f = 0; f < nb; ++f) max_pts = std::max(max_pts, c->h_desc[ds][f0 + f].n_pts);
             /* winner entries carry the set's generation: no memset between sub-batches (see winner_index) */
@@ -381,6 +502,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                 c->staggered[nxt] = true;
             }
         }
+        RoctxRange rb("bev:back (cell sums, resolve, rasters)");
         {
             ProfScope ps(c, K_CELL_SUMS, nb, st);
             launch_cell_sums(g, b, nb, st);
@@ -428,6 +550,9 @@ int ensure_staging(bev_ctx *c)
     HIPCK(c, hipMalloc((void **)&c->st_gm, (size_t)c->max_batch * S));
     HIPCK(c, hipStreamCreateWithFlags(&c->dl_stream, hipStreamNonBlocking));
     for (auto &e : c->out_ready) HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->downloader = new (std::nothrow) Downloader();
+    if (!c->downloader) return BEV_ERR_OOM;
+    c->downloader->start(c);
     c->staging_ready = true;
     return BEV_OK;
 }
@@ -608,6 +733,11 @@ void bev_destroy(bev_ctx_t *c)
     }
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->stagger_ev) (void)hipEventDestroy(c->stagger_ev);
+    if (c->downloader) {
+        c->downloader->close();
+        delete c->downloader;
+        c->downloader = nullptr;
+    }
     if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     for (auto e : c->out_ready)
         if (e) (void)hipEventDestroy(e);
@@ -645,94 +775,6 @@ int bev_process_device_resident(bev_ctx_t *c, int n_frames, const bev_point_t *d
                         /*fork=*/false);
 }
 
-namespace {
-/* Device -> host side of bev_process_batch.  Copies into pageable host memory block the calling thread, so the
- * downloads of chunk k run on their own thread and stream while the main thread uploads and launches chunk k + 1:
- * PCIe is used in both directions at once. */
-struct Downloader {
-    struct Task { int f0, nb, half; };
-    bev_ctx *c;
-    bev_point_t *const *ordered_out;
-    uint8_t *const *multi_out;
-    uint8_t *const *single_out;
-    int8_t *const *gm_out;
-    int half_frames;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<Task> queue;
-    bool closing = false;
-    int finished = 0; /* chunks whose outputs are in the caller's buffers */
-    hipError_t err = hipSuccess;
-    std::thread th;
-
-    void run()
-    {
-        (void)hipSetDevice(c->device);
-        const size_t S = (size_t)c->geo.S;
-        for (;;) {
-            Task t;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return closing || !queue.empty(); });
-                if (queue.empty()) return;
-                t = queue.front();
-                queue.pop_front();
-            }
-            hipError_t e = hipStreamWaitEvent(c->dl_stream, c->out_ready[t.half], 0);
-            const size_t base = (size_t)t.half * half_frames;
-            auto copy = [&](void *dst, const void *src, size_t n) {
-                if (e == hipSuccess && dst) e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, c->dl_stream);
-            };
-            /* frames whose destination buffers follow each other in host memory (rows of one array) leave in ONE copy:
-             * three small copies per frame otherwise cost the link ~15 % in call overhead */
-            auto copy_runs = [&](auto *const *dst, const unsigned char *src, size_t bytes) {
-                for (int f = 0; f < t.nb;) {
-                    int e = f + 1;
-                    auto *d0 = reinterpret_cast<unsigned char *>(dst[t.f0 + f]);
-                    while (e < t.nb && d0 && reinterpret_cast<unsigned char *>(dst[t.f0 + e]) == d0 + (size_t)(e - f) * bytes) ++e;
-                    if (!d0) e = f + 1;
-                    copy(d0, src + (base + f) * bytes, (size_t)(e - f) * bytes);
-                    f = e;
-                }
-            };
-            copy_runs(ordered_out, reinterpret_cast<const unsigned char *>(c->st_ordered), S * sizeof(bev_point_t));
-            if (multi_out) copy_runs(multi_out, c->st_multi, c->multi_bytes);
-            if (single_out) copy_runs(single_out, c->st_single, c->single_bytes);
-            if (gm_out) copy_runs(gm_out, reinterpret_cast<const unsigned char *>(c->st_gm), S);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->dl_stream);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (e != hipSuccess && err == hipSuccess) err = e;
-                ++finished;
-            }
-            cv.notify_all();
-        }
-    }
-    void push(Task t)
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            queue.push_back(t);
-        }
-        cv.notify_all();
-    }
-    void wait_finished(int n)
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return finished >= n; });
-    }
-    void close()
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            closing = true;
-        }
-        cv.notify_all();
-        if (th.joinable()) th.join();
-    }
-};
-} // namespace
-
 int bev_process_batch(bev_ctx_t *c, int n_frames, const bev_point_t *const *pts, const uint32_t *n_pts,
                       bev_point_t *const *ordered_out, uint8_t *const *multi_out, uint8_t *const *single_out,
                       int8_t *const *ground_mat_out)
@@ -753,13 +795,14 @@ int bev_process_batch(bev_ctx_t *c, int n_frames, const bev_point_t *const *pts,
     bool any_gm = false;
     for (int f = 0; f < n_frames && ground_mat_out; ++f) any_gm = any_gm || ground_mat_out[f] != nullptr;
 
-    Downloader dl{c, ordered_out, multi_out, single_out, any_gm ? ground_mat_out : nullptr, chunk};
-    dl.th = std::thread([&dl] { dl.run(); });
+    Downloader &dl = *c->downloader;
+    dl.begin_call();
     std::vector<uint64_t> off;
     int k = 0;
     rc = BEV_OK;
     for (int f0 = 0; f0 < n_frames && rc == BEV_OK; f0 += chunk, ++k) {
         const int nb = std::min(chunk, n_frames - f0), half = k % halves;
+        RoctxRange rc_range("bev_process_batch: chunk (upload, pipeline, hand-over to the downloader)");
         off.assign((size_t)nb + 1, 0);
         hipError_t e = hipSuccess;
         for (int f = 0; f < nb; ++f) off[f + 1] = off[f] + n_pts[f0 + f];
@@ -781,16 +824,17 @@ int bev_process_batch(bev_ctx_t *c, int n_frames, const bev_point_t *const *pts,
         const size_t base = (size_t)half * chunk;
         rc = run_pipeline(c, nb, c->st_in, off.data(), false, c->st_ordered + base * S,
                           multi_out ? c->st_multi + base * c->multi_bytes : nullptr,
-                          single_out ? c->st_single + base * c->single_bytes : nullptr, any_gm ? c->st_gm + base * S : nullptr);
+                          single_out ? c->st_single + base * c->single_bytes : nullptr, any_gm ? c->st_gm + base * S : nullptr,
+                          /*fork=*/true, /*sub_frames: two sub-batches, so that the two-stage pipeline engages*/ nb >= 8 ? (nb + 1) / 2 : 0);
         if (rc != BEV_OK) break;
         e = hipEventRecord(c->out_ready[half], c->stream);
         if (e != hipSuccess) {
             rc = hip_fail(c, e, "hipEventRecord", __LINE__);
             break;
         }
-        dl.push({f0, nb, half});
+        dl.push({f0, nb, half, ordered_out, multi_out, single_out, any_gm ? ground_mat_out : nullptr, chunk});
     }
-    dl.close(); /* drains the queue first */
+    dl.wait_finished(k); /* every chunk that was handed over has reached the caller's buffers */
     if (rc == BEV_OK && dl.err != hipSuccess) rc = hip_fail(c, dl.err, "device -> host copy", __LINE__);
     if (rc != BEV_OK) (void)hipDeviceSynchronize();
     return rc;

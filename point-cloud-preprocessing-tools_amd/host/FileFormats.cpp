@@ -206,11 +206,21 @@ int load_pcd(const std::string &path, pcl::PointCloud<pcl::PointXYZIRCT> &cloud)
     if (data_kind == "ascii") {
         for (std::size_t i = 0; i < points; ++i) {
             if (!std::getline(f, line)) return -1;
-            std::istringstream ss(line);
+            /* token by token with strtod: it accepts "nan" / "inf" like PCL's loader does (operator>> of libstdc++ does
+             * not: it fails on them and leaves every later field of the line at 0); a missing or unreadable token
+             * gives 0 for that value only */
+            const char *cur = line.c_str();
             for (auto &fd : fields)
                 for (int k = 0; k < fd.count; ++k) {
-                    double v = 0;
-                    ss >> v;
+                    while (*cur == ' ' || *cur == '\t' || *cur == '\r') ++cur;
+                    char *end = nullptr;
+                    double v = std::strtod(cur, &end);
+                    if (end == cur) { /* not a number: skip the token */
+                        v = 0;
+                        while (*cur && *cur != ' ' && *cur != '\t' && *cur != '\r') ++cur;
+                    } else {
+                        cur = end;
+                    }
                     if (k == 0) assign_field(cloud.points[i], fd.target, v);
                 }
         }

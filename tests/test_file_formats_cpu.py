@@ -110,6 +110,15 @@ def test_malformed_pcd_files_are_rejected(tmp_path):
     rc, got, _, _ = hc.pcd_load(tmp_path / "vals.pcd")
     assert rc == 0 and len(got) == 2
     assert got["row"][1] == 65535 and got["col"][1] == 65535 and got["t"][1] == 4294967295 and got["label"][1] == -32768
+    # "nan" / "inf" tokens are numbers to PCL's loader: the point keeps them AND the fields that follow on the line
+    (tmp_path / "nan.pcd").write_bytes(raw[:hdr_end].replace(b"DATA binary", b"DATA ascii").replace(b"POINTS 1000", b"POINTS 3").replace(b"WIDTH 1000", b"WIDTH 3")
+                                       + b"nan nan nan 0.5 17 901 77 -2\n1.5 inf -inf -1 3 4 5 -2\nbogus 2 3 4 5 6 7 8\n")
+    rc, got, _, _ = hc.pcd_load(tmp_path / "nan.pcd")
+    assert rc == 0 and len(got) == 3
+    assert np.isnan(got["x"][0]) and np.isnan(got["z"][0]) and got["intensity"][0] == np.float32(0.5)
+    assert (got["row"][0], got["col"][0], got["t"][0], got["label"][0]) == (17, 901, 77, -2)
+    assert got["x"][1] == np.float32(1.5) and np.isposinf(got["y"][1]) and np.isneginf(got["z"][1]) and got["row"][1] == 3
+    assert got["x"][2] == 0 and got["y"][2] == 2 and got["label"][2] == 8   # an unreadable token costs that value only
 
 
 def test_png_and_csv(tmp_path):

@@ -81,6 +81,14 @@ def test_ragged_batch_with_empty_and_tiny_frames(ctxs):
     _check_batch(p, ctx, frames)  # 6 frames through a max_batch=4 context: host-buffer chunks of max_batch / 2 frames
 
 
+def test_host_buffer_call_through_the_two_stage_pipeline(ctxs):
+    """bev_process_batch works in chunks of max_batch / 2 frames; a chunk of 8 or more frames is cut into two sub-batches
+    so that the front of one overlaps the back of the other (workspace hand-over between the stages)."""
+    p, ctx = ctxs("HDL_32E", 32)
+    frames = [synth.sweep(p, 200 + f, keep=0.7 + 0.01 * f, n_dup=100 * f) for f in range(37)]  # chunks of 16, 16, 5
+    _check_batch(p, ctx, frames)
+
+
 def test_degenerate_clouds(ctxs):
     p, ctx = ctxs("HDL_32E")
     base = synth.sweep(p, 5)
