@@ -376,7 +376,7 @@ __device__ __forceinline__ void store_ws(T *p, T v) { *p = v; }
 enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcStream = 2 };
 constexpr int kWinLen = kStripThreads + 2 * kStreamSlack; /* positions of a stream window */
 template <int kSrc>
-__global__ __launch_bounds__(kStripThreads) void k_strip_ground(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
+__global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
     constexpr bool kIdentity = kSrc == kSrcIdentity, kStream = kSrc == kSrcStream;
     /* the strips of a frame share halo columns and the lines at their seams: one XCD (one L2) per frame */
