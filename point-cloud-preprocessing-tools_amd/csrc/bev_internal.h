@@ -58,6 +58,7 @@ constexpr int kProbeStride = 127;   /* k_probe looks at every 127th point (odd: 
 constexpr int kMaxSamples = 8192;   /* => stream mode for frames of up to 2^20 points; longer ones go the general way */
 constexpr int kStreamSlack = 16;    /* positions a (row, strip) window starts before / ends after the estimate */
 constexpr int kStreamMinPrefix = 2048;
+constexpr int kStreamMaxRows = 128;  /* sensors with more rows go the general way (the stream walk keeps per-row estimates in LDS) */
 
 /* Workspace streams between the kernels of one sub-batch (see bev_exact.h for the candidate key):
  *   cand_key u32 / cand_z f32  [nf][segs][kSeg]   candidates, one segment per (row, strip), compacted in column order;

@@ -117,6 +117,44 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+/* Loads the compiler does not see, and the counted waits that go with them (stream source of the column walk).
+ * gfx950 retires loads in order among loads (and stores among stores) but counts both on vmcnt, so hipcc, which
+ * cannot tell how many of the pending operations are stores, waits for ALL of them (vmcnt(0)) before a loaded register
+ * is used in a loop that also stores — a software pipeline is drained once per iteration.  The sound rule is weaker: a
+ * load has completed once at most as many operations are outstanding as LOADS were issued after it (stores only make
+ * that wait longer, never wrong).  glds16 is an LDS-DMA load (global_load_lds_dwordx4): every lane gives its own source
+ * address, the 64 x 16 bytes land at a wave-uniform LDS address + lane * 16, no VGPR is involved, and it counts on
+ * vmcnt like any load (scripts/microbench/glds_test.hip checks both on the box). */
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void ld128(u32x4 &dst, const void *p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
+}
+__device__ __forceinline__ void ld128_16(u32x4 &dst, const void *p) /* bytes 16 .. 31 of *p */
+{
+    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(dst) : "v"(p));
+}
+__device__ __forceinline__ void ld32_nt(uint32_t &dst, const void *p)
+{
+    asm volatile("global_load_dword %0, %1, off nt" : "=v"(dst) : "v"(p));
+}
+/* all but the N newest memory operations have completed; the registers named are released by this wait: their uses
+ * cannot be scheduled above it */
+template <int N>
+__device__ __forceinline__ void wait_loads(u32x4 &a, u32x4 &b, uint32_t &c)
+{
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+
 /* A winner entry is (tag << shift) | (input index + 1).  The tag is the sub-batch generation of the workspace set:
  * entries left by earlier sub-batches carry a smaller tag, lose every atomicMax against the current one and read as
  * "empty", so the table needs no memset between sub-batches (bev_capi.hip clears it when the tag would wrap). */
@@ -142,7 +180,7 @@ __global__ __launch_bounds__(256) void k_probe(BatchPtrs b, Geometry g, int allo
     const uint32_t n = fd.n_pts;
     const bev_point_t *fp = b.pts + fd.in_offset;
     const uint32_t ns = n ? (n - 1u) / kProbeStride + 1u : 0u;
-    const bool can = allow_stream && n >= (uint32_t)kStreamMinPrefix && ns <= (uint32_t)kMaxSamples;
+    const bool can = allow_stream && n >= (uint32_t)kStreamMinPrefix && ns <= (uint32_t)kMaxSamples && g.N <= kStreamMaxRows;
     if (tid == 0) first_bad = can ? ns : 0u;
     __syncthreads();
     if (can) {
@@ -375,6 +413,8 @@ __device__ __forceinline__ void store_ws(T *p, T v) { *p = v; }
 
 enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcStream = 2 };
 constexpr int kWinLen = kStripThreads + 2 * kStreamSlack; /* positions of a stream window */
+constexpr int kWinSlots = 4;  /* rows of windows in LDS: one being read, one being indexed, two landing */
+constexpr int kWrapLen = 32;  /* positions of the wrap-around halo's mini window (last strip) */
 template <int kSrc>
 __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
@@ -408,17 +448,25 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
     __shared__ int edge_x[kGridRows], edge_y[kGridCols];   /* BEV bin of every ground-grid row's / column's lower edge */
     /* stream source: the row's points by column offset (two rows), the row each entry belongs to, and the slot of every
      * window position for the order check */
-    __shared__ uint4 rowbuf[kStream ? 2 : 1][kStream ? kStripThreads : 1][2];
-    __shared__ uint16_t rowtag[kStream ? 2 : 1][kStream ? kStripThreads : 1];
-    __shared__ uint32_t wslot[kStream ? 2 : 1][kStream ? kWinLen : 1];
+    __shared__ u32x4 win[kStream ? kWinSlots : 1][2][kStream ? kWinLen : 1];   /* windows as they lie in the input: low / high halves */
+    __shared__ u32x4 wrapw[kStream ? kWinSlots : 1][2][kStream ? kWrapLen : 1]; /* the row's first positions (wrap-around halo) */
+    __shared__ uint32_t colidx[kStream ? 2 : 1][kStream ? kStripThreads : 1];  /* column offset -> window position | (row + 1) << 16 */
+    __shared__ int est_l[kStream ? 2 : 1][kStream ? kStreamMaxRows : 1];       /* k_probe's estimates for this strip / for strip 0, every row */
     if (tid < kMaxBands) band_cursor[tid] = 0u;
     for (int k = tid; k < kSeenCodes; k += kStripThreads) seen[k] = kSkip;
     for (int x = tid; x < g.rp.mat_size; x += kStripThreads) band_tab[x] = (uint8_t)raster_band_of(x, g.rp);
     if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
     else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
     if (kStream) {
-        rowtag[0][tid] = 0;
-        rowtag[1][tid] = 0;
+        colidx[0][tid] = 0u;
+        colidx[1][tid] = 0u;
+        /* the estimates into LDS once: a global load inside the row loop would be one the compiler sees, and its use would
+         * bring back the vmcnt(0) that the counted waits below are there to avoid */
+        const uint32_t *fe = b.est + (size_t)f * N * g.strips;
+        for (int r = tid; r < N; r += kStripThreads) {
+            est_l[0][r] = (int)fe[r * g.strips + strip];
+            est_l[1][r] = (int)fe[r * g.strips];
+        }
     }
 
     /* Winner words are loaded UNCONDITIONALLY from a clamped address and decoded only when they are used, two rows
@@ -426,10 +474,12 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
      * for it — with vmcnt(0), i.e. for every point load in flight as well — inside the branch, once per row (that was
      * the shape of this loop in round 1: the software pipeline below existed on paper only). */
     auto has_slot = [&](int r) -> bool { return provider && r < N && r * H + vcol >= 0; };
-    auto load_winner_raw = [&](int r) -> uint32_t {
-        if (kIdentity) return 0u;
+    auto load_winner_raw = [&](int r, uint32_t &raw) { /* stream source: asm load, valid only behind a wait_loads */
+        raw = 0u;
+        if (kIdentity) return;
         const int fl = has_slot(r) ? r * H + vcol : 0;
-        return load_once(&fwin[fl]);
+        if (kStream) ld32_nt(raw, &fwin[fl]);
+        else raw = load_once(&fwin[fl]);
     };
     auto winner_of = [&](int r, uint32_t raw) -> uint32_t { /* input index + 1 of slot (r, this column), 0 = empty */
         if (!has_slot(r)) return 0u;
@@ -441,10 +491,15 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
      * one cached line) and is zeroed when the row is consumed, so that every iteration issues exactly three loads and
      * the compiler can wait for "all but the last six" instead of for everything */
     const Half *dummy = reinterpret_cast<const Half *>(b.ordered + frame_off);
-    auto load_point = [&](uint32_t w, Half &lo, Half &hi) {
+    auto load_point = [&](uint32_t w, u32x4 &lo, u32x4 &hi) {
         const Half *src = w != 0u ? reinterpret_cast<const Half *>(fpts + (w - 1u)) : dummy;
-        lo = src[0];
-        hi = src[1];
+        if (kStream) {
+            ld128(lo, src);
+            ld128_16(hi, src);
+        } else {
+            lo = *reinterpret_cast<const u32x4 *>(src);
+            hi = *reinterpret_cast<const u32x4 *>(src + 1);
+        }
     };
 
     /* software pipeline: while row r is handled, the points of rows r+1 .. r+kDepth and the raw winner words of the
@@ -454,130 +509,122 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
      * The stages live in small arrays indexed by r mod 3 / r mod 2 and the row loop is unrolled with compile-time
      * indices: rotating the stages through variables instead ("next = next2") makes the compiler copy registers that a
      * load is still writing, and wait for that load — the newest one — every row. */
-    constexpr int kDepth = kStream ? 1 : 2; /* the stream source has its own window in flight and fewer registers to spare */
-    Half plo[3], phi[3];   /* point of row r at [r % (kDepth + 1)] */
+    constexpr int kDepth = 2;
+    u32x4 plo[3], phi[3];  /* point of row r at [r % 3] */
     bool pfull[3];         /* the slot of that row holds a point (else: the dummy was loaded) */
     uint32_t wraw[2];      /* raw winner word of row r at [r % 2] */
-    if (kDepth == 2) {
-        const uint32_t r0 = load_winner_raw(0), r1 = load_winner_raw(1);
-        wraw[0] = load_winner_raw(2);
-        wraw[1] = load_winner_raw(3);
+    plo[0] = plo[1] = plo[2] = phi[0] = phi[1] = phi[2] = u32x4{0u, 0u, 0u, 0u};
+    {
+        uint32_t r0, r1;
+        load_winner_raw(0, r0);
+        load_winner_raw(1, r1);
+        load_winner_raw(2, wraw[0]);
+        load_winner_raw(3, wraw[1]);
+        if (kStream) {
+            wait_loads<0>(plo[0], phi[0], r0);
+            wait_loads<0>(plo[1], phi[1], r1);
+        }
         const uint32_t w0 = winner_of(0, r0), w1 = winner_of(1, r1);
         pfull[0] = w0 != 0u;
         pfull[1] = w1 != 0u;
         pfull[2] = false;
         load_point(w0, plo[0], phi[0]);
         load_point(w1, plo[1], phi[1]);
-        plo[2] = phi[2] = Half{{0, 0, 0, 0}};
-    } else {
-        wraw[0] = load_winner_raw(0);
-        wraw[1] = load_winner_raw(1);
-        const uint32_t w0 = winner_of(0, wraw[0]);
-        pfull[0] = w0 != 0u;
-        pfull[1] = pfull[2] = false;
-        load_point(w0, plo[0], phi[0]);
-        plo[1] = phi[1] = plo[2] = phi[2] = Half{{0, 0, 0, 0}};
     }
 
     /* ---- stream source (k_probe took the first T input points for sorted) ----
      * Row r's points of this strip's 256 virtual columns are consecutive in the input; they start near est[r][strip]
-     * (interpolated from sampled points).  Every thread loads ONE window position (position est - slack + tid; 32
-     * threads a second one, the window's last 32; in the last strip 36 more read the row's first positions for the two
-     * wrap-around halo columns), coalesced and in place, and drops the point into the LDS row at the offset its own
-     * (row, col) says.  One row later the owner of each column picks its point up there — unless the winner table,
-     * which now holds only the tail [T, n), says a later point has overwritten the slot.
-     * Verification (results must not depend on the guess): a thread that has found a point of the strip's OWN columns
-     * counts it and checks that the window position before it lies in the prefix and has a smaller slot.  When every
-     * one of a frame's T prefix points has been counted exactly once and no check has failed, the prefix is strictly
+     * (interpolated from sampled points).  Three rows ahead, every thread requests ONE window position (est - slack +
+     * tid; the first wave also the window's last 32 positions and, for the last strip's two wrap-around halo columns,
+     * 32 positions at the row's start) by LDS-DMA: coalesced, in place, no register.  Two steps later the window has
+     * landed (counted wait: everything requested two steps ago, see wait_loads); the thread then looks at the (row, col)
+     * of ITS position in LDS and enters the position in the row's column index; one step later the owner of each column
+     * follows the index and reads its point from the window — unless the winner table, which holds only the tail [T, n)
+     * now, says a later point has overwritten the slot (that path keeps the gather pipeline, through asm loads so that
+     * its waits are counted too).
+     * Verification (results must not depend on the guess): a thread whose position holds a point of the strip's OWN
+     * columns counts it and checks that the position before it lies in the prefix and has a smaller slot.  When all
+     * T prefix points of a frame have been counted exactly once and no check has failed, the prefix is strictly
      * ascending, every point was where its owner looked, and the result is what getOrderedCloud's scatter gives;
      * otherwise k_verdict sends the frame through the general kernels again. */
     const uint32_t T = kStream ? b.info[f].T : 0u;
-    const uint32_t *fest = kStream ? b.est + (size_t)f * N * g.strips : nullptr;
     const bool last_strip = strip == g.strips - 1;
-    Half w1lo{{0, 0, 0, 0}}, w1hi{{0, 0, 0, 0}}, w2lo{{0, 0, 0, 0}}, w2hi{{0, 0, 0, 0}}; /* window positions of the next row */
-    uint32_t est_nx = 0u, est0_nx = 0u;   /* estimates of the row after the one in flight (scalar loads, one row ahead) */
-    uint32_t w_est = 0u, w_est0 = 0u;     /* estimates the window in flight was loaded with */
     uint32_t consumed = 0u, failed = 0u;
-    uint32_t pend[2] = {0u, 0u};          /* last scatter, per load: bit 0 consumed a point, bits 1.. its window index + 1, bit 31: it is position 0 */
-    auto stream_pos = [&](uint32_t est, uint32_t est0, bool second, bool &ok) -> uint32_t {
-        long long q;
-        if (!second) q = (long long)est - kStreamSlack + tid;
-        else if (tid < 2 * kStreamSlack) q = (long long)est - kStreamSlack + kStripThreads + tid;
-        else q = (long long)est0 - (kStreamSlack - 2) + (tid - 2 * kStreamSlack); /* the row's first positions (wrap halo) */
-        ok = q >= 0 && q < (long long)T && (!second || tid < 2 * kStreamSlack || (last_strip && tid < 64));
-        return ok ? (uint32_t)q : 0u;
-    };
-    auto stream_issue = [&](int r) { /* loads of row r's window; T >= 1 in stream mode, so position 0 is always there */
+    const int first_col = strip * kStripCols - 2; /* virtual column of offset 0 */
+    auto window_pos = [&](int est, int j) -> int { return est - kStreamSlack + j; }; /* input position of window index j */
+    auto stream_issue = [&](int r) { /* LDS-DMA requests of row r's window (2 per wave, 6 for the first wave) */
         if (!kStream) return;
-        w_est = est_nx;
-        w_est0 = est0_nx;
-        bool ok1, ok2;
-        const uint32_t q1 = stream_pos(w_est, w_est0, false, ok1);
-        const Half *s1 = reinterpret_cast<const Half *>(fpts + q1);
-        w1lo = s1[0];
-        w1hi = s1[1];
-        if (wv == 0) { /* the window's last 32 positions and the wrap halo's 32: one wave (uniform branch, loads only) */
-            const uint32_t q2 = stream_pos(w_est, w_est0, true, ok2);
-            const Half *s2 = reinterpret_cast<const Half *>(fpts + q2);
-            w2lo = s2[0];
-            w2hi = s2[1];
+        const int rc = r < N ? r : N - 1;
+        const int est = est_l[0][rc], est0 = est_l[1][rc];
+        const int slot = r & (kWinSlots - 1);
+        {
+            const int q = window_pos(est, tid);
+            const Half *src = reinterpret_cast<const Half *>(fpts + (q >= 0 && q < (int)T ? q : 0));
+            glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(&win[slot][0][wv * 64])));
+            glds16(src + 1, __builtin_amdgcn_readfirstlane(lds_addr(&win[slot][1][wv * 64])));
         }
-        const int rn = r + 1 < N ? r + 1 : N - 1;
-        est_nx = fest[rn * g.strips + strip];
-        est0_nx = fest[rn * g.strips];
+        if (wv == 0) { /* wave-uniform; lanes 32 .. 63 idle */
+            if (lane < 2 * kStreamSlack) {
+                const int q = window_pos(est, kStripThreads + lane);
+                const Half *src = reinterpret_cast<const Half *>(fpts + (q >= 0 && q < (int)T ? q : 0));
+                glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(&win[slot][0][kStripThreads])));
+                glds16(src + 1, __builtin_amdgcn_readfirstlane(lds_addr(&win[slot][1][kStripThreads])));
+            }
+            if (lane < kWrapLen) {
+                const int q = est0 - (kStreamSlack - 2) + lane;
+                const Half *src = reinterpret_cast<const Half *>(fpts + (q >= 0 && q < (int)T ? q : 0));
+                glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(&wrapw[slot][0][0])));
+                glds16(src + 1, __builtin_amdgcn_readfirstlane(lds_addr(&wrapw[slot][1][0])));
+            }
+        }
     };
-    auto stream_scatter = [&](int r) { /* the window in flight belongs to row r: into the LDS row r & 1 */
-        if (!kStream) return;
-        const int pr = r & 1;
-        const long long row0 = (long long)r * H, first = row0 + (long long)strip * kStripCols - 2;
-        pend[0] = pend[1] = 0u;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (k == 1 && wv != 0) break; /* wave-uniform */
-            bool ok;
-            const uint32_t q = stream_pos(w_est, w_est0, k == 1, ok);
-            const Half &lo = k ? w2lo : w1lo, &hi = k ? w2hi : w1hi;
-            const uint32_t row = hi.w[1] & 0xffffu, col = hi.w[1] >> 16;
-            const bool valid = ok && r < N && row < (uint32_t)N && col < (uint32_t)H;
-            const long long flat = (long long)row * H + col;
-            const bool in_window = k == 0 || tid < 2 * kStreamSlack;
-            if (in_window) wslot[pr][k ? kStripThreads + tid : tid] = valid ? (uint32_t)flat : 0xffffffffu;
-            if (!valid) continue;
-            const long long off = flat - first;                       /* column offset in this strip's row */
-            const long long offw = flat - row0 + (H - ((long long)strip * kStripCols - 2)); /* ... as a wrap-around halo column */
-            if (off >= 0 && off < kStripThreads) {
-                rowbuf[pr][off][0] = make_uint4(lo.w[0], lo.w[1], lo.w[2], lo.w[3]);
-                rowbuf[pr][off][1] = make_uint4(hi.w[0], hi.w[1], hi.w[2], hi.w[3]);
-                rowtag[pr][off] = (uint16_t)(r + 1);
-                if (in_window && off >= 2 && off < 2 + kStripCols && (long long)strip * kStripCols + off - 2 < H) { /* an own column */
-                    ++consumed;
-                    pend[k] = 1u | ((uint32_t)((k ? kStripThreads + tid : tid) + 1) << 1) | (q == 0u ? 0x80000000u : 0u);
+    auto stream_index = [&](int r) { /* row r's window has landed: enter every position in the row's column index */
+        if (!kStream || r >= N) return;
+        const int est = est_l[0][r], est0 = est_l[1][r];
+        const int slot = r & (kWinSlots - 1), pr = r & 1;
+        const int row0 = r * H, first = row0 + first_col;
+        const uint32_t tag = (uint32_t)(r + 1) << 16;
+        auto one = [&](int j) { /* window index j */
+            const int q = window_pos(est, j);
+            if (q < 0 || q >= (int)T) return;
+            const uint32_t rcw = win[slot][1][j].y; /* row | col << 16 */
+            const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
+            if (row >= (uint32_t)N || col >= (uint32_t)H) return;
+            const int flat = (int)row * H + (int)col, off = flat - first;
+            if (off < 0 || off >= kStripThreads) return;
+            colidx[pr][off] = tag | (uint32_t)j;
+            if (off >= 2 && off < 2 + kStripCols && first_col + off < H) { /* a point of this strip's own columns */
+                ++consumed;
+                if (q > 0) { /* its predecessor in the input must lie in the window and have a smaller slot */
+                    if (j == 0) { failed = 1u; return; }
+                    const uint32_t pw = win[slot][1][j - 1].y;
+                    const uint32_t prow = pw & 0xffffu, pcol = pw >> 16;
+                    if (prow >= (uint32_t)N || pcol >= (uint32_t)H || (int)prow * H + (int)pcol >= flat) failed = 1u;
                 }
             }
-            if (flat >= row0 && flat < row0 + 2 && offw >= 0 && offw < kStripThreads) {
-                rowbuf[pr][offw][0] = make_uint4(lo.w[0], lo.w[1], lo.w[2], lo.w[3]);
-                rowbuf[pr][offw][1] = make_uint4(hi.w[0], hi.w[1], hi.w[2], hi.w[3]);
-                rowtag[pr][offw] = (uint16_t)(r + 1);
+        };
+        one(tid);
+        if (wv == 0 && lane < 2 * kStreamSlack) one(kStripThreads + lane);
+        if (wv == 0 && last_strip && lane < kWrapLen) { /* slots r*H and r*H + 1 as the wrap-around halo columns H, H + 1 */
+            const int q = est0 - (kStreamSlack - 2) + lane;
+            if (q >= 0 && q < (int)T) {
+                const uint32_t rcw = wrapw[slot][1][lane].y;
+                const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
+                if (row == (uint32_t)r && col < 2u) {
+                    const int off = H + (int)col - first_col;
+                    if (off >= 0 && off < kStripThreads) colidx[pr][off] = tag | 0x8000u | (uint32_t)lane;
+                }
             }
         }
     };
-    auto stream_check = [&](int r) { /* after the barrier that follows row r's scatter */
-        if (!kStream) return;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (!(pend[k] & 1u) || (pend[k] & 0x80000000u)) continue; /* nothing consumed / the very first input point */
-            const uint32_t j = ((pend[k] >> 1) & 0x3fffffffu) - 1u;
-            if (j == 0u) { failed = 1u; continue; } /* its predecessor is outside the window */
-            const uint32_t a = wslot[r & 1][j - 1u], c = wslot[r & 1][j];
-            if (a == 0xffffffffu || a >= c) failed = 1u;
-        }
-    };
-    if (kStream) { /* prologue: row 0's window into its LDS row, row 1's window in flight */
-        est_nx = fest[strip];
-        est0_nx = fest[0];
+    if (kStream) { /* prologue: rows 0 .. 2 requested, row 0 indexed */
+        lds_barrier(); /* est_l */
         stream_issue(0);
-        stream_scatter(0);
         stream_issue(1);
+        stream_issue(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier(); /* every wave's part of window 0 has landed */
+        stream_index(0);
         lds_barrier();
     }
 
@@ -596,27 +643,42 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
         constexpr int in = (decltype(I)::value + kDepth) % (kDepth + 1);   /* stage that takes row r + kDepth */
         constexpr int wu = (decltype(I)::value + kDepth) % 2, wl = decltype(I)::value % 2; /* winner word used / reloaded */
         const int par = r & 1;
-        Half cur_lo = plo[ic], cur_hi = phi[ic];
+        if (kStream) {
+            /* everything requested two steps ago — row r's override point, the winner word of row r + 2, the window of
+             * row r + 1 — has arrived once only the last step's requests are outstanding: 3 asm loads + 2 LDS-DMAs
+             * (6 in the first wave).  Steps 0 and 1 follow the prologue, whose order differs. */
+            if (r < 2) wait_loads<0>(plo[ic], phi[ic], wraw[wu]);
+            else if (wv == 0) wait_loads<9>(plo[ic], phi[ic], wraw[wu]);
+            else wait_loads<5>(plo[ic], phi[ic], wraw[wu]);
+        }
+        Half cur_lo{{plo[ic].x, plo[ic].y, plo[ic].z, plo[ic].w}}, cur_hi{{phi[ic].x, phi[ic].y, phi[ic].z, phi[ic].w}};
         if (!pfull[ic]) { /* untouched slot: value-initialised, BatchMultiBevGen.cpp:98 */
             cur_lo = Half{{0, 0, 0, 0}};
             cur_hi = Half{{0, 0, 0, 0}};
-            if (kStream && r < N && rowtag[par][tid] == (uint16_t)(r + 1)) { /* ... unless the prefix holds the slot's point */
-                const uint4 a = rowbuf[par][tid][0], c = rowbuf[par][tid][1];
-                cur_lo = Half{{a.x, a.y, a.z, a.w}};
-                cur_hi = Half{{c.x, c.y, c.z, c.w}};
+            if (kStream && r < N) { /* ... unless the prefix holds the slot's point */
+                const uint32_t e = colidx[par][tid];
+                if ((e >> 16) == (uint32_t)(r + 1)) {
+                    const int slot = r & (kWinSlots - 1), j = (int)(e & 0x7fffu);
+                    const u32x4 a = (e & 0x8000u) ? wrapw[slot][0][j] : win[slot][0][j];
+                    const u32x4 c = (e & 0x8000u) ? wrapw[slot][1][j] : win[slot][1][j];
+                    cur_lo = Half{{a.x, a.y, a.z, a.w}};
+                    cur_hi = Half{{c.x, c.y, c.z, c.w}};
+                }
             }
         }
         if (kStream) {
-            stream_check(r);        /* row r's window: scattered one step ago, a barrier since */
-            stream_scatter(r + 1);  /* row r + 1's window has arrived: into the other LDS row */
-            stream_issue(r + 2);
+            /* a window is filled by all four waves, and the order check looks one position to the left (another wave's
+             * part for a wave's first lane): every wave must have passed its wait before the window is indexed */
+            lds_barrier();
+            stream_index(r + 1); /* the row barrier below separates the index from its readers */
+            stream_issue(r + 3);
         }
         {
             const uint32_t wn = winner_of(r + kDepth, wraw[wu]);
             pfull[in] = wn != 0u;
             load_point(wn, plo[in], phi[in]);
         }
-        wraw[wl] = load_winner_raw(r + 2 * kDepth);
+        load_winner_raw(r + 2 * kDepth, wraw[wl]);
 
         const XYZI cur{__uint_as_float(cur_lo.w[0]), __uint_as_float(cur_lo.w[1]), __uint_as_float(cur_lo.w[2]),
                        __uint_as_float(cur_hi.w[0])};
@@ -740,21 +802,15 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
         prev = cur;
     };
     /* two extra iterations drain the pipeline */
-    if (kDepth == 2) {
-        for (int r0 = 0; r0 < N + 2; r0 += 6) {
-            row_step(std::integral_constant<int, 0>{}, r0);
-            if (r0 + 1 < N + 2) row_step(std::integral_constant<int, 1>{}, r0 + 1);
-            if (r0 + 2 < N + 2) row_step(std::integral_constant<int, 2>{}, r0 + 2);
-            if (r0 + 3 < N + 2) row_step(std::integral_constant<int, 3>{}, r0 + 3);
-            if (r0 + 4 < N + 2) row_step(std::integral_constant<int, 4>{}, r0 + 4);
-            if (r0 + 5 < N + 2) row_step(std::integral_constant<int, 5>{}, r0 + 5);
-        }
-    } else {
-        for (int r0 = 0; r0 < N + 2; r0 += 2) {
-            row_step(std::integral_constant<int, 0>{}, r0);
-            if (r0 + 1 < N + 2) row_step(std::integral_constant<int, 1>{}, r0 + 1);
-        }
+    for (int r0 = 0; r0 < N + 2; r0 += 6) {
+        row_step(std::integral_constant<int, 0>{}, r0);
+        if (r0 + 1 < N + 2) row_step(std::integral_constant<int, 1>{}, r0 + 1);
+        if (r0 + 2 < N + 2) row_step(std::integral_constant<int, 2>{}, r0 + 2);
+        if (r0 + 3 < N + 2) row_step(std::integral_constant<int, 3>{}, r0 + 3);
+        if (r0 + 4 < N + 2) row_step(std::integral_constant<int, 4>{}, r0 + 4);
+        if (r0 + 5 < N + 2) row_step(std::integral_constant<int, 5>{}, r0 + 5);
     }
+    if (kStream) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* no LDS-DMA may outlive the workgroup's LDS */
     lds_barrier();
     if (tid < bands) b.ncode[((size_t)f * g.emitters + strip) * bands + tid] = band_cursor[tid];
     if (kStream) {
