@@ -46,6 +46,7 @@ struct Lane {
     hipEvent_t front_done = nullptr, back_done = nullptr; /* staged mode: workspace hand-over between the two stages */
     FrameInfo *info = nullptr;  /* per frame: how its points reach their slots (k_probe / k_verdict) */
     uint32_t *est = nullptr;    /* stream frames: estimated input position of every (row, strip)'s first slot */
+    uint32_t *tail_list = nullptr, *tail_cnt = nullptr; /* ... and their tail points per (row, strip) (stream mode only) */
     uint32_t *winner = nullptr;
     uint32_t win_gen = 0; /* generation tag of the last sub-batch that used this set's winner table */
     uint32_t *cand_key = nullptr;
@@ -436,6 +437,8 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.frames = identity ? nullptr : c->d_desc[ds] + f0;
         b.info = identity ? nullptr : ln.info;
         b.est = ln.est;
+        b.tail_list = ln.tail_list;
+        b.tail_cnt = ln.tail_cnt;
         b.winner = ln.winner;
         b.win_shift = c->win_shift;
         b.ordered = d_ordered + (size_t)f0 * S;
@@ -691,6 +694,10 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipMalloc((void **)&ln.info, nb * sizeof(FrameInfo)));
         CK(hipMemset(ln.info, 0, nb * sizeof(FrameInfo)));
         CK(hipMalloc((void **)&ln.est, nb * (size_t)c->geo.N * c->geo.strips * sizeof(uint32_t)));
+        if (c->allow_stream && c->geo.N <= kStreamMaxRows && c->geo.N * c->geo.strips <= kTailBuckets) {
+            CK(hipMalloc((void **)&ln.tail_list, nb * (size_t)c->geo.N * c->geo.strips * kTailCap * sizeof(uint32_t)));
+            CK(hipMalloc((void **)&ln.tail_cnt, nb * (size_t)c->geo.N * c->geo.strips * sizeof(uint32_t)));
+        }
         CK(hipMalloc((void **)&ln.winner, nb * S * sizeof(uint32_t)));
         CK(hipMemset(ln.winner, 0, nb * S * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.cand_key, nb * (size_t)c->geo.segs * kSeg * sizeof(uint32_t)));
@@ -723,7 +730,7 @@ void bev_destroy(bev_ctx_t *c)
     for (int l = 0; l < kMaxLanes; ++l) {
         Lane &ln = c->lanes[l];
         if (ln.st) (void)hipStreamSynchronize(ln.st);
-        void *ws[] = {ln.info, ln.est, ln.winner, ln.cand_key, ln.cand_z, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
+        void *ws[] = {ln.info, ln.est, ln.tail_list, ln.tail_cnt, ln.winner, ln.cand_key, ln.cand_z, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
         for (void *p : ws)
             if (p) (void)hipFree(p);
         if (ln.done) (void)hipEventDestroy(ln.done);

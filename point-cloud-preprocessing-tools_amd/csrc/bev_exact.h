@@ -85,6 +85,16 @@ BEVX_HD bool angle_is_ground(float dx, float dy, float dz)
     float q = a / s;
     return q <= bits_to_float(kTanThresholdBits);
 }
+/* the same without a branch (0 / 0 is NaN and compares false): what the device's row loop uses */
+BEVX_HD bool angle_is_ground_flat(float dx, float dy, float dz)
+{
+    const float xx = dx * dx;
+    const float yy = dy * dy;
+    const float s = sqrtf(xx + yy);
+    const float a = fabsf(dz);
+    const float q = a / s;
+    return ((a == 0.0f) & (s == 0.0f)) | (q <= bits_to_float(kTanThresholdBits));
+}
 
 /* getBelongingGrid, BatchMultiBevGen.h:73-99 -> cell = row * 50 + col.
  * The reference mixes float and double here; every step has an exact float-only equivalent
@@ -193,10 +203,14 @@ BEVX_HD int raster_band_rows(int band, const RasterParams &rp)
  * +-2^31 (cvttsd2si -> INT_MIN) are reported as kIntMin as well.  Checked for all 2^32 floats. */
 BEVX_HD int round_half_up_bin(float v)
 {
-    if (!(v > -2147483000.0f && v < 2147483000.0f)) return kIntMin;
-    if (v >= 0.0f) return (int)floorf(v) + 1;
-    if (v >= -0.5f) return v >= -0x1p-55f ? 1 : 0;
-    return (int)ceilf(v);
+    /* written without early returns: on the device each of them was a divergent branch in the row loop */
+    const bool ok = v > -2147483000.0f && v < 2147483000.0f;
+    const bool nonneg = v >= 0.0f;
+    const float w = ok ? v : 0.0f;
+    const float f = nonneg ? floorf(w) : ceilf(w);   /* ceil of (-0.5, 0) is -0 */
+    int t = (int)f + (nonneg ? 1 : 0);
+    t = (!nonneg && v >= -0.5f) ? (v >= -0x1p-55f ? 1 : 0) : t;
+    return ok ? t : kIntMin;
 }
 BEVX_HD int bev_bin(float p, float max_range_f, float interval)
 {
@@ -225,11 +239,13 @@ BEVX_HD uint32_t bev_code_from_bins(int x, int y, float pz, const RasterParams &
 }
 BEVX_HD uint32_t bev_code(float px, float py, float pz, int label, const RasterParams &rp)
 {
-    if (label == 0) return kSkip;                                      /* :285, :349 */
-    int x = bev_bin_rp(px, rp);                                        /* :279, :343 */
-    int y = bev_bin_rp(py, rp);                                        /* :280, :344 */
-    if (x < 0 || x >= rp.mat_size || y < 0 || y >= rp.mat_size) return kSkip;
-    return bev_code_from_bins(x, y, pz, rp);
+    /* straight-line (selects, no early return): the walk calls this once per slot */
+    const int x = bev_bin_rp(px, rp);                                  /* :279, :343 */
+    const int y = bev_bin_rp(py, rp);                                  /* :280, :344 */
+    const bool in = (label != 0) &                                     /* :285, :349 */
+                    ((unsigned)x < (unsigned)rp.mat_size) & ((unsigned)y < (unsigned)rp.mat_size);
+    const uint32_t code = bev_code_from_bins(in ? x : 0, in ? y : 0, pz, rp);
+    return in ? code : kSkip;
 }
 BEVX_HD int code_x(uint32_t c) { return (int)(c & 511u); }
 BEVX_HD int code_y(uint32_t c) { return (int)((c >> 9) & 511u); }

@@ -58,6 +58,9 @@ constexpr int kProbeStride = 127;   /* k_probe looks at every 127th point (odd: 
 constexpr int kMaxSamples = 8192;   /* => stream mode for frames of up to 2^20 points; longer ones go the general way */
 constexpr int kStreamSlack = 16;    /* positions a (row, strip) window starts before / ends after the estimate */
 constexpr int kStreamMinPrefix = 2048;
+constexpr int kTailCap = 64;         /* tail points (those after the sorted prefix) a (row, strip) can list; more: general way */
+constexpr int kTailMax = 16384;     /* ... a frame can have */
+constexpr int kTailBuckets = 2048;  /* (row, strip) pairs of a frame that k_probe can count in LDS */
 constexpr int kStreamMaxRows = 128;  /* sensors with more rows go the general way (the stream walk keeps per-row estimates in LDS) */
 
 /* Workspace streams between the kernels of one sub-batch (see bev_exact.h for the candidate key):
@@ -90,6 +93,8 @@ struct BatchPtrs {
     const FrameDesc *frames;
     FrameInfo *info;             /* [nf] (nullptr: every frame general) */
     uint32_t *est;               /* [nf][N][strips]: stream frames: estimated input position of slot (r, first column of strip - 2) */
+    uint32_t *tail_list;         /* [nf][N][strips][kTailCap]: stream frames: column offset | input index << 8 of the tail points (nullptr: no stream mode) */
+    uint32_t *tail_cnt;          /* [nf][N][strips] */
     uint32_t *winner;            /* [nf][S]  (win_tag << win_shift) | index+1 of the last input point per slot */
     uint32_t win_tag;            /* generation of this sub-batch in its workspace set (0: table was cleared) */
     int win_shift;               /* bits of index+1 */

@@ -171,20 +171,23 @@ __device__ __forceinline__ uint32_t winner_index(uint32_t w, uint32_t tag, int s
  * strictly ascending bound a prefix [0, T) that is TAKEN for sorted; for every (row, strip) the position of its first
  * slot inside that prefix is estimated by interpolation between the two samples around it.  Nothing here is trusted:
  * the stream walk verifies every point it consumes and a frame that fails is redone the general way. */
-__global__ __launch_bounds__(256) void k_probe(BatchPtrs b, Geometry g, int allow_stream)
+constexpr int kProbeThreads = 1024; /* one workgroup per frame: its latency is the kernel's */
+__global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g, int allow_stream)
 {
     __shared__ uint32_t samp[kMaxSamples]; /* slot of sample k (position k * kProbeStride) */
-    __shared__ uint32_t first_bad;
+    __shared__ uint32_t first_bad, overflow;
+    __shared__ uint32_t tcnt[kTailBuckets]; /* tail points listed per (row, strip) */
     const int f = blockIdx.x, tid = threadIdx.x;
     const FrameDesc fd = b.frames[f];
     const uint32_t n = fd.n_pts;
     const bev_point_t *fp = b.pts + fd.in_offset;
     const uint32_t ns = n ? (n - 1u) / kProbeStride + 1u : 0u;
-    const bool can = allow_stream && n >= (uint32_t)kStreamMinPrefix && ns <= (uint32_t)kMaxSamples && g.N <= kStreamMaxRows;
+    const bool can = allow_stream && n >= (uint32_t)kStreamMinPrefix && ns <= (uint32_t)kMaxSamples && g.N <= kStreamMaxRows &&
+                     g.N * g.strips <= kTailBuckets && n < (1u << 24) && b.tail_list != nullptr;
     if (tid == 0) first_bad = can ? ns : 0u;
     __syncthreads();
     if (can) {
-        for (uint32_t k = tid; k < ns; k += 256u) {
+        for (uint32_t k = tid; k < ns; k += (uint32_t)kProbeThreads) {
             const size_t i = (size_t)k * kProbeStride;
             const uint32_t rc = reinterpret_cast<const uint32_t *>(fp + i)[5]; /* row | col << 16 */
             const uint32_t row = rc & 0xffffu, col = rc >> 16;
@@ -197,17 +200,43 @@ __global__ __launch_bounds__(256) void k_probe(BatchPtrs b, Geometry g, int allo
             samp[k] = sl;
         }
         __syncthreads();
-        for (uint32_t k = tid; k < ns; k += 256u) /* first sample that is out of range or not above its predecessor */
+        for (uint32_t k = tid; k < ns; k += (uint32_t)kProbeThreads) /* first sample that is out of range or not above its predecessor */
             if (samp[k] == 0xffffffffu || (k > 0u && samp[k] <= samp[k - 1u])) atomicMin(&first_bad, k);
         __syncthreads();
     }
     const uint32_t m = first_bad;                                      /* samples 0 .. m-1 ascend */
-    const uint32_t T = m ? (m - 1u) * kProbeStride + 1u : 0u;          /* the last of them is position T - 1 */
-    const bool stream = can && T >= (uint32_t)kStreamMinPrefix && 2u * T >= n;
-    if (tid == 0) b.info[f] = FrameInfo{stream ? T : 0u, stream ? kFrameStream : kFrameGeneral, 0u, 0u};
-    if (!stream) return;
+    const uint32_t T0 = m ? (m - 1u) * kProbeStride + 1u : 0u;         /* the last of them is position T0 - 1 */
+    /* ... and the points after it, one by one, up to the first that does not ascend (at the latest the successor of the
+     * sample that failed): a sweep that is sorted to its end has no tail at all, and an appended block of other points
+     * starts exactly where the prefix ends — otherwise up to 126 sorted points of ONE (row, strip) would be "tail" */
+    __syncthreads();
+    if (tid == 0) first_bad = T0 + (uint32_t)kProbeStride + 1u < n ? T0 + (uint32_t)kProbeStride + 1u : n;
+    __syncthreads();
+    if (can && m && tid <= kProbeStride) {
+        const uint32_t i = T0 + (uint32_t)tid;
+        if (i < n) {
+            const uint32_t rc0 = reinterpret_cast<const uint32_t *>(fp + i - 1u)[5], rc1 = reinterpret_cast<const uint32_t *>(fp + i)[5];
+            const uint32_t r0 = rc0 & 0xffffu, c0 = rc0 >> 16, r1 = rc1 & 0xffffu, c1 = rc1 >> 16;
+            const bool ok = r0 < (uint32_t)g.N && c0 < (uint32_t)g.H && r1 < (uint32_t)g.N && c1 < (uint32_t)g.H &&
+                            r1 * (uint32_t)g.H + c1 > r0 * (uint32_t)g.H + c0;
+            if (!ok) atomicMin(&first_bad, i);
+        }
+    }
+    __syncthreads();
+    const uint32_t T = m ? first_bad : 0u;
+    const bool stream = can && T >= (uint32_t)kStreamMinPrefix && n - T <= (uint32_t)kTailMax;
+    if (!stream) { /* (`consumed` of a general frame says why, for bev_debug_get_frame_info: 1 not eligible, 2 prefix too
+                    * short, 3 tail too long, 4 a (row, strip) with more than kTailCap tail points) */
+        if (tid == 0) b.info[f] = FrameInfo{0u, kFrameGeneral, !can ? 1u : (T < (uint32_t)kStreamMinPrefix ? 2u : 3u), 0u};
+        return;
+    }
     uint32_t *fest = b.est + (size_t)f * g.N * g.strips;
-    for (int i = tid; i < g.N * g.strips; i += 256) {
+    uint32_t slot_last; /* of position T - 1 (in range and above the last sample's: checked above) */
+    {
+        const uint32_t rc = reinterpret_cast<const uint32_t *>(fp + (T - 1u))[5];
+        slot_last = (rc & 0xffffu) * (uint32_t)g.H + (rc >> 16);
+    }
+    for (int i = tid; i < g.N * g.strips; i += kProbeThreads) {
         const int r = i / g.strips, st = i - r * g.strips;
         const long long want = (long long)r * g.H + (long long)st * kStripCols - 2; /* first slot of the strip's window */
         uint32_t est = 0u;
@@ -221,12 +250,62 @@ __global__ __launch_bounds__(256) void k_probe(BatchPtrs b, Geometry g, int allo
             if (lo + 1u < m) {
                 const uint32_t s1 = samp[lo + 1u];
                 est = lo * kProbeStride + (uint32_t)(((unsigned long long)(want - s0) * kProbeStride) / (s1 - s0));
-            } else {
-                est = T; /* beyond the last sample: nothing of the prefix lies there */
+            } else if (want >= (long long)slot_last) { /* at or beyond the prefix's last point */
+                est = want > (long long)slot_last ? T : T - 1u;
+            } else { /* between the last sample and the prefix's last point (position T - 1) */
+                const uint32_t p0 = lo * kProbeStride;
+                est = p0 + (uint32_t)(((unsigned long long)(want - s0) * (T - 1u - p0)) / (slot_last - s0));
             }
         }
         fest[i] = est < T ? est : T;
     }
+
+    /* The tail [T, n): too few points to be worth a pass of the order scan (scattered atomics run at a twentieth of the
+     * rate of the scan's coalesced ones), and the stream walk has no winner table to look them up in.  They are listed
+     * per (row, strip) — under every strip whose 256 virtual columns hold the slot: its own, a neighbour's halo, strip
+     * 0's flat-index halo of the row below, the last strip's wrap-around halo — as column offset | input index << 8, in
+     * any order; the walk drops them over the prefix's points of the same row, the last of several points of one slot
+     * winning (it settles that per row, among at most kTailCap entries). */
+    for (int i = tid; i < g.N * g.strips; i += kProbeThreads) tcnt[i] = 0u;
+    if (tid == 0) overflow = 0u;
+    __syncthreads();
+    uint32_t *flist = b.tail_list + (size_t)f * g.N * g.strips * kTailCap;
+    auto append = [&](int row, int strip, int off, uint32_t i) {
+        const int bucket = row * g.strips + strip;
+        const uint32_t pos = atomicAdd(&tcnt[bucket], 1u);
+        if (pos < (uint32_t)kTailCap) flist[(size_t)bucket * kTailCap + pos] = (uint32_t)off | (i << 8);
+        else overflow = 1u;
+    };
+    constexpr int kPer = 8; /* loads in flight per thread: a 5000-point tail is one trip */
+    for (uint32_t i0 = T; i0 < n; i0 += (uint32_t)kProbeThreads * kPer) {
+        uint32_t rc[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const uint32_t i = i0 + (uint32_t)kProbeThreads * k + tid;
+            rc[k] = load_once(reinterpret_cast<const uint32_t *>(fp + (i < n ? i : n - 1u)) + 5);
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const uint32_t i = i0 + (uint32_t)kProbeThreads * k + tid;
+            const int row = (int)(rc[k] & 0xffffu), col = (int)(rc[k] >> 16);
+            if (i >= n || row >= g.N || col >= g.H) continue; /* :106-111 */
+            const int st = col / kStripCols, c = col - st * kStripCols;
+            append(row, st, c + 2, i);
+            if (c < 2 && st > 0) append(row, st - 1, kStripCols + 2 + c, i);
+            if (c >= kStripCols - 2 && st + 1 < g.strips) append(row, st + 1, c - (kStripCols - 2), i);
+            if (col >= g.H - 2 && row + 1 < g.N) append(row + 1, 0, col - (g.H - 2), i);
+            if (col < 2) {
+                const int off = g.H + col - ((g.strips - 1) * kStripCols - 2);
+                if (off < kStripThreads) append(row, g.strips - 1, off, i);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *fcnt = b.tail_cnt + (size_t)f * g.N * g.strips;
+    for (int i = tid; i < g.N * g.strips; i += kProbeThreads) fcnt[i] = tcnt[i] < (uint32_t)kTailCap ? tcnt[i] : (uint32_t)kTailCap;
+    /* a list that does not hold its (row, strip)'s tail points: the frame goes the general way (the scan repeats the
+     * scatter of the tail among all the others) */
+    if (tid == 0) b.info[f] = overflow ? FrameInfo{0u, kFrameGeneral, 4u, 0u} : FrameInfo{T, kFrameStream, 0u, 0u};
 }
 
 /* after the stream walk: a frame whose consumed points do not add up to its prefix, or with a failed check, is redone */
@@ -241,7 +320,7 @@ __global__ __launch_bounds__(256) void k_verdict(FrameInfo *info, int nf)
 /* ------------------------------------------------------------------------- */
 /* getOrderedCloud, BatchMultiBevGen.cpp:102-116: bounds test + slot index;
  * "last point in input order wins" == max input index per slot.            */
-constexpr int kSeenBits = 11, kSeenCodes = 1 << kSeenBits; /* the walk's memo of listed BEV codes: 8 KB of LDS */
+constexpr int kSeenBits = 11; /* the walk's memo of listed BEV codes: 2048 entries, 8 KB of LDS */
 constexpr int kScanPerThread = 4;
 constexpr int kScanIdxBits = 10; /* 256 * kScanPerThread = 1024 points per block */
 constexpr int kScanRowBins = 128; /* rows the LDS regrouping below can bin (more rows: plain path) */
@@ -261,7 +340,7 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
     if (info) {
         const FrameInfo fi = info[f];
         if (pass == 0) {
-            if (fi.mode == kFrameStream) first = fi.T; /* the prefix is read in place by the stream walk */
+            if (fi.mode == kFrameStream) return; /* read in place by the stream walk; k_probe has listed its tail */
         } else if (fi.mode != kFrameRedo) {
             return;
         }
@@ -412,19 +491,26 @@ template <class T>
 __device__ __forceinline__ void store_ws(T *p, T v) { *p = v; }
 
 enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcStream = 2 };
-constexpr int kWinLen = kStripThreads + 2 * kStreamSlack; /* positions of a stream window */
-constexpr int kWinSlots = 4;  /* rows of windows in LDS: one being read, one being indexed, two landing */
-constexpr int kWrapLen = 32;  /* positions of the wrap-around halo's mini window (last strip) */
+/* Gives a wave-uniform value a scalar register of its own.  Kernel arguments arrive as 8-register tuples; the walk keeps
+ * more uniform values alive than there are scalar registers, and the compiler spills and restores whole tuples (through
+ * lanes of a vector register, one VALU instruction per dword): the raster constants came back eight at a time around
+ * every use — a third of the walk's vector instructions. */
+template <class T>
+__device__ __forceinline__ T own_sgpr(T v)
+{
+    asm volatile("" : "+s"(v));
+    return v;
+}
 template <int kSrc>
-__global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
+__global__ __launch_bounds__(kStripThreads, 4) void k_strip_ground(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
     constexpr bool kIdentity = kSrc == kSrcIdentity, kStream = kSrc == kSrcStream;
     /* the strips of a frame share halo columns and the lines at their seams: one XCD (one L2) per frame */
     int f, strip;
     if (!map_block_xcd(blockIdx.x, nf, g.strips, f, strip)) return;
     if (!kIdentity && b.info && b.info[f].mode != want_mode) return; /* another launch of this kernel has the frame */
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int N = g.N, H = g.H, lo_row = g.N - g.G;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = own_sgpr(g.N), H = own_sgpr(g.H), lo_row = own_sgpr(g.N - g.G);
     const size_t frame_off = (size_t)f * g.S;
     const int bands = g.raster_bands;
 
@@ -432,6 +518,9 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
     const bool provider = (v < H + 2) && (v >= 0 || strip == 0);     /* has a point to load */
     const bool outcol = tid >= 2 && tid < 2 + kStripCols && v < H;   /* owns column v's outputs */
     const int vcol = v >= H ? v - H : v;                             /* wrap; v < 0 keeps the flat rule */
+    /* stream source: (row | col << 16) of the thread's slot in row 0 (the tail of row -1 for strip 0's left halo: never
+     * there; column 0xffff for threads without a slot: never there either) */
+    const uint32_t slot_rc = !provider ? 0xffff0000u : (v < 0 ? ((uint32_t)(H + v) << 16) + 0xffffffffu : (uint32_t)vcol << 16);
 
     const bev_point_t *fpts = kIdentity ? (b.pts + frame_off) : (b.pts + b.frames[f].in_offset);
     const uint32_t *fwin = b.winner + frame_off;
@@ -444,28 +533,33 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
     __shared__ uint32_t wave_cnt[2][kWaves];               /* per-wave candidate counts of the row being written */
     __shared__ uint32_t band_cursor[kMaxBands];            /* entries already in this strip's code list of each band */
     __shared__ uint8_t band_tab[512];                      /* x bin -> raster band */
-    __shared__ uint32_t seen[kSeenCodes];                  /* direct-mapped memo of codes this strip has already listed */
+    constexpr int kSeenB = kStream ? kSeenBits - 1 : kSeenBits; /* (the stream source needs the LDS for its row buffers) */
+    __shared__ uint32_t seen[1 << kSeenB];                 /* direct-mapped memo of codes this strip has already listed */
     __shared__ int edge_x[kGridRows], edge_y[kGridCols];   /* BEV bin of every ground-grid row's / column's lower edge */
-    /* stream source: the row's points by column offset (two rows), the row each entry belongs to, and the slot of every
-     * window position for the order check */
-    __shared__ u32x4 win[kStream ? kWinSlots : 1][2][kStream ? kWinLen : 1];   /* windows as they lie in the input: low / high halves */
-    __shared__ u32x4 wrapw[kStream ? kWinSlots : 1][2][kStream ? kWrapLen : 1]; /* the row's first positions (wrap-around halo) */
-    __shared__ uint32_t colidx[kStream ? 2 : 1][kStream ? kStripThreads : 1];  /* column offset -> window position | (row + 1) << 16 */
-    __shared__ int est_l[kStream ? 2 : 1][kStream ? kStreamMaxRows : 1];       /* k_probe's estimates for this strip / for strip 0, every row */
+    /* stream source (see below): three rows of points by column offset, the first wave's extra window positions, the
+     * second wave's tail points, the estimates and tail counts of every row */
+    __shared__ u32x4 rowbuf[3][2][kStream ? kStripThreads : 1];
+    __shared__ u32x4 xwin[kStream ? 2 : 1][2][kStream ? 64 : 1];
+    __shared__ u32x4 twin[kStream ? 2 : 1][2][kStream ? 64 : 1];
+    __shared__ uint32_t lastrc[kStream ? 2 : 1][kStripThreads / 64];
+    __shared__ int est_l[2][kStream ? kStreamMaxRows : 1];
+    __shared__ uint32_t tcnt_l[kStream ? kStreamMaxRows : 1];
     if (tid < kMaxBands) band_cursor[tid] = 0u;
-    for (int k = tid; k < kSeenCodes; k += kStripThreads) seen[k] = kSkip;
+    for (int k = tid; k < (1 << kSeenB); k += kStripThreads) seen[k] = kSkip;
     for (int x = tid; x < g.rp.mat_size; x += kStripThreads) band_tab[x] = (uint8_t)raster_band_of(x, g.rp);
     if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
     else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
     if (kStream) {
-        colidx[0][tid] = 0u;
-        colidx[1][tid] = 0u;
-        /* the estimates into LDS once: a global load inside the row loop would be one the compiler sees, and its use would
-         * bring back the vmcnt(0) that the counted waits below are there to avoid */
+        /* no entry of the row buffers may look like a point of the slot it stands for: row 0xffff does not exist */
+        for (int k = 0; k < 3; ++k) rowbuf[k][1][tid] = u32x4{0u, 0xffffffffu, 0u, 0u};
+        /* estimates and tail counts into LDS once: a global load the compiler sees inside the row loop would bring back
+         * the vmcnt(0) that the counted waits below are there to avoid */
         const uint32_t *fe = b.est + (size_t)f * N * g.strips;
+        const uint32_t *fc = b.tail_cnt + (size_t)f * N * g.strips;
         for (int r = tid; r < N; r += kStripThreads) {
             est_l[0][r] = (int)fe[r * g.strips + strip];
             est_l[1][r] = (int)fe[r * g.strips];
+            tcnt_l[r] = fc[r * g.strips + strip];
         }
     }
 
@@ -474,12 +568,11 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
      * for it — with vmcnt(0), i.e. for every point load in flight as well — inside the branch, once per row (that was
      * the shape of this loop in round 1: the software pipeline below existed on paper only). */
     auto has_slot = [&](int r) -> bool { return provider && r < N && r * H + vcol >= 0; };
-    auto load_winner_raw = [&](int r, uint32_t &raw) { /* stream source: asm load, valid only behind a wait_loads */
+    auto load_winner_raw = [&](int r, uint32_t &raw) {
         raw = 0u;
-        if (kIdentity) return;
+        if (kIdentity || kStream) return; /* the stream source has no winner table */
         const int fl = has_slot(r) ? r * H + vcol : 0;
-        if (kStream) ld32_nt(raw, &fwin[fl]);
-        else raw = load_once(&fwin[fl]);
+        raw = load_once(&fwin[fl]);
     };
     auto winner_of = [&](int r, uint32_t raw) -> uint32_t { /* input index + 1 of slot (r, this column), 0 = empty */
         if (!has_slot(r)) return 0u;
@@ -492,14 +585,10 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
      * the compiler can wait for "all but the last six" instead of for everything */
     const Half *dummy = reinterpret_cast<const Half *>(b.ordered + frame_off);
     auto load_point = [&](uint32_t w, u32x4 &lo, u32x4 &hi) {
+        if (kStream) return; /* window positions instead: issue_P below */
         const Half *src = w != 0u ? reinterpret_cast<const Half *>(fpts + (w - 1u)) : dummy;
-        if (kStream) {
-            ld128(lo, src);
-            ld128_16(hi, src);
-        } else {
-            lo = *reinterpret_cast<const u32x4 *>(src);
-            hi = *reinterpret_cast<const u32x4 *>(src + 1);
-        }
+        lo = *reinterpret_cast<const u32x4 *>(src);
+        hi = *reinterpret_cast<const u32x4 *>(src + 1);
     };
 
     /* software pipeline: while row r is handled, the points of rows r+1 .. r+kDepth and the raw winner words of the
@@ -520,10 +609,6 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
         load_winner_raw(1, r1);
         load_winner_raw(2, wraw[0]);
         load_winner_raw(3, wraw[1]);
-        if (kStream) {
-            wait_loads<0>(plo[0], phi[0], r0);
-            wait_loads<0>(plo[1], phi[1], r1);
-        }
         const uint32_t w0 = winner_of(0, r0), w1 = winner_of(1, r1);
         pfull[0] = w0 != 0u;
         pfull[1] = w1 != 0u;
@@ -532,100 +617,191 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
         load_point(w1, plo[1], phi[1]);
     }
 
-    /* ---- stream source (k_probe took the first T input points for sorted) ----
-     * Row r's points of this strip's 256 virtual columns are consecutive in the input; they start near est[r][strip]
-     * (interpolated from sampled points).  Three rows ahead, every thread requests ONE window position (est - slack +
-     * tid; the first wave also the window's last 32 positions and, for the last strip's two wrap-around halo columns,
-     * 32 positions at the row's start) by LDS-DMA: coalesced, in place, no register.  Two steps later the window has
-     * landed (counted wait: everything requested two steps ago, see wait_loads); the thread then looks at the (row, col)
-     * of ITS position in LDS and enters the position in the row's column index; one step later the owner of each column
-     * follows the index and reads its point from the window — unless the winner table, which holds only the tail [T, n)
-     * now, says a later point has overwritten the slot (that path keeps the gather pipeline, through asm loads so that
-     * its waits are counted too).
-     * Verification (results must not depend on the guess): a thread whose position holds a point of the strip's OWN
-     * columns counts it and checks that the position before it lies in the prefix and has a smaller slot.  When all
-     * T prefix points of a frame have been counted exactly once and no check has failed, the prefix is strictly
-     * ascending, every point was where its owner looked, and the result is what getOrderedCloud's scatter gives;
-     * otherwise k_verdict sends the frame through the general kernels again. */
+    /* ---- stream source (k_probe took the first T input points for sorted, and listed the rest per (row, strip)) ----
+     * Row rho's points of this strip's 256 virtual columns are consecutive in the input; they start near
+     * est[rho][strip] (interpolated from sampled points).  Every thread owns ONE window position (est - slack + tid; the
+     * first wave also the window's last 32 positions and, for the last strip's two wrap-around halo columns, 32
+     * positions at the row's start), loads it coalesced and in place four steps before the row is needed, looks at the
+     * (row, col) the point carries and, two steps later, drops the point into the row buffer at its column offset.
+     * The tail points of the (row, strip) — at most kTailCap, listed by k_probe, none shadowed by a later one — follow
+     * one step later through the second wave, so that they overwrite prefix points of the same slot as the reference's
+     * scatter would.  One step after that the owner of each column reads its slot from the row buffer; an entry whose
+     * (row, col) is not the slot's own is an empty slot.  Steps are separated by the row barrier, three row buffers
+     * rotate, nothing but LDS is shared.
+     * Verification (results must not depend on the estimate): a position that holds a point of the strip's OWN columns
+     * counts it and checks that the position before it lies in the prefix and has a smaller slot (across wave edges
+     * one step later, through LDS).  When all T prefix points of a frame have been counted exactly once and no check has
+     * failed, the prefix is strictly ascending, every point was where its strip looked, and the result is what
+     * getOrderedCloud's scatter gives; otherwise k_verdict sends the frame through the general kernels again.
+     * Loads are asm / LDS-DMA with counted waits: every step each wave issues its auxiliary loads first and its two
+     * position loads last, so "all but the two newest" (wait_loads<2>) is everything issued before the previous step's
+     * position loads. */
     const uint32_t T = kStream ? b.info[f].T : 0u;
     const bool last_strip = strip == g.strips - 1;
     uint32_t consumed = 0u, failed = 0u;
     const int first_col = strip * kStripCols - 2; /* virtual column of offset 0 */
-    auto window_pos = [&](int est, int j) -> int { return est - kStreamSlack + j; }; /* input position of window index j */
-    auto stream_issue = [&](int r) { /* LDS-DMA requests of row r's window (2 per wave, 6 for the first wave) */
-        if (!kStream) return;
-        const int rc = r < N ? r : N - 1;
-        const int est = est_l[0][rc], est0 = est_l[1][rc];
-        const int slot = r & (kWinSlots - 1);
+    uint32_t te[3] = {0u, 0u, 0u};                /* second wave: tail entry of this lane, rows rho at [rho % 3] */
+    bool dneed = false;                           /* lane 0: the check against the previous wave's last position is due */
+    int dflat = 0;
+    const uint32_t *ftail = kStream ? b.tail_list + ((size_t)f * N * g.strips + strip) * kTailCap : nullptr;
+    const int tail_stride = g.strips * kTailCap;  /* words from one row's list to the next */
+    auto clamp_row = [&](int rho) -> int { return rho < N ? rho : N - 1; };
+    auto issue_P = [&](auto STG, int rho) { /* the thread's window position of row rho */
+        constexpr int sg = decltype(STG)::value;
+        const int q = est_l[0][clamp_row(rho)] - kStreamSlack + tid;
+        const Half *src = reinterpret_cast<const Half *>(fpts + (q >= 0 && q < (int)T ? q : 0));
+        ld128(plo[sg], src);
+        ld128_16(phi[sg], src);
+    };
+    auto issue_X = [&](int rho) { /* first wave: lanes 0 .. 31 positions 256 .. 287, lanes 32 .. 63 the row's first positions */
+        const int rc = clamp_row(rho);
+        const int q = lane < 32 ? est_l[0][rc] - kStreamSlack + kStripThreads + lane : est_l[1][rc] - (kStreamSlack - 2) + (lane - 32);
+        const Half *src = reinterpret_cast<const Half *>(fpts + (q >= 0 && q < (int)T ? q : 0));
+        glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(&xwin[rho & 1][0][0])));
+        glds16(src + 1, __builtin_amdgcn_readfirstlane(lds_addr(&xwin[rho & 1][1][0])));
+    };
+    auto issue_TE = [&](auto STG, int rho) { /* second wave: this lane's entry of the row's tail list (stale past the count) */
+        constexpr int sg = decltype(STG)::value;
+        ld32_nt(te[sg], ftail + (size_t)clamp_row(rho) * tail_stride + lane);
+    };
+    /* second wave: which of row rho's listed tail points are the last of their slot (getOrderedCloud's scatter keeps the
+     * last writer, BatchMultiBevGen.cpp:112).  Lanes whose entries share a column offset find each other with eight
+     * ballots (one per offset bit); only then — a few times per frame — the group is walked.  Entries that lose, and
+     * lanes past the list's count, become 0xffffffff. */
+    auto settle = [&](auto STG, int rho) {
+        constexpr int sg = decltype(STG)::value;
+        const bool on = rho < N && (uint32_t)lane < tcnt_l[clamp_row(rho)];
+        const uint32_t e = te[sg];
+        const uint32_t off = e & 0xffu, idx = e >> 8;
+        unsigned long long peers = __ballot(on);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long m = __ballot((off >> bit) & 1u);
+            peers &= ((off >> bit) & 1u) ? m : ~m;
+        }
+        bool dead = !on;
+        unsigned long long crowd = __ballot(on && __popcll(peers) > 1);
+        while (crowd) { /* wave-uniform */
+            const int j = __ffsll((long long)crowd) - 1;
+            crowd &= crowd - 1ull;
+            const uint32_t ej = (uint32_t)__shfl((int)e, j);
+            if (on && (ej & 0xffu) == off && (ej >> 8) > idx) dead = true;
+        }
+        te[sg] = dead ? 0xffffffffu : e;
+    };
+    auto issue_TP = [&](auto STG, int rho) { /* second wave: the (settled) tail points of row rho, by LDS-DMA */
+        constexpr int sg = decltype(STG)::value;
+        const bool on = te[sg] != 0xffffffffu;
+        const Half *src = reinterpret_cast<const Half *>(fpts + (on ? (te[sg] >> 8) : 0u));
+        glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(&twin[rho & 1][0][0])));
+        glds16(src + 1, __builtin_amdgcn_readfirstlane(lds_addr(&twin[rho & 1][1][0])));
+    };
+    /* one window position: into the row buffer, counted and checked */
+    auto place = [&](int rho, int q, const u32x4 &lo, const u32x4 &hi, bool first_of_group, int dwave) {
+        const uint32_t rcw = hi.y; /* row | col << 16 */
+        const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
+        const bool inpre = q >= 0 && q < (int)T;
+        const bool valid = inpre && row < (uint32_t)N && col < (uint32_t)H;
+        const int flat = (int)row * H + (int)col, off = flat - (rho * H + first_col);
+        /* (a window of the last strip runs into the next row: those points are not this row's wrap-around halo) */
+        const bool inr = valid && (unsigned)off < (unsigned)kStripThreads && flat < (rho + 1) * H;
+        if (inr) {
+            rowbuf[rho % 3][0][off] = lo;
+            rowbuf[rho % 3][1][off] = hi;
+        }
+        const bool own = inr && off >= 2 && off < 2 + kStripCols && first_col + off < H;
+        consumed += own ? 1u : 0u;
+        /* its predecessor in the input must lie in the prefix and have a smaller slot */
+        const uint32_t pw = (uint32_t)__shfl_up((int)rcw, 1);
+        const uint32_t prow = pw & 0xffffu, pcol = pw >> 16;
+        const bool pok = prow < (uint32_t)N && pcol < (uint32_t)H && (int)prow * H + (int)pcol < flat;
+        /* (straight-line: `if (a) failed = 1; else dflat = flat;` becomes a store through a selected pointer, and the
+         * variables stay in scratch memory — a load the compiler waits for with vmcnt(0) every step) */
+        const bool chk = own && q > 0;
+        const bool bad = chk && (first_of_group ? dwave < 0 /* window position 0: the estimate was too high */ : !pok);
+        const bool defer = chk && first_of_group && dwave >= 0;
+        failed |= bad ? 1u : 0u;
+        dneed = dneed | defer;
+        dflat = defer ? flat : dflat;
+    };
+    auto scatter = [&](auto STG, int rho) { /* the prefix positions of row rho -> row buffer */
+        constexpr int sg = decltype(STG)::value;
+        /* last step's open check: the lane's point against the last position of the wave before */
         {
-            const int q = window_pos(est, tid);
-            const Half *src = reinterpret_cast<const Half *>(fpts + (q >= 0 && q < (int)T ? q : 0));
-            glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(&win[slot][0][wv * 64])));
-            glds16(src + 1, __builtin_amdgcn_readfirstlane(lds_addr(&win[slot][1][wv * 64])));
+            const uint32_t pw = lastrc[(rho - 1) & 1][wv == 0 ? kStripThreads / 64 - 1 : wv - 1];
+            const uint32_t prow = pw & 0xffffu, pcol = pw >> 16;
+            const bool pok = prow < (uint32_t)N && pcol < (uint32_t)H && (int)prow * H + (int)pcol < dflat;
+            failed |= (dneed && !pok) ? 1u : 0u;
+            dneed = false;
         }
-        if (wv == 0) { /* wave-uniform; lanes 32 .. 63 idle */
-            if (lane < 2 * kStreamSlack) {
-                const int q = window_pos(est, kStripThreads + lane);
-                const Half *src = reinterpret_cast<const Half *>(fpts + (q >= 0 && q < (int)T ? q : 0));
-                glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(&win[slot][0][kStripThreads])));
-                glds16(src + 1, __builtin_amdgcn_readfirstlane(lds_addr(&win[slot][1][kStripThreads])));
-            }
-            if (lane < kWrapLen) {
-                const int q = est0 - (kStreamSlack - 2) + lane;
-                const Half *src = reinterpret_cast<const Half *>(fpts + (q >= 0 && q < (int)T ? q : 0));
-                glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(&wrapw[slot][0][0])));
-                glds16(src + 1, __builtin_amdgcn_readfirstlane(lds_addr(&wrapw[slot][1][0])));
-            }
+        if (rho >= N) return;
+        const int est = est_l[0][rho];
+        {
+            const int q = est - kStreamSlack + tid;
+            if (lane == 63) lastrc[rho & 1][wv] = (q >= 0 && q < (int)T) ? phi[sg].y : 0xffffffffu;
+            place(rho, q, plo[sg], phi[sg], lane == 0, wv == 0 ? -1 : wv - 1); /* lane 0 of a later wave: checked one step later */
         }
-    };
-    auto stream_index = [&](int r) { /* row r's window has landed: enter every position in the row's column index */
-        if (!kStream || r >= N) return;
-        const int est = est_l[0][r], est0 = est_l[1][r];
-        const int slot = r & (kWinSlots - 1), pr = r & 1;
-        const int row0 = r * H, first = row0 + first_col;
-        const uint32_t tag = (uint32_t)(r + 1) << 16;
-        auto one = [&](int j) { /* window index j */
-            const int q = window_pos(est, j);
-            if (q < 0 || q >= (int)T) return;
-            const uint32_t rcw = win[slot][1][j].y; /* row | col << 16 */
-            const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
-            if (row >= (uint32_t)N || col >= (uint32_t)H) return;
-            const int flat = (int)row * H + (int)col, off = flat - first;
-            if (off < 0 || off >= kStripThreads) return;
-            colidx[pr][off] = tag | (uint32_t)j;
-            if (off >= 2 && off < 2 + kStripCols && first_col + off < H) { /* a point of this strip's own columns */
-                ++consumed;
-                if (q > 0) { /* its predecessor in the input must lie in the window and have a smaller slot */
-                    if (j == 0) { failed = 1u; return; }
-                    const uint32_t pw = win[slot][1][j - 1].y;
-                    const uint32_t prow = pw & 0xffffu, pcol = pw >> 16;
-                    if (prow >= (uint32_t)N || pcol >= (uint32_t)H || (int)prow * H + (int)pcol >= flat) failed = 1u;
-                }
-            }
-        };
-        one(tid);
-        if (wv == 0 && lane < 2 * kStreamSlack) one(kStripThreads + lane);
-        if (wv == 0 && last_strip && lane < kWrapLen) { /* slots r*H and r*H + 1 as the wrap-around halo columns H, H + 1 */
-            const int q = est0 - (kStreamSlack - 2) + lane;
-            if (q >= 0 && q < (int)T) {
-                const uint32_t rcw = wrapw[slot][1][lane].y;
+        if (wv == 0) { /* wave-uniform */
+            const u32x4 xl = xwin[rho & 1][0][lane], xh = xwin[rho & 1][1][lane];
+            if (lane < 32) {
+                /* positions 256 .. 287; lane 0 follows the last wave's last position */
+                place(rho, est - kStreamSlack + kStripThreads + lane, xl, xh, lane == 0, kStripThreads / 64 - 1);
+            } else if (last_strip) { /* slots rho*H and rho*H + 1 as the wrap-around halo columns H, H + 1 */
+                const int q = est_l[1][rho] - (kStreamSlack - 2) + (lane - 32);
+                const uint32_t rcw = xh.y;
                 const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
-                if (row == (uint32_t)r && col < 2u) {
-                    const int off = H + (int)col - first_col;
-                    if (off >= 0 && off < kStripThreads) colidx[pr][off] = tag | 0x8000u | (uint32_t)lane;
+                const int off = H + (int)col - first_col;
+                if (q >= 0 && q < (int)T && row == (uint32_t)rho && col < 2u && (unsigned)off < (unsigned)kStripThreads) {
+                    rowbuf[rho % 3][0][off] = xl;
+                    rowbuf[rho % 3][1][off] = xh;
                 }
             }
         }
     };
-    if (kStream) { /* prologue: rows 0 .. 2 requested, row 0 indexed */
-        lds_barrier(); /* est_l */
-        stream_issue(0);
-        stream_issue(1);
-        stream_issue(2);
+    auto tail_scatter = [&](auto STG, int rho) { /* second wave: the listed tail points of row rho over the prefix's */
+        constexpr int sg = decltype(STG)::value;
+        if (rho >= N) return;
+        if (te[sg] != 0xffffffffu) {
+            const int off = (int)(te[sg] & 0xffu);
+            rowbuf[rho % 3][0][off] = twin[rho & 1][0][lane];
+            rowbuf[rho % 3][1][off] = twin[rho & 1][1][lane];
+        }
+    };
+    if (kStream) { /* prologue: rows 0 and 1 placed, row 0's tail over them; the steady state's loads under way */
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        lds_barrier(); /* est_l, tcnt_l, row buffers */
+        issue_P(I0{}, 0);
+        issue_P(I1{}, 1);
+        if (wv == 0) {
+            issue_X(0);
+            issue_X(1);
+        }
+        if (wv == 1) {
+            issue_TE(I0{}, 0);
+            issue_TE(I1{}, 1);
+            issue_TE(I2{}, 2);
+        }
+        wait_loads<0>(plo[0], phi[0], te[0]);
+        wait_loads<0>(plo[1], phi[1], te[1]);
+        asm volatile("" : "+v"(te[2]));
+        if (wv == 1) {
+            settle(I0{}, 0);
+            settle(I1{}, 1);
+            issue_TP(I0{}, 0);
+            issue_TP(I1{}, 1);
+        }
+        scatter(I0{}, 0);
+        lds_barrier(); /* lastrc of row 0 */
+        scatter(I1{}, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier(); /* every wave's part of window 0 has landed */
-        stream_index(0);
-        lds_barrier();
+        lds_barrier(); /* rows 0 and 1 placed */
+        if (wv == 1) tail_scatter(I0{}, 0);
+        if (wv == 0) issue_X(2);
+        issue_P(I2{}, 2);
+        issue_P(I0{}, 3);
+        lds_barrier(); /* row 0 complete */
     }
 
     XYZI prev{0.f, 0.f, 0.f, 0.f}, prevprev{0.f, 0.f, 0.f, 0.f};
@@ -634,8 +810,23 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
     unsigned long long m_ready = 0;     /* candidate ballot of row r-2 */
 
     const size_t cand_base = (size_t)f * g.segs * kSeg;
-    uint32_t *fncand = b.ncand + (size_t)f * g.segs;
-    uint32_t *flist = b.code_main + ((size_t)f * g.emitters + strip) * bands * (size_t)g.code_cap;
+    uint32_t *const fkey = own_sgpr(b.cand_key + cand_base);
+    float *const fz = own_sgpr(b.cand_z + cand_base);
+    uint32_t *const fncand = own_sgpr(b.ncand + (size_t)f * g.segs);
+    const uint32_t code_cap = own_sgpr(g.code_cap);
+    uint32_t *const flist = own_sgpr(b.code_main + ((size_t)f * g.emitters + strip) * bands * (size_t)code_cap);
+    bev_point_t *const fordered = own_sgpr(b.ordered + frame_off);
+    int8_t *const fgm = own_sgpr(b.gm ? b.gm + frame_off : nullptr);
+    const int strips = own_sgpr(g.strips);
+    RasterParams rp = g.rp; /* only the fields the BEV code needs stay alive */
+    rp.max_range_f = own_sgpr(rp.max_range_f);
+    rp.interval = own_sgpr(rp.interval);
+    rp.inv_interval = own_sgpr(rp.inv_interval);
+    rp.height_res = own_sgpr(rp.height_res);
+    rp.inv_height_res = own_sgpr(rp.inv_height_res);
+    rp.lidar_to_ground = own_sgpr(rp.lidar_to_ground);
+    rp.mat_size = own_sgpr(rp.mat_size);
+    rp.n_layers = own_sgpr(rp.n_layers);
 
     /* one row; I = r mod 6 (r mod 2 at depth 1) at compile time */
     auto row_step = [&](auto I, const int r) {
@@ -643,35 +834,34 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
         constexpr int in = (decltype(I)::value + kDepth) % (kDepth + 1);   /* stage that takes row r + kDepth */
         constexpr int wu = (decltype(I)::value + kDepth) % 2, wl = decltype(I)::value % 2; /* winner word used / reloaded */
         const int par = r & 1;
+        Half cur_lo, cur_hi;
         if (kStream) {
-            /* everything requested two steps ago — row r's override point, the winner word of row r + 2, the window of
-             * row r + 1 — has arrived once only the last step's requests are outstanding: 3 asm loads + 2 LDS-DMAs
-             * (6 in the first wave).  Steps 0 and 1 follow the prologue, whose order differs. */
-            if (r < 2) wait_loads<0>(plo[ic], phi[ic], wraw[wu]);
-            else if (wv == 0) wait_loads<9>(plo[ic], phi[ic], wraw[wu]);
-            else wait_loads<5>(plo[ic], phi[ic], wraw[wu]);
-        }
-        Half cur_lo{{plo[ic].x, plo[ic].y, plo[ic].z, plo[ic].w}}, cur_hi{{phi[ic].x, phi[ic].y, phi[ic].z, phi[ic].w}};
-        if (!pfull[ic]) { /* untouched slot: value-initialised, BatchMultiBevGen.cpp:98 */
-            cur_lo = Half{{0, 0, 0, 0}};
-            cur_hi = Half{{0, 0, 0, 0}};
-            if (kStream && r < N) { /* ... unless the prefix holds the slot's point */
-                const uint32_t e = colidx[par][tid];
-                if ((e >> 16) == (uint32_t)(r + 1)) {
-                    const int slot = r & (kWinSlots - 1), j = (int)(e & 0x7fffu);
-                    const u32x4 a = (e & 0x8000u) ? wrapw[slot][0][j] : win[slot][0][j];
-                    const u32x4 c = (e & 0x8000u) ? wrapw[slot][1][j] : win[slot][1][j];
-                    cur_lo = Half{{a.x, a.y, a.z, a.w}};
-                    cur_hi = Half{{c.x, c.y, c.z, c.w}};
-                }
+            /* everything but the previous step's two position loads has arrived (the prologue issues in the same order) */
+            constexpr int s2 = (decltype(I)::value + 2) % 3, s1 = (decltype(I)::value + 1) % 3, s0 = decltype(I)::value % 3;
+            wait_loads<2>(plo[s2], phi[s2], te[s2]);
+            /* row r from its buffer: the entry is the slot's own point, or the slot is empty (value-initialised,
+             * BatchMultiBevGen.cpp:98) */
+            const u32x4 a = rowbuf[s0][0][tid], c = rowbuf[s0][1][tid];
+            const uint32_t want = slot_rc + (uint32_t)r; /* row | col << 16 of this thread's slot in row r */
+            const bool hit = r < N && c.y == want;
+            cur_lo = Half{{hit ? a.x : 0u, hit ? a.y : 0u, hit ? a.z : 0u, hit ? a.w : 0u}};
+            cur_hi = Half{{hit ? c.x : 0u, hit ? c.y : 0u, hit ? c.z : 0u, hit ? c.w : 0u}};
+            scatter(std::integral_constant<int, s2>{}, r + 2);
+            if (wv == 1) tail_scatter(std::integral_constant<int, s1>{}, r + 1);
+            if (wv == 0) issue_X(r + 3);
+            if (wv == 1) {
+                settle(std::integral_constant<int, s2>{}, r + 2);
+                issue_TE(std::integral_constant<int, s0>{}, r + 3);
+                issue_TP(std::integral_constant<int, s2>{}, r + 2);
             }
-        }
-        if (kStream) {
-            /* a window is filled by all four waves, and the order check looks one position to the left (another wave's
-             * part for a wave's first lane): every wave must have passed its wait before the window is indexed */
-            lds_barrier();
-            stream_index(r + 1); /* the row barrier below separates the index from its readers */
-            stream_issue(r + 3);
+            issue_P(std::integral_constant<int, s1>{}, r + 4);
+        } else {
+            cur_lo = Half{{plo[ic].x, plo[ic].y, plo[ic].z, plo[ic].w}};
+            cur_hi = Half{{phi[ic].x, phi[ic].y, phi[ic].z, phi[ic].w}};
+            if (!pfull[ic]) { /* untouched slot: value-initialised, BatchMultiBevGen.cpp:98 */
+                cur_lo = Half{{0, 0, 0, 0}};
+                cur_hi = Half{{0, 0, 0, 0}};
+            }
         }
         {
             const uint32_t wn = winner_of(r + kDepth, wraw[wu]);
@@ -684,7 +874,9 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
                        __uint_as_float(cur_hi.w[0])};
         if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
         if (lane == 0) wave_cnt[par][wv] = (uint32_t)__popcll(m_ready);
+#ifndef BEV_EXP_NOBARRIER
         lds_barrier();
+#endif
 
         /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
         int s_r = kSteep;
@@ -701,7 +893,7 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
                 if (up.i == -1.0f) up = left;                    /* flat (r-1)*H + c - 2      :151-154 */
                 if (up.i == -1.0f && r >= 2) up = prevprev;      /* (r-2, c)                  :157-160 */
                 if (cur.i == -1.0f || up.i == -1.0f) s_r = kInvalid; /* :162-167 */
-                else s_r = angle_is_ground(up.x - cur.x, up.y - cur.y, up.z - cur.z) ? kGround : kSteep; /* :169-182 */
+                else s_r = angle_is_ground_flat(up.x - cur.x, up.y - cur.y, up.z - cur.z) ? kGround : kSteep; /* :169-182 */
             }
         }
 
@@ -745,12 +937,15 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
                     if (w < wv) before += c;
                     total += c;
                 }
-                const size_t seg = (size_t)rr * g.strips + strip;
+                const uint32_t seg = (uint32_t)(rr * strips + strip);
                 if (is_cand) {
-                    const uint32_t rank = before + (uint32_t)__popcll(m_ready & ((1ull << lane) - 1ull));
-                    const size_t at = cand_base + seg * kSeg + rank;
-                    store_ws(&b.cand_key[at], p2.key);
-                    store_ws(&b.cand_z[at], __uint_as_float(p2.lo.w[2]));
+                    uint32_t rank = before + (uint32_t)__popcll(m_ready & ((1ull << lane) - 1ull));
+#ifdef BEV_EXP_NOBARRIER /* timing experiment only: results are wrong, accesses stay in range */
+                    rank &= (uint32_t)kSeg - 1u;
+#endif
+                    const uint32_t at = seg * (uint32_t)kSeg + rank; /* < 2^32: a frame's segments hold fewer slots than S */
+                    store_ws(&fkey[at], p2.key);
+                    store_ws(&fz[at], __uint_as_float(p2.lo.w[2]));
                 }
                 if (tid == 2) fncand[seg] = total;
             }
@@ -767,25 +962,25 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
                  * cells at the same heights again and again: a HDL_64E frame lists 74 k codes of which 24 k are
                  * distinct).  The rasters are idempotent, so a stale or racing memo entry only costs a duplicate. */
                 if (has) {
-                    const uint32_t slot = (p2.code * 0x9E3779B1u) >> (32 - kSeenBits);
+                    const uint32_t slot = (p2.code * 0x9E3779B1u) >> (32 - kSeenB);
                     if (seen[slot] == p2.code) has = false;
                     else seen[slot] = p2.code;
                 }
                 if (has) {
                     const int band = band_tab[code_x(p2.code)];
                     const uint32_t pos = atomicAdd(&band_cursor[band], 1u);
-                    store_ws(&flist[(size_t)band * g.code_cap + pos], p2.code);
+                    store_ws(&flist[(uint32_t)band * code_cap + pos], p2.code);
                 }
             }
             if (outcol) {
                 Half hi = p2.hi;
                 const bool as_ground = is_cand && !p2.pred;
                 if (as_ground) hi.w[3] &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
-                const size_t idx = frame_off + (size_t)(q * H + v);
-                Half *dst = reinterpret_cast<Half *>(b.ordered + idx);
+                const uint32_t idx = (uint32_t)(q * H + v);
+                Half *dst = reinterpret_cast<Half *>(fordered + idx);
                 store_stream(dst, p2.lo);
                 store_stream(dst + 1, hi);
-                if (b.gm) b.gm[idx] = (int8_t)p2.gflag;
+                if (fgm) fgm[idx] = (int8_t)p2.gflag;
             }
         }
 
@@ -797,7 +992,7 @@ __global__ __launch_bounds__(kStripThreads, 3) void k_strip_ground(BatchPtrs b, 
         p1.status = s_r;
         p1.gflag = 0;
         p1.key = 0u;
-        p1.code = bev_code(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w[3] & 0xffffu), g.rp);
+        p1.code = bev_code(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w[3] & 0xffffu), rp);
         prevprev = prev;
         prev = cur;
     };
@@ -1626,7 +1821,7 @@ void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int sou
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_probe, dim3(nf), dim3(256), 0, st, b, g, allow_stream ? 1 : 0);
+    hipLaunchKernelGGL(k_probe, dim3(nf), dim3(kProbeThreads), 0, st, b, g, allow_stream ? 1 : 0);
 }
 void launch_verdict(const BatchPtrs &b, int nf, hipStream_t st)
 {
