@@ -514,6 +514,10 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_strip_ground(BatchPtrs b, 
     const size_t frame_off = (size_t)f * g.S;
     const int bands = g.raster_bands;
 
+    /* lanes two to the right / left (wrapping inside the wave; the edge lanes are patched from LDS), one to the left */
+    const int sh_right = ((lane + 2) & 63) << 2, sh_left = ((lane - 2) & 63) << 2, sh_left1 = ((lane - 1) & 63) << 2;
+    auto lane_from = [&](int sel, uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)x); };
+    auto lane_from_f = [&](int sel, float x) -> float { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)__float_as_uint(x))); };
     const int v = strip * kStripCols + tid - 2;                      /* virtual column */
     const bool provider = (v < H + 2) && (v >= 0 || strip == 0);     /* has a point to load */
     const bool outcol = tid >= 2 && tid < 2 + kStripCols && v < H;   /* owns column v's outputs */
@@ -665,27 +669,27 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_strip_ground(BatchPtrs b, 
         ld32_nt(te[sg], ftail + (size_t)clamp_row(rho) * tail_stride + lane);
     };
     /* second wave: which of row rho's listed tail points are the last of their slot (getOrderedCloud's scatter keeps the
-     * last writer, BatchMultiBevGen.cpp:112).  Lanes whose entries share a column offset find each other with eight
-     * ballots (one per offset bit); only then — a few times per frame — the group is walked.  Entries that lose, and
-     * lanes past the list's count, become 0xffffffff. */
+     * last writer, BatchMultiBevGen.cpp:112).  Every entry counts itself in at its column offset (256 LDS counters in
+     * the buffer the row's tail points are about to be loaded into: it is idle right now); only when some offset has
+     * been taken twice — a few times per frame — those entries are compared with the others of their offset.  Entries
+     * that lose, and lanes past the list's count, become 0xffffffff. */
     auto settle = [&](auto STG, int rho) {
         constexpr int sg = decltype(STG)::value;
         const bool on = rho < N && (uint32_t)lane < tcnt_l[clamp_row(rho)];
         const uint32_t e = te[sg];
         const uint32_t off = e & 0xffu, idx = e >> 8;
-        unsigned long long peers = __ballot(on);
-#pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-            const unsigned long long m = __ballot((off >> bit) & 1u);
-            peers &= ((off >> bit) & 1u) ? m : ~m;
-        }
+        uint32_t *cnt = reinterpret_cast<uint32_t *>(&twin[rho & 1][0][0]); /* [256] */
+        twin[rho & 1][0][lane] = u32x4{0u, 0u, 0u, 0u};
+        const uint32_t before = on ? atomicAdd(&cnt[off], 1u) : 0u; /* (LDS operations of one wave execute in order) */
         bool dead = !on;
-        unsigned long long crowd = __ballot(on && __popcll(peers) > 1);
+        unsigned long long crowd = __ballot(before != 0u);
         while (crowd) { /* wave-uniform */
             const int j = __ffsll((long long)crowd) - 1;
             crowd &= crowd - 1ull;
-            const uint32_t ej = (uint32_t)__shfl((int)e, j);
-            if (on && (ej & 0xffu) == off && (ej >> 8) > idx) dead = true;
+            const uint32_t ej = (uint32_t)__builtin_amdgcn_readlane((int)e, j);
+            const bool same = on && (ej & 0xffu) == off;
+            if (same && (ej >> 8) > idx) dead = true;                          /* lane j's point comes later than this one */
+            if (__ballot(same && idx > (ej >> 8)) != 0ull && lane == j) dead = true; /* ... or some other after lane j's */
         }
         te[sg] = dead ? 0xffffffffu : e;
     };
@@ -696,25 +700,28 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_strip_ground(BatchPtrs b, 
         glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(&twin[rho & 1][0][0])));
         glds16(src + 1, __builtin_amdgcn_readfirstlane(lds_addr(&twin[rho & 1][1][0])));
     };
-    /* one window position: into the row buffer, counted and checked */
-    auto place = [&](int rho, int q, const u32x4 &lo, const u32x4 &hi, bool first_of_group, int dwave) {
-        const uint32_t rcw = hi.y; /* row | col << 16 */
+    /* one window position: into the row buffer, counted and checked.  `sflat` is the position's slot, or INT_MAX when the
+     * position is outside the prefix or its point outside the range image (such a predecessor fails every check) */
+    const int own_cols = (H - first_col - 2) < kStripCols ? (H - first_col - 2) : kStripCols; /* own columns of this strip */
+    const int row_span = (H - first_col) < kStripThreads ? (H - first_col) : kStripThreads;  /* offsets that belong to the row */
+    auto slot_or_max = [&](int q, uint32_t rcw) -> int {
         const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
-        const bool inpre = q >= 0 && q < (int)T;
-        const bool valid = inpre && row < (uint32_t)N && col < (uint32_t)H;
-        const int flat = (int)row * H + (int)col, off = flat - (rho * H + first_col);
+        const bool valid = (unsigned)q < T && row < (uint32_t)N && col < (uint32_t)H;
+        return valid ? (int)row * H + (int)col : 0x7fffffff;
+    };
+    auto place = [&](int rho, int q, const u32x4 &lo, const u32x4 &hi, bool first_of_group, int dwave) {
+        const int sflat = slot_or_max(q, hi.y);
+        const int off = (int)((uint32_t)sflat - (uint32_t)(rho * H + first_col));
         /* (a window of the last strip runs into the next row: those points are not this row's wrap-around halo) */
-        const bool inr = valid && (unsigned)off < (unsigned)kStripThreads && flat < (rho + 1) * H;
+        const bool inr = (unsigned)off < (unsigned)row_span;
         if (inr) {
             rowbuf[rho % 3][0][off] = lo;
             rowbuf[rho % 3][1][off] = hi;
         }
-        const bool own = inr && off >= 2 && off < 2 + kStripCols && first_col + off < H;
+        const bool own = (unsigned)(off - 2) < (unsigned)own_cols;
         consumed += own ? 1u : 0u;
         /* its predecessor in the input must lie in the prefix and have a smaller slot */
-        const uint32_t pw = (uint32_t)__shfl_up((int)rcw, 1);
-        const uint32_t prow = pw & 0xffffu, pcol = pw >> 16;
-        const bool pok = prow < (uint32_t)N && pcol < (uint32_t)H && (int)prow * H + (int)pcol < flat;
+        const bool pok = (int)lane_from(sh_left1, (uint32_t)sflat) < sflat;
         /* (straight-line: `if (a) failed = 1; else dflat = flat;` becomes a store through a selected pointer, and the
          * variables stay in scratch memory — a load the compiler waits for with vmcnt(0) every step) */
         const bool chk = own && q > 0;
@@ -722,23 +729,21 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_strip_ground(BatchPtrs b, 
         const bool defer = chk && first_of_group && dwave >= 0;
         failed |= bad ? 1u : 0u;
         dneed = dneed | defer;
-        dflat = defer ? flat : dflat;
+        dflat = defer ? sflat : dflat;
     };
     auto scatter = [&](auto STG, int rho) { /* the prefix positions of row rho -> row buffer */
         constexpr int sg = decltype(STG)::value;
         /* last step's open check: the lane's point against the last position of the wave before */
         {
-            const uint32_t pw = lastrc[(rho - 1) & 1][wv == 0 ? kStripThreads / 64 - 1 : wv - 1];
-            const uint32_t prow = pw & 0xffffu, pcol = pw >> 16;
-            const bool pok = prow < (uint32_t)N && pcol < (uint32_t)H && (int)prow * H + (int)pcol < dflat;
-            failed |= (dneed && !pok) ? 1u : 0u;
+            const int pflat = (int)lastrc[(rho - 1) & 1][wv == 0 ? kStripThreads / 64 - 1 : wv - 1];
+            failed |= (dneed && !(pflat < dflat)) ? 1u : 0u;
             dneed = false;
         }
         if (rho >= N) return;
         const int est = est_l[0][rho];
         {
             const int q = est - kStreamSlack + tid;
-            if (lane == 63) lastrc[rho & 1][wv] = (q >= 0 && q < (int)T) ? phi[sg].y : 0xffffffffu;
+            if (lane == 63) lastrc[rho & 1][wv] = (uint32_t)slot_or_max(q, phi[sg].y);
             place(rho, q, plo[sg], phi[sg], lane == 0, wv == 0 ? -1 : wv - 1); /* lane 0 of a later wave: checked one step later */
         }
         if (wv == 0) { /* wave-uniform */
@@ -804,8 +809,10 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_strip_ground(BatchPtrs b, 
         lds_barrier(); /* row 0 complete */
     }
 
-    XYZI prev{0.f, 0.f, 0.f, 0.f}, prevprev{0.f, 0.f, 0.f, 0.f};
-    PendingRow p1{}, p2{};              /* rows r-1 (ground flag still open) and r-2 (ready to write) */
+    /* rows r-1 (ground flag still open) and r-2 (ready to write) live in pr[(r-1) % 3], pr[(r-2) % 3]; row r takes the
+     * third record.  (Handing them on through variables — p2 = p1; p1 = cur — cost 36 register moves per row.) */
+    PendingRow pr[3] = {};
+
     float zref = __uint_as_float(0x7fc00000u); /* height of the column's last candidate taken for ground (NaN: none yet) */
     unsigned long long m_ready = 0;     /* candidate ballot of row r-2 */
 
@@ -833,6 +840,9 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_strip_ground(BatchPtrs b, 
         constexpr int ic = decltype(I)::value % (kDepth + 1);              /* stage holding row r */
         constexpr int in = (decltype(I)::value + kDepth) % (kDepth + 1);   /* stage that takes row r + kDepth */
         constexpr int wu = (decltype(I)::value + kDepth) % 2, wl = decltype(I)::value % 2; /* winner word used / reloaded */
+        PendingRow &p0 = pr[decltype(I)::value % 3], &p1 = pr[(decltype(I)::value + 2) % 3], &p2 = pr[(decltype(I)::value + 1) % 3];
+        const XYZI prev{__uint_as_float(p1.lo.w[0]), __uint_as_float(p1.lo.w[1]), __uint_as_float(p1.lo.w[2]), __uint_as_float(p1.hi.w[0])};
+        const XYZI prevprev{__uint_as_float(p2.lo.w[0]), __uint_as_float(p2.lo.w[1]), __uint_as_float(p2.lo.w[2]), __uint_as_float(p2.hi.w[0])};
         const int par = r & 1;
         Half cur_lo, cur_hi;
         if (kStream) {
@@ -878,53 +888,10 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_strip_ground(BatchPtrs b, 
         lds_barrier();
 #endif
 
-        /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
-        int s_r = kSteep;
-        if (r >= lo_row && r < N) { /* workgroup-uniform */
-            /* row r-1 of the threads two to the right / left */
-            XYZI right{__shfl(prev.x, lane + 2), __shfl(prev.y, lane + 2), __shfl(prev.z, lane + 2), __shfl(prev.i, lane + 2)};
-            XYZI left{__shfl(prev.x, lane - 2), __shfl(prev.y, lane - 2), __shfl(prev.z, lane - 2), __shfl(prev.i, lane - 2)};
-            const float4(*pe)[4] = edge[(r + 2) % 3];
-            if (lane >= 62 && wv + 1 < kWaves) { const float4 q = pe[wv + 1][lane - 62]; right = XYZI{q.x, q.y, q.z, q.w}; }
-            if (lane < 2 && wv > 0) { const float4 q = pe[wv - 1][lane + 2]; left = XYZI{q.x, q.y, q.z, q.w}; }
-            if (outcol) {
-                XYZI up = prev;                                  /* (r-1, c)                  :143     */
-                if (up.i == -1.0f) up = right;                   /* (r-1, (c+2) % H)          :146-149 */
-                if (up.i == -1.0f) up = left;                    /* flat (r-1)*H + c - 2      :151-154 */
-                if (up.i == -1.0f && r >= 2) up = prevprev;      /* (r-2, c)                  :157-160 */
-                if (cur.i == -1.0f || up.i == -1.0f) s_r = kInvalid; /* :162-167 */
-                else s_r = angle_is_ground_flat(up.x - cur.x, up.y - cur.y, up.z - cur.z) ? kGround : kSteep; /* :169-182 */
-            }
-        }
-
-        /* ---- ground_mat of row r-1 is now decided (closed form, see bev_exact.h) ---- */
-        {
-            const int q = r - 1;
-            int gf = 0;
-            if (q >= lo_row) gf = (p1.status == kInvalid) ? -1 : (p1.status == kGround ? 1 : (s_r == kGround ? 1 : 0));
-            else if (q == lo_row - 1) gf = (s_r == kGround) ? 1 : 0;
-            p1.gflag = (q >= 0 && q < N) ? gf : 0;
-        }
-        const bool cand1 = outcol && p1.gflag == 1;
-        const unsigned long long m_new = __ballot(cand1);
-        /* Provisional labels.  Phase C un-grounds a candidate that lies 0.30 m above a neighbour cell's average ground
-         * height — known only after the whole frame has been summed.  The walk GUESSES: a candidate 0.30 m above the last
-         * candidate of its column that it took for ground is written with its own label, every other candidate with
-         * label 0; k_ground_resolve tests every candidate exactly and patches the wrong guesses in either direction.
-         * The guess only decides how many sparse 2-byte patches are needed (benchmark frames: 1.3 k instead of 7.9 k per
-         * frame). */
-        {
-            const float zq = __uint_as_float(p1.lo.w[2]);
-            p1.pred = cand1 && (zq - zref >= 0.3f); /* false while zref is NaN */
-            if (cand1 && !p1.pred) zref = zq;
-        }
-        if (cand1) {
-            const int cell = ground_cell(__uint_as_float(p1.lo.w[0]), __uint_as_float(p1.lo.w[1]));
-            p1.key = candidate_key_edges(cell, tid - 2, p1.pred, p1.code, (int)(int16_t)(p1.hi.w[3] & 0xffffu),
-                                         edge_x[cell / kGridCols], edge_y[cell % kGridCols]);
-        }
-
         /* ---- write out row r-2 (its per-wave counts were published before the barrier) ---- */
+        /* (first thing after the barrier: the stores then have the whole status computation to complete in — gfx950 counts
+         * them on the same counter as the loads, and the wait at the top of the next step would otherwise sit right
+         * behind them) */
         if (r >= 2) {
             const int q = r - 2;
             const bool is_cand = outcol && p2.gflag == 1;
@@ -955,8 +922,8 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_strip_ground(BatchPtrs b, 
              * neighbour appends the very same code skips (near the sensor dozens of consecutive returns share a bin). */
             {
                 bool has = outcol && !is_cand && p2.code != kSkip;
-                const uint32_t left_code = __shfl_up(p2.code, 1);
-                const bool left_has = __shfl_up(has ? 1 : 0, 1) != 0;
+                const uint32_t left_code = lane_from(sh_left1, p2.code);
+                const bool left_has = lane_from(sh_left1, has ? 1u : 0u) != 0u;
                 if (lane > 0 && left_has && left_code == p2.code) has = false;
                 /* ... and so does one whose code this strip has listed before and still remembers (rings hit the same
                  * cells at the same heights again and again: a HDL_64E frame lists 74 k codes of which 24 k are
@@ -978,32 +945,92 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_strip_ground(BatchPtrs b, 
                 if (as_ground) hi.w[3] &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
                 const uint32_t idx = (uint32_t)(q * H + v);
                 Half *dst = reinterpret_cast<Half *>(fordered + idx);
+#ifndef BEV_EXP_NOSTORE /* timing experiment: what the ordered cloud's stores cost (results are wrong without them) */
                 store_stream(dst, p2.lo);
                 store_stream(dst + 1, hi);
+#else
+                if (hi.w[0] == 0x12345678u && p2.lo.w[0] == 0x9abcdef0u) store_stream(dst, p2.lo); /* keeps the values alive */
+#endif
                 if (fgm) fgm[idx] = (int8_t)p2.gflag;
             }
         }
 
-        /* ---- shift the pipeline ---- */
-        p2 = p1;
+        /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
+        int s_r = kSteep;
+        if (r >= lo_row && r < N) { /* workgroup-uniform */
+            /* row r-1 of the threads two to the right / left */
+            XYZI right{lane_from_f(sh_right, prev.x), lane_from_f(sh_right, prev.y), lane_from_f(sh_right, prev.z), lane_from_f(sh_right, prev.i)};
+            XYZI left{lane_from_f(sh_left, prev.x), lane_from_f(sh_left, prev.y), lane_from_f(sh_left, prev.z), lane_from_f(sh_left, prev.i)};
+            const float4(*pe)[4] = edge[(r + 2) % 3];
+            if (lane >= 62 && wv + 1 < kWaves) { const float4 q = pe[wv + 1][lane - 62]; right = XYZI{q.x, q.y, q.z, q.w}; }
+            if (lane < 2 && wv > 0) { const float4 q = pe[wv - 1][lane + 2]; left = XYZI{q.x, q.y, q.z, q.w}; }
+            if (outcol) {
+                XYZI up = prev;                                  /* (r-1, c)                  :143     */
+                if (up.i == -1.0f) up = right;                   /* (r-1, (c+2) % H)          :146-149 */
+                if (up.i == -1.0f) up = left;                    /* flat (r-1)*H + c - 2      :151-154 */
+                if (up.i == -1.0f && r >= 2) up = prevprev;      /* (r-2, c)                  :157-160 */
+                if (cur.i == -1.0f || up.i == -1.0f) s_r = kInvalid; /* :162-167 */
+#ifndef BEV_EXP_NOANGLE
+                else s_r = angle_is_ground_flat(up.x - cur.x, up.y - cur.y, up.z - cur.z) ? kGround : kSteep; /* :169-182 */
+#else /* timing experiment */
+                else s_r = (up.x - cur.x) > 1e30f ? kGround : kSteep;
+#endif
+            }
+        }
+
+        /* ---- ground_mat of row r-1 is now decided (closed form, see bev_exact.h) ---- */
+        {
+            const int q = r - 1;
+            int gf = 0;
+            if (q >= lo_row) gf = (p1.status == kInvalid) ? -1 : (p1.status == kGround ? 1 : (s_r == kGround ? 1 : 0));
+            else if (q == lo_row - 1) gf = (s_r == kGround) ? 1 : 0;
+            p1.gflag = (q >= 0 && q < N) ? gf : 0;
+        }
+        const bool cand1 = outcol && p1.gflag == 1;
+        const unsigned long long m_new = __ballot(cand1);
+        /* Provisional labels.  Phase C un-grounds a candidate that lies 0.30 m above a neighbour cell's average ground
+         * height — known only after the whole frame has been summed.  The walk GUESSES: a candidate 0.30 m above the last
+         * candidate of its column that it took for ground is written with its own label, every other candidate with
+         * label 0; k_ground_resolve tests every candidate exactly and patches the wrong guesses in either direction.
+         * The guess only decides how many sparse 2-byte patches are needed (benchmark frames: 1.3 k instead of 7.9 k per
+         * frame). */
+        {
+            const float zq = __uint_as_float(p1.lo.w[2]);
+            p1.pred = cand1 && (zq - zref >= 0.3f); /* false while zref is NaN */
+            if (cand1 && !p1.pred) zref = zq;
+        }
+        if (cand1) {
+            const int cell = ground_cell(__uint_as_float(p1.lo.w[0]), __uint_as_float(p1.lo.w[1]));
+            p1.key = candidate_key_edges(cell, tid - 2, p1.pred, p1.code, (int)(int16_t)(p1.hi.w[3] & 0xffffu),
+                                         edge_x[cell / kGridCols], edge_y[cell % kGridCols]);
+        }
+
+        /* ---- row r's record (the one row r-3 has left) ---- */
         m_ready = m_new;
-        p1.lo = cur_lo;
-        p1.hi = cur_hi;
-        p1.status = s_r;
-        p1.gflag = 0;
-        p1.key = 0u;
-        p1.code = bev_code(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w[3] & 0xffffu), rp);
-        prevprev = prev;
-        prev = cur;
+        p0.lo = cur_lo;
+        p0.hi = cur_hi;
+        p0.status = s_r;
+        p0.gflag = 0;
+        p0.pred = false;
+        p0.key = 0u;
+#ifndef BEV_EXP_NOCODE
+        p0.code = bev_code(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w[3] & 0xffffu), rp);
+#else /* timing experiment */
+        p0.code = kSkip;
+#endif
     };
     /* two extra iterations drain the pipeline */
-    for (int r0 = 0; r0 < N + 2; r0 += 6) {
+    /* (the stream source has no stage that rotates with period 2: three copies of the step instead of six) */
+    constexpr int kUnroll = kStream ? 3 : 6;
+    for (int r0 = 0; r0 < N + 2; r0 += kUnroll) {
         row_step(std::integral_constant<int, 0>{}, r0);
         if (r0 + 1 < N + 2) row_step(std::integral_constant<int, 1>{}, r0 + 1);
         if (r0 + 2 < N + 2) row_step(std::integral_constant<int, 2>{}, r0 + 2);
-        if (r0 + 3 < N + 2) row_step(std::integral_constant<int, 3>{}, r0 + 3);
-        if (r0 + 4 < N + 2) row_step(std::integral_constant<int, 4>{}, r0 + 4);
-        if (r0 + 5 < N + 2) row_step(std::integral_constant<int, 5>{}, r0 + 5);
+        if (kUnroll == 6) {
+            if (r0 + 3 < N + 2) row_step(std::integral_constant<int, 3>{}, r0 + 3);
+            if (r0 + 4 < N + 2) row_step(std::integral_constant<int, 4>{}, r0 + 4);
+            if (r0 + 5 < N + 2) row_step(std::integral_constant<int, 5>{}, r0 + 5);
+        }
     }
     if (kStream) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* no LDS-DMA may outlive the workgroup's LDS */
     lds_barrier();
@@ -1164,8 +1191,8 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
         cnt_next = load_counts(p + 2);
         PHA(5);
 
-        /* hist.  Lanes of a 64-slice that hold the same cell find each other with one ballot per key bit (12 bits cover
-         * 3750 cells; 0xfff is not a cell): constant work however many distinct cells the slice has.  Every lane keeps
+        /* hist.  Lanes of a 64-slice that hold the same cell find each other with one ballot per key bit (see below; 12
+         * bits cover 3750 cells; 0xfff is not a cell): constant work however many distinct cells the slice has.  Every lane keeps
          * its rank inside its group, the group's size and whether it leads the group in the spare bits of its cell
          * register (cell | rank << 12 | size << 18 | leader << 25), so the placement below needs no second look.
          * Only leaders touch the histogram (64 LDS atomics on one address would serialise).  The first leader to touch
@@ -1177,12 +1204,25 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
                 if (64 * k >= nn[j]) break; /* wave-uniform */
                 const uint32_t c = cell[j][k];
                 const bool valid = c != 0xfffu;
+                /* the cells of 64 consecutive slots are neighbours on the grid (numbers that differ by 1, 49, 50, 51):
+                 * their low six bits tell them apart; the group's first lane shows its whole cell, and only a slice
+                 * where somebody disagrees (far-apart cells with equal low bits) takes all twelve ballots */
                 unsigned long long peers = __ballot(valid);
 #pragma unroll
-                for (int bit = 0; bit < 12; ++bit) {
+                for (int bit = 0; bit < 6; ++bit) {
                     const bool one = (c >> bit) & 1u;
                     const unsigned long long bal = __ballot(one);
                     peers &= one ? bal : ~bal;
+                }
+                const int first = valid ? __ffsll((long long)peers) - 1 : lane;
+                const uint32_t cf = (uint32_t)__builtin_amdgcn_ds_bpermute(first << 2, (int)c);
+                if (__ballot(valid && cf != c) != 0ull) { /* wave-uniform, rare */
+#pragma unroll
+                    for (int bit = 6; bit < 12; ++bit) {
+                        const bool one = (c >> bit) & 1u;
+                        const unsigned long long bal = __ballot(one);
+                        peers &= one ? bal : ~bal;
+                    }
                 }
                 const unsigned long long lower = peers & ((1ull << lane) - 1ull);
                 const uint32_t size = (uint32_t)__popcll(peers), rank = (uint32_t)__popcll(lower);
@@ -1811,12 +1851,15 @@ void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int sou
 {
     if (nf == 0) return;
     const int grid = xcd_grid(nf, g.strips);
+    /* experiment knob: BEV_WALK_PAD = bytes of dynamic LDS a walk workgroup asks for on top of its own (never touched):
+     * caps the walk workgroups per CU, so that the other stream's kernels find registers and LDS beside them */
+    static const unsigned pad = [] { const char *e = getenv("BEV_WALK_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
     if (source == kSrcIdentity)
-        hipLaunchKernelGGL(k_strip_ground<kSrcIdentity>, dim3(grid), dim3(kStripThreads), 0, st, b, g, nf, mode);
+        hipLaunchKernelGGL(k_strip_ground<kSrcIdentity>, dim3(grid), dim3(kStripThreads), pad, st, b, g, nf, mode);
     else if (source == kSrcStream)
-        hipLaunchKernelGGL(k_strip_ground<kSrcStream>, dim3(grid), dim3(kStripThreads), 0, st, b, g, nf, mode);
+        hipLaunchKernelGGL(k_strip_ground<kSrcStream>, dim3(grid), dim3(kStripThreads), pad, st, b, g, nf, mode);
     else
-        hipLaunchKernelGGL(k_strip_ground<kSrcGather>, dim3(grid), dim3(kStripThreads), 0, st, b, g, nf, mode);
+        hipLaunchKernelGGL(k_strip_ground<kSrcGather>, dim3(grid), dim3(kStripThreads), pad, st, b, g, nf, mode);
 }
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st)
 {
