@@ -502,7 +502,7 @@ __device__ __forceinline__ T own_sgpr(T v)
     return v;
 }
 template <int kSrc>
-__global__ __launch_bounds__(kStripThreads, 4) void k_strip_ground(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
+__global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_strip_ground(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
     constexpr bool kIdentity = kSrc == kSrcIdentity, kStream = kSrc == kSrcStream;
     /* the strips of a frame share halo columns and the lines at their seams: one XCD (one L2) per frame */
@@ -534,6 +534,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_strip_ground(BatchPtrs b, 
      * workgroups can share a CU with the back end's workgroups of the other lane). */
     constexpr int kWaves = kStripThreads / 64;
     __shared__ float4 edge[3][kWaves][4];                  /* rows r, r-1, (r-2): lanes 0, 1, 62, 63 of every wave */
+    __shared__ u32x4 xpose[kWaves][128];                   /* a wave's 64 finished points, to be stored as two whole KiB */
     __shared__ uint32_t wave_cnt[2][kWaves];               /* per-wave candidate counts of the row being written */
     __shared__ uint32_t band_cursor[kMaxBands];            /* entries already in this strip's code list of each band */
     __shared__ uint8_t band_tab[512];                      /* x bin -> raster band */
@@ -939,19 +940,26 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_strip_ground(BatchPtrs b, 
                     store_ws(&flist[(uint32_t)band * code_cap + pos], p2.code);
                 }
             }
-            if (outcol) {
+            {
+                /* The 64 points of a wave are 2 KiB of consecutive bytes of the output.  Stored as they sit in the
+                 * registers — the low halves with one instruction, the high halves with another — every 128-byte line
+                 * leaves the CU in two instalments of four 16-byte pieces, and L2 writes some lines back in between.
+                 * Through 2 KiB of LDS (wave-private, no barrier) each instruction stores 1 KiB of whole lines instead. */
                 Half hi = p2.hi;
                 const bool as_ground = is_cand && !p2.pred;
                 if (as_ground) hi.w[3] &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
-                const uint32_t idx = (uint32_t)(q * H + v);
-                Half *dst = reinterpret_cast<Half *>(fordered + idx);
+                xpose[wv][2 * lane] = u32x4{p2.lo.w[0], p2.lo.w[1], p2.lo.w[2], p2.lo.w[3]};
+                xpose[wv][2 * lane + 1] = u32x4{hi.w[0], hi.w[1], hi.w[2], hi.w[3]};
+                const u32x4 pa = xpose[wv][lane], pb = xpose[wv][64 + lane];
+                const unsigned long long owners = __ballot(outcol);
+                u32x4 *dst = reinterpret_cast<u32x4 *>(fordered + (q * H + (strip * kStripCols - 2 + 64 * wv)));
 #ifndef BEV_EXP_NOSTORE /* timing experiment: what the ordered cloud's stores cost (results are wrong without them) */
-                store_stream(dst, p2.lo);
-                store_stream(dst + 1, hi);
+                if ((owners >> (lane >> 1)) & 1ull) __builtin_nontemporal_store(pa, dst + lane);
+                if ((owners >> (32 + (lane >> 1))) & 1ull) __builtin_nontemporal_store(pb, dst + 64 + lane);
 #else
-                if (hi.w[0] == 0x12345678u && p2.lo.w[0] == 0x9abcdef0u) store_stream(dst, p2.lo); /* keeps the values alive */
+                if (pa.x == 0x12345678u && pb.x == 0x9abcdef0u && owners) __builtin_nontemporal_store(pa, dst + lane); /* keeps the values alive */
 #endif
-                if (fgm) fgm[idx] = (int8_t)p2.gflag;
+                if (outcol && fgm) fgm[(uint32_t)(q * H + v)] = (int8_t)p2.gflag;
             }
         }
 
