@@ -638,14 +638,20 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
      * one step later, through LDS).  When all T prefix points of a frame have been counted exactly once and no check has
      * failed, the prefix is strictly ascending, every point was where its strip looked, and the result is what
      * getOrderedCloud's scatter gives; otherwise k_verdict sends the frame through the general kernels again.
-     * Loads are asm / LDS-DMA with counted waits: every step each wave issues its auxiliary loads first and its two
-     * position loads last, so "all but the two newest" (wait_loads<2>) is everything issued before the previous step's
-     * position loads. */
+     * Loads are asm / LDS-DMA, issued one step (the position loads: two steps) before they are used and waited for with
+     * ONE s_waitcnt vmcnt(0) at the top of a step — where the row's stores, issued right after the previous barrier, have
+     * had a whole step to complete as well.  (Counting — vmcnt(2), "all but the newest two" — measured the same.)  What
+     * matters is that the compiler never sees these loads: a load it sees in a loop that also stores is waited for with
+     * vmcnt(0) wherever its result is first touched, i.e. in the middle of the step. */
     const uint32_t T = kStream ? b.info[f].T : 0u;
     const bool last_strip = strip == g.strips - 1;
     uint32_t consumed = 0u, failed = 0u;
     const int first_col = strip * kStripCols - 2; /* virtual column of offset 0 */
-    uint32_t te[3] = {0u, 0u, 0u};                /* second wave: tail entry of this lane, rows rho at [rho % 3] */
+    /* tail entry of this lane, rows rho at [rho % 3]: te as the asm load delivers it (written by nothing else: a register
+     * that a load is still filling must not be redefined on one side of a branch — the compiler merges the two
+     * definitions through a copy, and a copy made while the load is in flight carries the stale word), ts after the
+     * second wave has settled it */
+    uint32_t te[3] = {0u, 0u, 0u}, ts[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
     bool dneed = false;                           /* lane 0: the check against the previous wave's last position is due */
     int dflat = 0;
     const uint32_t *ftail = kStream ? b.tail_list + ((size_t)f * N * g.strips + strip) * kTailCap : nullptr;
@@ -692,12 +698,12 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
             if (same && (ej >> 8) > idx) dead = true;                          /* lane j's point comes later than this one */
             if (__ballot(same && idx > (ej >> 8)) != 0ull && lane == j) dead = true; /* ... or some other after lane j's */
         }
-        te[sg] = dead ? 0xffffffffu : e;
+        ts[sg] = dead ? 0xffffffffu : e;
     };
     auto issue_TP = [&](auto STG, int rho) { /* second wave: the (settled) tail points of row rho, by LDS-DMA */
         constexpr int sg = decltype(STG)::value;
-        const bool on = te[sg] != 0xffffffffu;
-        const Half *src = reinterpret_cast<const Half *>(fpts + (on ? (te[sg] >> 8) : 0u));
+        const bool on = ts[sg] != 0xffffffffu;
+        const Half *src = reinterpret_cast<const Half *>(fpts + (on ? (ts[sg] >> 8) : 0u));
         glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(&twin[rho & 1][0][0])));
         glds16(src + 1, __builtin_amdgcn_readfirstlane(lds_addr(&twin[rho & 1][1][0])));
     };
@@ -767,8 +773,8 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
     auto tail_scatter = [&](auto STG, int rho) { /* second wave: the listed tail points of row rho over the prefix's */
         constexpr int sg = decltype(STG)::value;
         if (rho >= N) return;
-        if (te[sg] != 0xffffffffu) {
-            const int off = (int)(te[sg] & 0xffu);
+        if (ts[sg] != 0xffffffffu) {
+            const int off = (int)(ts[sg] & 0xffu);
             rowbuf[rho % 3][0][off] = twin[rho & 1][0][lane];
             rowbuf[rho % 3][1][off] = twin[rho & 1][1][lane];
         }
@@ -784,11 +790,9 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
             issue_X(0);
             issue_X(1);
         }
-        if (wv == 1) {
-            issue_TE(I0{}, 0);
-            issue_TE(I1{}, 1);
-            issue_TE(I2{}, 2);
-        }
+        issue_TE(I0{}, 0);
+        issue_TE(I1{}, 1);
+        issue_TE(I2{}, 2);
         wait_loads<0>(plo[0], phi[0], te[0]);
         wait_loads<0>(plo[1], phi[1], te[1]);
         asm volatile("" : "+v"(te[2]));
@@ -847,9 +851,9 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
         const int par = r & 1;
         Half cur_lo, cur_hi;
         if (kStream) {
-            /* everything but the previous step's two position loads has arrived (the prologue issues in the same order) */
+            /* everything issued in earlier steps has arrived */
             constexpr int s2 = (decltype(I)::value + 2) % 3, s1 = (decltype(I)::value + 1) % 3, s0 = decltype(I)::value % 3;
-            wait_loads<2>(plo[s2], phi[s2], te[s2]);
+            wait_loads<0>(plo[s2], phi[s2], te[s2]);
             /* row r from its buffer: the entry is the slot's own point, or the slot is empty (value-initialised,
              * BatchMultiBevGen.cpp:98) */
             const u32x4 a = rowbuf[s0][0][tid], c = rowbuf[s0][1][tid];
@@ -860,11 +864,12 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
             scatter(std::integral_constant<int, s2>{}, r + 2);
             if (wv == 1) tail_scatter(std::integral_constant<int, s1>{}, r + 1);
             if (wv == 0) issue_X(r + 3);
-            if (wv == 1) {
-                settle(std::integral_constant<int, s2>{}, r + 2);
-                issue_TE(std::integral_constant<int, s0>{}, r + 3);
-                issue_TP(std::integral_constant<int, s2>{}, r + 2);
-            }
+            if (wv == 1) settle(std::integral_constant<int, s2>{}, r + 2);
+            /* (every wave issues this load although only the second one uses it: a register that an asm load is still
+             * writing must not be defined on one side of a branch only — the compiler then merges it with its old
+             * value through a copy, and a copy made while the load is in flight carries the stale word) */
+            issue_TE(std::integral_constant<int, s0>{}, r + 3);
+            if (wv == 1) issue_TP(std::integral_constant<int, s2>{}, r + 2);
             issue_P(std::integral_constant<int, s1>{}, r + 4);
         } else {
             cur_lo = Half{{plo[ic].x, plo[ic].y, plo[ic].z, plo[ic].w}};
@@ -1004,7 +1009,11 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
          * frame). */
         {
             const float zq = __uint_as_float(p1.lo.w[2]);
-            p1.pred = cand1 && (zq - zref >= 0.3f); /* false while zref is NaN */
+            /* a candidate whose label is not the -2 every producer writes (MulranPointCloudSelect.cpp:126) keeps its
+             * label whatever the guess: phase C can then always patch without looking the input point up again (the
+             * key says "-2" or the patch is a 0) */
+            const bool plain = (p1.hi.w[3] & 0xffffu) == 0xfffeu;
+            p1.pred = cand1 && (!plain || zq - zref >= 0.3f); /* (the comparison is false while zref is NaN) */
             if (cand1 && !p1.pred) zref = zq;
         }
         if (cand1) {
@@ -1472,17 +1481,9 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
                     }
                 }
                 if (wrong) { /* the walk's provisional label differs */
-                    uint16_t label = 0;             /* not un-grounded: label = 0, BatchMultiBevGen.cpp:245 */
-                    if (hit) {                      /* un-grounded: the point's own label back */
-                        if (kk & kKeyLabelM2Bit) label = (uint16_t)(int16_t)-2;
-                        else if (kIdentity) label = reinterpret_cast<const uint16_t *>(b.pts + idx)[14];
-                        else {
-                            /* an EMPTY slot can be a candidate too (a value-initialised point has intensity 0, not -1,
-                             * so phase A tests it like any other): its label is the zero point's 0 */
-                            const uint32_t w = winner_index(b.winner[idx], b.win_tag, b.win_shift);
-                            if (w != 0u) label = reinterpret_cast<const uint16_t *>(b.pts + b.frames[f].in_offset + (w - 1u))[14];
-                        }
-                    }
+                    /* not un-grounded: label = 0, BatchMultiBevGen.cpp:245; un-grounded: the point's own label back —
+                     * which is -2: the walk guesses "stays ground" only for points that carry it */
+                    const uint16_t label = hit ? (uint16_t)(int16_t)-2 : (uint16_t)0;
                     reinterpret_cast<uint16_t *>(b.ordered + idx)[14] = label; /* label @28 */
                 }
             }

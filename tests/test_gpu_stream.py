@@ -44,6 +44,27 @@ def test_sorted_sweeps_are_read_in_place(sensor):
         ctx.close()
 
 
+def test_labels_other_than_minus_two_survive_the_in_place_path():
+    """phase C puts a candidate's own label back when it un-grounds it; in place there is no winner table to find the
+    input point through, so the walk must not have overwritten a label it cannot reconstruct (anything but -2)"""
+    p = bev_amd.params_for_sensor("HDL_64E")
+    rng = np.random.default_rng(5)
+    frames = []
+    for i in range(3):
+        f = synth.sweep(p, 200 + i, keep=0.95, n_dup=2000)
+        f["label"] = rng.choice(np.array([-2, -1, 0, 1, 7], dtype=np.int16), size=len(f), p=[0.5, 0.2, 0.1, 0.1, 0.1])
+        frames.append(f)
+    # (repeated: a register copy made while its asm load was still in flight once gave wrong tail points in one run of
+    # six — a timing-dependent fault that a single pass does not show)
+    for _ in range(12):
+        ctx = bev_amd.BevContext(p, device=0, max_batch=8, max_points=max(len(f) for f in frames))
+        try:
+            info = _run(p, ctx, frames)
+            assert [int(m) for m in info[:3, 1]] == [1, 1, 1]
+        finally:
+            ctx.close()
+
+
 def test_unsorted_frames_go_the_general_way():
     p = bev_amd.params_for_sensor("OS1_64")
     frames = [synth.firing_order(p, 3), synth.adversarial(p, 60000, 1, False), synth.sweep(p, 4)[:1500]]
