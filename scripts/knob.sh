@@ -1,7 +1,7 @@
 # usage: bash scripts/knob.sh "ENV=VAL ..." ... ; one bench line per setting (same box, interleaved twice)
 #        BENCH_ARGS=--sub-batch,128 inside a setting adds bench.py arguments (commas for blanks)
 R=$GRAFT_REPO_ROOT; cd $R
-for rep in 1 2; do
+for rep in 1 2 3; do
 for setting in "$@"; do
   env $setting timeout -k 10 300 python3 bench.py --no-build --steps 8 --warmup 3 --no-cpu $(for kv in $setting; do case $kv in BENCH_ARGS=*) echo ${kv#BENCH_ARGS=} | tr , " ";; esac; done) 2>/dev/null | tail -1 > /tmp/knob.json || exit 1
   python3 - "$setting" <<'PY'
