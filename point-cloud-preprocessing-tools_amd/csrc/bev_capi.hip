@@ -398,6 +398,13 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             }
             c->h_desc[ds][f].in_offset = a;
             c->h_desc[ds][f].n_pts = (uint32_t)(b - a);
+#ifdef BEV_EXP_ALIAS /* timing experiment: every frame reads the input of frame f % BEV_EXP_ALIAS (cache-resident input) */
+            {
+                const int src = f % BEV_EXP_ALIAS;
+                c->h_desc[ds][f].in_offset = h_offsets[src];
+                c->h_desc[ds][f].n_pts = (uint32_t)(h_offsets[src + 1] - h_offsets[src]);
+            }
+#endif
             c->h_desc[ds][f]._pad = 0;
         }
         HIPCK(c, hipMemcpyAsync(c->d_desc[ds], c->h_desc[ds], (size_t)n_frames * sizeof(FrameDesc),

@@ -75,26 +75,18 @@ BEVX_HD float bits_to_float(uint32_t u)
     return c.f;
 }
 
+/* written without a branch (0 / 0 is NaN and compares false, so the (0, 0) case needs no early return): the device's row
+ * loop evaluates this once per slot */
 BEVX_HD bool angle_is_ground(float dx, float dy, float dz)
-{
-    float xx = dx * dx;
-    float yy = dy * dy;
-    float s = sqrtf(xx + yy);
-    float a = fabsf(dz);
-    if (a == 0.0f && s == 0.0f) return true; /* atan2f(+-0, +0) = +-0 */
-    float q = a / s;
-    return q <= bits_to_float(kTanThresholdBits);
-}
-/* the same without a branch (0 / 0 is NaN and compares false): what the device's row loop uses */
-BEVX_HD bool angle_is_ground_flat(float dx, float dy, float dz)
 {
     const float xx = dx * dx;
     const float yy = dy * dy;
     const float s = sqrtf(xx + yy);
     const float a = fabsf(dz);
     const float q = a / s;
-    return ((a == 0.0f) & (s == 0.0f)) | (q <= bits_to_float(kTanThresholdBits));
+    return ((a == 0.0f) & (s == 0.0f)) | (q <= bits_to_float(kTanThresholdBits)); /* atan2f(+-0, +0) = +-0 */
 }
+BEVX_HD bool angle_is_ground_flat(float dx, float dy, float dz) { return angle_is_ground(dx, dy, dz); }
 
 /* getBelongingGrid, BatchMultiBevGen.h:73-99 -> cell = row * 50 + col.
  * The reference mixes float and double here; every step has an exact float-only equivalent
