@@ -137,6 +137,7 @@ struct bev_ctx {
     int n_lanes_active = 1; /* <= n_lanes; bev_set_lanes */
     bool staged = true;     /* two-stage pipeline, see run_pipeline; BEV_STAGED=0 falls back to free-running lanes */
     bool allow_stream = false; /* BEV_STREAM=1: sorted-prefix frames are read in place (k_probe), see bev_create */
+    bool cs_quarters = false;  /* BEV_CS_QUARTERS=1: phase B as four small workgroups per frame (see bev_create) */
     hipEvent_t fork_ev = nullptr;
     hipEvent_t stagger_ev = nullptr; /* recorded on a lane after its bandwidth-bound kernels */
     bool staggered[kMaxLanes] = {false, false, false, false};
@@ -515,7 +516,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         RoctxRange rb("bev:back (cell sums, resolve, rasters)");
         {
             ProfScope ps(c, K_CELL_SUMS, nb, st);
-            launch_cell_sums(g, b, nb, st);
+            launch_cell_sums(g, b, nb, c->cs_quarters, st);
         }
         if (d_gm) {
             ProfScope ps(c, K_GROUND_MAT, nb, st);
@@ -679,6 +680,11 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
          * 0.9 + 2.4 us for order scan + gather walk; it is opt-in until it does. */
         const char *sm = getenv("BEV_STREAM");
         c->allow_stream = sm && atoi(sm) != 0;
+        /* Phase B as four 37-KB workgroups per frame (cells by cell mod 4) is bit-identical and 17 % shorter alone, but
+         * its 1000 high-priority workgroups per sub-batch take the CUs from the front stage: 230 k instead of 260 k
+         * frames/s; opt-in until the back end is scheduled differently. */
+        const char *cq = getenv("BEV_CS_QUARTERS");
+        c->cs_quarters = cq && atoi(cq) != 0;
         const char *sg = getenv("BEV_STAGED");
         c->staged = (!sg || atoi(sg) != 0) && c->n_lanes >= 2;
     }
@@ -707,8 +713,9 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         }
         CK(hipMalloc((void **)&ln.winner, nb * S * sizeof(uint32_t)));
         CK(hipMemset(ln.winner, 0, nb * S * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.cand_key, nb * (size_t)c->geo.segs * kSeg * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.cand_z, nb * (size_t)c->geo.segs * kSeg * sizeof(float)));
+        /* (+ one segment: a quarter workgroup of k_cell_sums reads whole 64-slices from where its run starts) */
+        CK(hipMalloc((void **)&ln.cand_key, (nb * (size_t)c->geo.segs + 1) * kSeg * sizeof(uint32_t)));
+        CK(hipMalloc((void **)&ln.cand_z, (nb * (size_t)c->geo.segs + 1) * kSeg * sizeof(float)));
         CK(hipMalloc((void **)&ln.ncand, nb * (size_t)c->geo.segs * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.code_main, nb * (size_t)c->geo.emitters * c->geo.raster_bands * c->geo.code_cap * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.ncode, nb * (size_t)c->geo.emitters * c->geo.raster_bands * sizeof(uint32_t)));

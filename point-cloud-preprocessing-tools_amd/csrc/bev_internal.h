@@ -139,7 +139,8 @@ void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int sou
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st);
 void launch_verdict(const BatchPtrs &b, int nf, hipStream_t st);
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
-void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
+/* quarters: four 37-KB workgroups per frame (cells by cell mod 4) instead of one 99-KB workgroup */
+void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, bool quarters, hipStream_t st);
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st);
 /* the rasters of a sub-batch from its code lists */
 void launch_bev_raster(const Geometry &g, const BatchPtrs &b, bool want_multi, bool want_single, int nf, hipStream_t st);

@@ -819,7 +819,6 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
     PendingRow pr[3] = {};
 
     float zref = __uint_as_float(0x7fc00000u); /* height of the column's last candidate taken for ground (NaN: none yet) */
-    unsigned long long m_ready = 0;     /* candidate ballot of row r-2 */
 
     const size_t cand_base = (size_t)f * g.segs * kSeg;
     uint32_t *const fkey = own_sgpr(b.cand_key + cand_base);
@@ -889,7 +888,17 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
         const XYZI cur{__uint_as_float(cur_lo.w[0]), __uint_as_float(cur_lo.w[1]), __uint_as_float(cur_lo.w[2]),
                        __uint_as_float(cur_hi.w[0])};
         if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
-        if (lane == 0) wave_cnt[par][wv] = (uint32_t)__popcll(m_ready);
+        /* candidates of row r-2 by cell quarter (cell mod 4, the low bits of the key): a segment keeps its candidates as
+         * four consecutive runs, one per quarter, each in column order, so that phase B can be cut into four small
+         * workgroups per frame that each read one run — cells are independent, only the order inside a cell matters.
+         * A wave's four counts (at most 64 each) travel in one word. */
+        const uint32_t q2 = p2.key & 3u;
+        const bool cand2 = outcol && p2.gflag == 1;
+        const unsigned long long mq0 = __ballot(cand2 && q2 == 0u), mq1 = __ballot(cand2 && q2 == 1u),
+                                 mq2 = __ballot(cand2 && q2 == 2u), mq3 = __ballot(cand2 && q2 == 3u);
+        if (lane == 0)
+            wave_cnt[par][wv] = (uint32_t)__popcll(mq0) | ((uint32_t)__popcll(mq1) << 8) | ((uint32_t)__popcll(mq2) << 16) |
+                                ((uint32_t)__popcll(mq3) << 24);
 #ifndef BEV_EXP_NOBARRIER
         lds_barrier();
 #endif
@@ -900,10 +909,10 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
          * behind them) */
         if (r >= 2) {
             const int q = r - 2;
-            const bool is_cand = outcol && p2.gflag == 1;
+            const bool is_cand = cand2;
             const int rr = q - (lo_row - 1);        /* only rows lo-1 .. N-1 can hold candidates */
             if (rr >= 0) {
-                uint32_t before = 0, total = 0;
+                uint32_t before = 0, total = 0;     /* four byte-wide counters each (a segment holds at most 252) */
 #pragma unroll
                 for (int w = 0; w < kWaves; ++w) {
                     const uint32_t c = wave_cnt[par][w];
@@ -912,7 +921,12 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
                 }
                 const uint32_t seg = (uint32_t)(rr * strips + strip);
                 if (is_cand) {
-                    uint32_t rank = before + (uint32_t)__popcll(m_ready & ((1ull << lane) - 1ull));
+                    const unsigned long long mine = q2 == 0u ? mq0 : (q2 == 1u ? mq1 : (q2 == 2u ? mq2 : mq3));
+                    const uint32_t sh = 8u * q2;
+                    /* where the quarter's run starts (byte q of total * 0x01010100 = the quarters below it: no byte
+                     * of these sums exceeds 252), the earlier waves' candidates of the quarter, the earlier lanes' */
+                    uint32_t rank = (((total * 0x01010100u) >> sh) & 0xffu) + ((before >> sh) & 0xffu) +
+                                    (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
 #ifdef BEV_EXP_NOBARRIER /* timing experiment only: results are wrong, accesses stay in range */
                     rank &= (uint32_t)kSeg - 1u;
 #endif
@@ -920,7 +934,7 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
                     store_ws(&fkey[at], p2.key);
                     store_ws(&fz[at], __uint_as_float(p2.lo.w[2]));
                 }
-                if (tid == 2) fncand[seg] = total;
+                if (tid == 2) fncand[seg] = total;  /* n0 | n1 << 8 | n2 << 16 | n3 << 24 */
             }
             /* BEV code of the slot.  A slot that is not a candidate has its final label, so its code is final too: it
              * is appended to this strip's list of the raster band its x bin falls into (the order inside a list does
@@ -1000,7 +1014,6 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
             p1.gflag = (q >= 0 && q < N) ? gf : 0;
         }
         const bool cand1 = outcol && p1.gflag == 1;
-        const unsigned long long m_new = __ballot(cand1);
         /* Provisional labels.  Phase C un-grounds a candidate that lies 0.30 m above a neighbour cell's average ground
          * height — known only after the whole frame has been summed.  The walk GUESSES: a candidate 0.30 m above the last
          * candidate of its column that it took for ground is written with its own label, every other candidate with
@@ -1023,7 +1036,6 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
         }
 
         /* ---- row r's record (the one row r-3 has left) ---- */
-        m_ready = m_new;
         p0.lo = cur_lo;
         p0.hi = cur_hi;
         p0.status = s_r;
@@ -1109,31 +1121,41 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_only(BatchPtrs b, Geo
  * while the next part's keys and heights are already in flight, so the only memory round trip that is ever exposed is
  * the first one.  No intermediate of phase B touches HBM (round 1: the sorted heights bounced through global memory). */
 constexpr int kCells = kGridCells;
-constexpr int kCellPairs = (kCells + 1) / 2;        /* two 16-bit counters per 32-bit word */
-constexpr int kHistStride = (kCellPairs + 3) / 4 * 4; /* words per wave's histogram */
-constexpr int kTouchWords = (kCells + 31) / 32;
 static_assert(kPartSegs * kSeg <= 4096, "a part's run start (12 bits) and length (13 bits) share a word with room to spare");
+/* kQ = 1: one workgroup per frame, all 3750 cells (99 KB of LDS: one workgroup per CU).  kQ = 4: four workgroups per
+ * frame, workgroup q has the cells with cell mod 4 == q (938 of them, 37 KB: four workgroups per CU, and room beside
+ * three column-walk workgroups) and reads run q of every segment (the walk keeps a segment's candidates as four runs by
+ * cell quarter).  Cells are independent and a cell lies in one quarter, so the order inside a cell is the same. */
+template <int kQ>
+struct SumDims {
+    static constexpr int cells = (kCells + kQ - 1) / kQ;
+    static constexpr int hist_stride = ((cells + 1) / 2 + 3) / 4 * 4; /* words per wave's histogram: two 16-bit counters per word */
+    static constexpr int touch_words = (cells + 31) / 32;
+    static constexpr size_t lds_bytes = sizeof(uint32_t) * ((size_t)kSumWaves * hist_stride + cells + (size_t)kPartSegs * kSeg +
+                                                            2 * (size_t)cells + touch_words + (cells + 1) / 2 + 16);
+};
+size_t cell_sums_lds_bytes() { return SumDims<1>::lds_bytes; }
 
-size_t cell_sums_lds_bytes()
+template <int kQ>
+__global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry g, int nf)
 {
-    return sizeof(uint32_t) * ((size_t)kSumWaves * kHistStride + kCells + (size_t)kPartSegs * kSeg + 2 * (size_t)kCells +
-                               kTouchWords + (kCells + 1) / 2 + 16);
-}
-
-__global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry g)
-{
+    using D = SumDims<kQ>;
+    constexpr int kCellsQ = D::cells, kHistStride = D::hist_stride, kTouchWords = D::touch_words;
+    constexpr int kShift = kQ == 4 ? 2 : 0; /* cell -> index inside the quarter */
+    static_assert(kQ == 1 || kQ == 4, "quarters are cell mod 4");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *hist = lds;                                 /* [kSumWaves][kHistStride]: 16-bit counts, cells 2i | 2i+1 << 16 */
-    uint32_t *start = hist + kSumWaves * kHistStride;     /* [kCells]: the part's runs, start | length << 16 */
-    float *zbuf = reinterpret_cast<float *>(start + kCells); /* [kPartSegs * kSeg]: the part's heights by cell */
-    float *sumv = zbuf + kPartSegs * kSeg;                /* [kCells] running sums */
-    float *cntv = sumv + kCells;                          /* [kCells] running counts */
-    uint32_t *tbits = reinterpret_cast<uint32_t *>(cntv + kCells); /* [kTouchWords]: cells this part has touched */
-    uint16_t *tlist = reinterpret_cast<uint16_t *>(tbits + kTouchWords); /* [kCells]: ... listed, in any order */
-    uint32_t *misc = reinterpret_cast<uint32_t *>(tlist) + (kCells + 1) / 2; /* [0..1] list lengths (by part parity), [4..7] wave sums, [8] carry */
+    uint32_t *start = hist + kSumWaves * kHistStride;     /* [kCellsQ]: the part's runs, start | length << 16 */
+    float *zbuf = reinterpret_cast<float *>(start + kCellsQ); /* [kPartSegs * kSeg]: the part's heights by cell */
+    float *sumv = zbuf + kPartSegs * kSeg;                /* [kCellsQ] running sums */
+    float *cntv = sumv + kCellsQ;                          /* [kCellsQ] running counts */
+    uint32_t *tbits = reinterpret_cast<uint32_t *>(cntv + kCellsQ); /* [kTouchWords]: cells this part has touched */
+    uint16_t *tlist = reinterpret_cast<uint16_t *>(tbits + kTouchWords); /* [kCellsQ]: ... listed, in any order */
+    uint32_t *misc = reinterpret_cast<uint32_t *>(tlist) + (kCellsQ + 1) / 2; /* [0..1] list lengths (by part parity), [4..7] wave sums, [8] carry */
     uint16_t *hist16 = reinterpret_cast<uint16_t *>(hist); /* the same counters, cell c of wave w at [w * 2 * kHistStride + c] */
 
-    const int f = blockIdx.x;
+    int f = blockIdx.x, quarter = 0;
+    if (kQ > 1 && !map_block_xcd(blockIdx.x, nf, kQ, f, quarter)) return; /* the quarters of a frame on one XCD: they read the same lines */
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int T = g.segs, P = g.parts;
     const uint32_t *ckey = b.cand_key + (size_t)f * T * kSeg;
@@ -1146,15 +1168,18 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     for (int k = tid; k < kSumWaves * kHistStride; k += kSumThreads) hist[k] = 0u;
     for (int k = tid; k < kTouchWords; k += kSumThreads) tbits[k] = 0u;
     if (tid < 16) misc[tid] = 0u;
-    for (int c = tid; c < kCells; c += kSumThreads) {
+    for (int c = tid; c < kCellsQ; c += kSumThreads) {
         sumv[c] = 0.0f;   /* :133-134 */
         cntv[c] = 0.01f;  /* :135-136 */
     }
 
     /* software pipeline: counts two parts ahead, keys + heights one part ahead */
-    auto load_counts = [&](int p) -> uint32_t { /* lane j < kSegsPerWave: count of this wave's segment j of part p */
+    auto load_counts = [&](int p) -> uint32_t { /* lane j < kSegsPerWave: count (| run start << 16) of this wave's segment j of part p */
         const int t = p * kPartSegs + wv * kSegsPerWave + lane;
-        return (p < P && lane < kSegsPerWave && t < T) ? fn[t] : 0u;
+        const uint32_t w = (p < P && lane < kSegsPerWave && t < T) ? fn[t] : 0u; /* four byte-wide counts: the segment's runs */
+        if (kQ == 1) return (w & 0xffu) + ((w >> 8) & 0xffu) + ((w >> 16) & 0xffu) + (w >> 24);
+        const uint32_t sh = 8u * (uint32_t)quarter;
+        return ((w >> sh) & 0xffu) | ((((w * 0x01010100u) >> sh) & 0xffu) << 16); /* this quarter's count | where its run starts << 16 */
     };
     uint32_t key_n[kSegsPerWave][kSl]; /* next part (raw keys; lanes past the segment's count hold garbage) */
     float z_n[kSegsPerWave][kSl];
@@ -1163,13 +1188,14 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
         const int t0 = p * kPartSegs + wv * kSegsPerWave;
 #pragma unroll
         for (int j = 0; j < kSegsPerWave; ++j) {
-            n_n[j] = (int)__shfl(counts, j);
+            const uint32_t cw = (uint32_t)__shfl((int)counts, j);
+            n_n[j] = (int)(cw & 0xffffu);
             /* whole 64-slices, loaded or skipped by a WAVE-UNIFORM test, and nothing but the loads inside the test: a
              * per-lane predicated load makes the compiler branch around it and wait for the data inside the branch —
              * one round trip after the other (this loop took 4 us per part that way).  Lanes past the count read stale
              * entries of the segment (allocated memory) and are masked where the values are used. */
             const int n = __builtin_amdgcn_readfirstlane(n_n[j]);
-            const size_t at = (size_t)(t0 + j) * kSeg + lane;
+            const size_t at = (size_t)(t0 + j) * kSeg + (cw >> 16) + lane;
 #pragma unroll
             for (int k = 0; k < kSl; ++k) {
                 key_n[j][k] = 0u;
@@ -1200,7 +1226,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
             nn[j] = n_n[j];
 #pragma unroll
             for (int k = 0; k < kSl; ++k) {
-                cell[j][k] = lane + 64 * k < nn[j] ? (key_n[j][k] & kKeyCellMask) : 0xfffu; /* 0xfff: no candidate */
+                cell[j][k] = lane + 64 * k < nn[j] ? ((key_n[j][k] & kKeyCellMask) >> kShift) : 0xfffu; /* 0xfff: no candidate */
                 zz[j][k] = z_n[j][k];
             }
         }
@@ -1361,7 +1387,8 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     PHA_PRINT("cell_sums barrier0 - scan place sum request histloop looptop", tid == 0 && blockIdx.x == 100);
     PH();
     float *avg = b.avg + (size_t)f * kCells;
-    for (int c = tid; c < kCells; c += kSumThreads) avg[c] = sumv[c] / cntv[c]; /* :210 */
+    for (int c = tid; c < kCellsQ; c += kSumThreads)
+        if (c * kQ + quarter < kCells) avg[c * kQ + quarter] = sumv[c] / cntv[c]; /* :210 */
     PH_PRINT("cell_sums all-parts", tid == 0 && blockIdx.x == 100);
 }
 
@@ -1417,7 +1444,10 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int T = g.segs;
     const int t0 = (int)((long long)T * part / kResolveParts), t1 = (int)((long long)T * (part + 1) / kResolveParts);
-    for (int i = tid; i < t1 - t0; i += kResolveThreads) cnt[i] = (uint16_t)b.ncand[(size_t)f * T + t0 + i];
+    for (int i = tid; i < t1 - t0; i += kResolveThreads) {
+        const uint32_t w = b.ncand[(size_t)f * T + t0 + i]; /* four byte-wide counts (the segment's runs by cell quarter) */
+        cnt[i] = (uint16_t)((w & 0xffu) + ((w >> 8) & 0xffu) + ((w >> 16) & 0xffu) + (w >> 24));
+    }
     for (int c = tid; c < kCells; c += kResolveThreads) avg[c] = b.avg[(size_t)f * kCells + c];
     if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
     else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
@@ -1839,8 +1869,8 @@ __global__ __launch_bounds__(256) void k_angle_debug(const float *dx, const floa
 /* launchers                                                                  */
 hipError_t configure_kernels(const Geometry &g)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cell_sums),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)cell_sums_lds_bytes());
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cell_sums<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SumDims<1>::lds_bytes);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)raster_lds_bytes(g));
@@ -1885,10 +1915,13 @@ void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream
     if (nf == 0) return;
     hipLaunchKernelGGL(k_gather_only, dim3(xcd_grid(nf, g.tiles)), dim3(kGatherThreads), 0, st, b, g, nf);
 }
-void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
+void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, bool quarters, hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_cell_sums, dim3(nf), dim3(kSumThreads), cell_sums_lds_bytes(), st, b, g);
+    if (quarters)
+        hipLaunchKernelGGL(k_cell_sums<4>, dim3(xcd_grid(nf, 4)), dim3(kSumThreads), SumDims<4>::lds_bytes, st, b, g, nf);
+    else
+        hipLaunchKernelGGL(k_cell_sums<1>, dim3(nf), dim3(kSumThreads), SumDims<1>::lds_bytes, st, b, g, nf);
 }
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st)
 {
