@@ -700,6 +700,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         Lane &ln = c->lanes[l];
         int prio = prio_greatest + l;
         if (prio > prio_least) prio = prio_least;
+        if (getenv("BEV_PRIO_SWAP") && atoi(getenv("BEV_PRIO_SWAP")) != 0) prio = l == 0 ? prio_least : prio_greatest; /* experiment: the back stage below the front */
         CK(hipStreamCreateWithPriority(&ln.st, hipStreamNonBlocking, prio));
         CK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ln.front_done, hipEventDisableTiming));
