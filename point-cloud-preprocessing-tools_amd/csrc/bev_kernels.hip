@@ -852,10 +852,10 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
         if (kStream) {
             /* everything issued in earlier steps has arrived */
             constexpr int s2 = (decltype(I)::value + 2) % 3, s1 = (decltype(I)::value + 1) % 3, s0 = decltype(I)::value % 3;
-            wait_loads<0>(plo[s2], phi[s2], te[s2]);
-            /* row r from its buffer: the entry is the slot's own point, or the slot is empty (value-initialised,
-             * BatchMultiBevGen.cpp:98) */
+            /* row r from its buffer (requested before the wait for the global loads: it does not depend on them): the
+             * entry is the slot's own point, or the slot is empty (value-initialised, BatchMultiBevGen.cpp:98) */
             const u32x4 a = rowbuf[s0][0][tid], c = rowbuf[s0][1][tid];
+            wait_loads<0>(plo[s2], phi[s2], te[s2]);
             const uint32_t want = slot_rc + (uint32_t)r; /* row | col << 16 of this thread's slot in row r */
             const bool hit = r < N && c.y == want;
             cur_lo = Half{{hit ? a.x : 0u, hit ? a.y : 0u, hit ? a.z : 0u, hit ? a.w : 0u}};
