@@ -675,9 +675,10 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         int nl = e ? atoi(e) : 2;
         c->n_lanes = std::max(1, std::min(kMaxLanes, nl));
         c->n_lanes_active = c->n_lanes;
-        /* Reading sorted frames in place is complete and verified (tests/test_gpu_stream.py) but does not pay yet: the
-         * stream walk needs 170 VGPRs (two workgroups per CU instead of four) and measures 4.4 us per frame against
-         * 0.9 + 2.4 us for order scan + gather walk; it is opt-in until it does. */
+        /* Reading sorted frames in place is complete and verified (tests/test_gpu_stream.py) and saves 5.6 MB of HBM
+         * traffic per frame, but it is a wash: its walk is bound by instruction issue and its latency chain, not by
+         * memory, and three of its workgroups fill a CU's LDS, so the back end overlaps worse than beside order scan +
+         * gather walk (+4 % on the pool's slow boxes, -5 ... -10 % on the fast ones); opt-in. */
         const char *sm = getenv("BEV_STREAM");
         c->allow_stream = sm && atoi(sm) != 0;
         /* Phase B as four 37-KB workgroups per frame (cells by cell mod 4) is bit-identical and 17 % shorter alone, but
