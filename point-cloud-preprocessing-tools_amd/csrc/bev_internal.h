@@ -28,7 +28,10 @@ constexpr int kSegsPerWave = 4;                              /* segments a wave 
 constexpr int kPartSegs = kSumWaves * kSegsPerWave;          /* segments per part: 16 (4,096 candidates at most) */
 constexpr int kResolveThreads = 256;
 constexpr int kResolveParts = 4;  /* workgroups per frame in k_ground_resolve, each with its own code lists */
-constexpr int kRasterThreads = 512;
+#ifndef BEV_RASTER_THREADS
+#define BEV_RASTER_THREADS 512 /* (overridable for `make exp`: bev_kernels.hip is the only user) */
+#endif
+constexpr int kRasterThreads = BEV_RASTER_THREADS;
 constexpr int kRasterSplit = 8;   /* x-bands per frame in the raster kernel at the reference's 224 x 224 (see raster_bands_for) */
 constexpr int kMaxBands = 32;     /* coarse + fine raster bands (see RasterParams) */
 constexpr int kMaxStrips = 264;   /* ceil(65535 / kStripCols) rounded up */

@@ -485,8 +485,9 @@ struct PendingRow {
 
 /* Narrow workspace streams (candidate keys / heights, code lists) are written with the default cache policy: a row's
  * pieces from the four waves are contiguous, so L2 merges them into whole lines before they leave (with `nt` every
- * piece left as partial lines: the walk wrote 6.5 MB per frame where 5.8 MB were needed).  The 32-byte ordered-cloud
- * stores (whole 2 KiB wave rows) keep `nt`. */
+ * piece left as partial lines: the walk wrote 6.5 MB per frame where 5.8 MB were needed).  The ordered cloud's stores
+ * (whole 1 KiB pieces of a wave's 2 KiB row, see the write-out below) keep `nt`: with the default policy the pipeline is
+ * 4-6 % slower. */
 template <class T>
 __device__ __forceinline__ void store_ws(T *p, T v) { *p = v; }
 
@@ -494,7 +495,7 @@ enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcStream = 2 };
 /* Gives a wave-uniform value a scalar register of its own.  Kernel arguments arrive as 8-register tuples; the walk keeps
  * more uniform values alive than there are scalar registers, and the compiler spills and restores whole tuples (through
  * lanes of a vector register, one VALU instruction per dword): the raster constants came back eight at a time around
- * every use — a third of the walk's vector instructions. */
+ * every use (a third of the STATIC vector instructions of the row loop; executed, about 1 %). */
 template <class T>
 __device__ __forceinline__ T own_sgpr(T v)
 {
@@ -973,8 +974,13 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
                 const unsigned long long owners = __ballot(outcol);
                 u32x4 *dst = reinterpret_cast<u32x4 *>(fordered + (q * H + (strip * kStripCols - 2 + 64 * wv)));
 #ifndef BEV_EXP_NOSTORE /* timing experiment: what the ordered cloud's stores cost (results are wrong without them) */
+#ifdef BEV_EXP_WBSTORE /* timing experiment: default (write-back) policy for the ordered cloud's whole-line stores */
+                if ((owners >> (lane >> 1)) & 1ull) dst[lane] = pa;
+                if ((owners >> (32 + (lane >> 1))) & 1ull) dst[64 + lane] = pb;
+#else
                 if ((owners >> (lane >> 1)) & 1ull) __builtin_nontemporal_store(pa, dst + lane);
                 if ((owners >> (32 + (lane >> 1))) & 1ull) __builtin_nontemporal_store(pb, dst + 64 + lane);
+#endif
 #else
                 if (pa.x == 0x12345678u && pb.x == 0x9abcdef0u && owners) __builtin_nontemporal_store(pa, dst + lane); /* keeps the values alive */
 #endif
@@ -1116,7 +1122,8 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_only(BatchPtrs b, Geo
  *           word); keys and heights stay in registers
  *   scan    per-cell totals over the waves, exclusive scan over the cells -> the part's runs
  *   place   stable placement into the part's height buffer: lanes of a 64-slice that share a cell rank themselves with
- *           12 ballots (one per key bit): constant work however many distinct cells a slice has
+ *           ballots (six key bits, a verification, the other six only when it fails): constant work however many
+ *           distinct cells a slice has
  *   sum     thread t continues the running (sum, cnt) of cells t, t + 256, ... through their runs of this part
  * while the next part's keys and heights are already in flight, so the only memory round trip that is ever exposed is
  * the first one.  No intermediate of phase B touches HBM (round 1: the sorted heights bounced through global memory). */
