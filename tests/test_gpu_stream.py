@@ -135,3 +135,80 @@ def test_stream_and_general_frames_mixed_in_one_sub_batch_and_the_knob():
         assert [int(m) for m in info[:, 1]] == [0, 0, 0, 0, 0, 0]
     finally:
         ctx.close()
+
+
+# ---- property-based: sorted clouds of mid-sized sensors with everything the tiny-sensor test (test_gpu_property.py) throws
+# at the general path — boundary coordinates, non-finite values, intensity -1, mixed labels — plus appended out-of-order
+# points (also out of range) and hidden defects.  Whatever mode a frame ends in, its outputs must equal the oracle.
+from hypothesis import HealthCheck, given, settings          # noqa: E402
+from hypothesis import strategies as st                      # noqa: E402
+
+import collections                                           # noqa: E402
+_MODES = collections.Counter()
+_SPECIAL = np.array([0.0, -0.0, 0.5, -75.0, -75.000008, 75.0, -50.0, 49.999996, -112.0, -112.99999, 111.99999, 112.0,
+                     0.29999998, 0.3, -1.73, -2.0, 3.8750002, 1e9, -3e38, np.inf, -np.inf, np.nan, 1e-40], np.float32)
+
+
+@st.composite
+def _sorted_frames(draw):
+    n = draw(st.integers(8, 40))
+    h = draw(st.sampled_from([300, 504, 505, 506, 757, 1024]))   # 2 .. 5 strips, strip edges on / next to the row end
+    g = draw(st.integers(1, n - 2))
+    frames = []
+    for _ in range(draw(st.integers(1, 3))):
+        rng = np.random.default_rng(draw(st.integers(0, 2**32 - 1)))
+        keep = draw(st.sampled_from([1.0, 0.97, 0.8, 0.5]))
+        slots = np.nonzero(rng.random(n * h) < keep)[0]
+        n_tail = draw(st.sampled_from([0, 0, 40, 900, 3000]))
+        cnt = len(slots) + n_tail
+        pts = np.zeros(cnt, bev_amd.POINT_DTYPE)
+        row = np.concatenate([slots // h, rng.integers(0, n + 2, n_tail)])      # tail: anywhere, also out of range
+        col = np.concatenate([slots % h, rng.integers(0, h + 2, n_tail)])
+        a = col.astype(np.float32) * np.float32(2 * np.pi / h)
+        rad = np.float32(3) + row.astype(np.float32) * np.float32(80.0 / n)
+        pts["x"], pts["y"] = rad * np.cos(a), rad * np.sin(a)
+        pts["z"] = np.float32(-1.7) + rng.normal(0, 0.08, cnt).astype(np.float32) + (rng.random(cnt) < 0.1) * np.float32(1.5)
+        for f in ("x", "y", "z"):
+            odd = rng.random(cnt) < 0.03
+            pts[f] = np.where(odd, _SPECIAL[rng.integers(0, len(_SPECIAL), cnt)], pts[f])
+        pts["intensity"] = rng.choice(np.array([-1.0, 0.0, 0.5, 1.0], np.float32), cnt, p=[0.15, 0.05, 0.4, 0.4])
+        pts["row"], pts["col"] = row, col
+        pts["t"] = rng.integers(0, 2**32, cnt, dtype=np.uint64).astype(np.uint32)
+        pts["label"] = rng.choice(np.array([-2, -1, 0, 1, 7], np.int16), cnt, p=[0.6, 0.1, 0.1, 0.1, 0.1])
+        defect = draw(st.sampled_from(["none", "none", "swap", "dup", "oob"]))
+        if len(slots) > 3000 and defect != "none":
+            i = int(rng.integers(1500, len(slots) - 1000))
+            if defect == "swap":
+                pts[[i, i + 1]] = pts[[i + 1, i]]
+            elif defect == "dup":
+                pts["row"][i + 1], pts["col"][i + 1] = pts["row"][i], pts["col"][i]
+            else:
+                pts["row"][i] = n + 5
+        frames.append(pts)
+    return (n, h, g), frames
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(_sorted_frames())
+def test_sorted_clouds_of_mid_sized_sensors_match_oracle(case):
+    (n, h, g), frames = case
+    p = bev_amd.params_for_sensor("HDL_32E")
+    p.n_scan, p.horizon_scan, p.ground_upper_scan = n, h, g
+    sp = orc.sensor_from_params(p)
+    ctx = bev_amd.BevContext(p, device=0, max_batch=8, max_points=max(8, max(len(f) for f in frames)))  # one chunk, one sub-batch
+    try:
+        ordered, multi, single, gm = ctx.process_batch(frames, want_ground_mat=True)
+        for m in ctx.frame_info(0, len(frames))[:, 1]:
+            _MODES[int(m)] += 1
+        for i, pts in enumerate(frames):
+            o_ord, o_gm, o_multi, o_single = orc.process_frame(sp, pts)
+            assert ordered[i].tobytes() == o_ord.tobytes(), (n, h, g, i, "ordered cloud / labels")
+            assert np.array_equal(gm[i], o_gm), (n, h, g, i, "ground_mat")
+            assert np.array_equal(multi[i], o_multi) and np.array_equal(single[i], o_single), (n, h, g, i, "BEVs")
+    finally:
+        ctx.close()
+
+
+def test_the_property_examples_took_all_three_routes():
+    """(runs after the test above: read in place, general, caught and redone)"""
+    assert _MODES[1] >= 10 and _MODES[0] >= 1 and _MODES[2] >= 1, dict(_MODES)
