@@ -33,3 +33,28 @@ def test_quarter_workgroups_equal_the_oracle(sensor):
             assert np.array_equal(gm[i], o_gm) and np.array_equal(multi[i], o_multi) and np.array_equal(single[i], o_single), i
     finally:
         ctx.close()
+
+
+# the tiny-sensor property examples of test_gpu_property.py (duplicates, out-of-range points, intensity -1 fall-backs,
+# boundary and non-finite coordinates, empty frames) through the four-workgroup form
+from hypothesis import HealthCheck, given, settings     # noqa: E402
+from test_gpu_property import sensor_and_frames          # noqa: E402
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+@given(sensor_and_frames())
+def test_tiny_sensors_match_oracle_with_quarter_workgroups(case):
+    (n, h, g, res), frames = case
+    p = bev_amd.params_for_sensor("HDL_32E")
+    p.n_scan, p.horizon_scan, p.ground_upper_scan, p.height_res = n, h, g, res
+    sp = orc.sensor_from_params(p)
+    ctx = bev_amd.BevContext(p, device=0, max_batch=2, max_points=max(8, max(len(f) for f in frames)))
+    try:
+        ordered, multi, single, gm = ctx.process_batch(frames, want_ground_mat=True)
+        for i, pts in enumerate(frames):
+            o_ord, o_gm, o_multi, o_single = orc.process_frame(sp, pts)
+            assert ordered[i].tobytes() == o_ord.tobytes(), (n, h, g, i, "ordered cloud / labels")
+            assert np.array_equal(gm[i], o_gm), (n, h, g, i, "ground_mat")
+            assert np.array_equal(multi[i], o_multi) and np.array_equal(single[i], o_single), (n, h, g, i, "BEVs")
+    finally:
+        ctx.close()
