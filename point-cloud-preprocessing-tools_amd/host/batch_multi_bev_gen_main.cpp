@@ -6,6 +6,8 @@
  * through the C ABI in batches.  Extra, optional environment:
  *   BEV_DEVICES=N   use GPUs 0..N-1 of this node (one host thread + one context
  *                   per GPU, contiguous shards of the sorted file list)
+ *   BEV_DEVICE_MAP=a,b,...  the GPU of each of those N ranks instead of 0..N-1; an ordinal may repeat (0,0: two ranks, two
+ *                   contexts, two shards on ONE GPU — the sharded path on a one-GPU machine)
  *   BEV_BATCH=B     frames per bev_process_batch call (default 32)
  *   BEV_MAX_POINTS=P input points per cloud the GPU contexts are sized for at first (default 4 Mi; larger clouds make
  *                   a context grow)
@@ -71,50 +73,78 @@ int main(int argc, char **argv)
     std::vector<std::thread> workers;
     const size_t F = files.size();
     std::vector<int64_t> ranges(2 * (size_t)n_dev, 0);
+    /* rank d runs on GPU dev_of[d]: 0..N-1, or what BEV_DEVICE_MAP lists.  Ranks may share a GPU (BEV_DEVICE_MAP=0,0):
+     * every rank still has its own host thread, context, streams and shard; RCCL spans the DISTINCT GPUs (it refuses
+     * a device twice), and ranks that share one read their row from that GPU's copy of the table. */
+    std::vector<int> dev_of(n_dev);
+    for (int d = 0; d < n_dev; ++d) dev_of[d] = d;
+    if (const char *map = std::getenv("BEV_DEVICE_MAP")) {
+        std::vector<int> listed;
+        for (const char *p = map; *p;) {
+            char *end = nullptr;
+            const long v = std::strtol(p, &end, 10);
+            if (end == p || v < 0) { listed.clear(); break; }
+            listed.push_back((int)v);
+            p = *end == ',' ? end + 1 : end;
+            if (*end != ',' && *end != '\0') { listed.clear(); break; }
+        }
+        if ((int)listed.size() != n_dev) {
+            std::cerr << "BEV_DEVICE_MAP must list " << n_dev << " GPU ordinals separated by commas (BEV_DEVICES=" << n_dev << ")\n";
+            return 1;
+        }
+        dev_of = listed;
+    }
+    std::vector<int> uniq;                 /* distinct GPUs, in order of first use: uniq[0] holds rank 0 */
+    std::vector<int> uidx(n_dev, 0);       /* rank -> index into uniq */
+    for (int d = 0; d < n_dev; ++d) {
+        size_t k = 0;
+        while (k < uniq.size() && uniq[k] != dev_of[d]) ++k;
+        if (k == uniq.size()) uniq.push_back(dev_of[d]);
+        uidx[d] = (int)k;
+    }
     {
+        const int n_u = (int)uniq.size();
         std::vector<int64_t> table(2 * (size_t)n_dev);
         for (int d = 0; d < n_dev; ++d) {
             table[2 * d] = (int64_t)(F * d / n_dev);
             table[2 * d + 1] = (int64_t)(F * (d + 1) / n_dev) - table[2 * d];
         }
-        std::vector<int> devs(n_dev);
-        std::vector<ncclComm_t> comms(n_dev);
-        std::vector<hipStream_t> streams(n_dev);
-        std::vector<int64_t *> bufs(n_dev, nullptr);
-        for (int d = 0; d < n_dev; ++d) devs[d] = d;
-        bool ok = ncclCommInitAll(comms.data(), n_dev, devs.data()) == ncclSuccess;
-        for (int d = 0; ok && d < n_dev; ++d) {
-            ok = hipSetDevice(d) == hipSuccess && hipStreamCreate(&streams[d]) == hipSuccess &&
-                 hipMalloc((void **)&bufs[d], table.size() * sizeof(int64_t)) == hipSuccess;
-            if (ok && d == 0)
+        std::vector<ncclComm_t> comms(n_u);
+        std::vector<hipStream_t> streams(n_u);
+        std::vector<int64_t *> bufs(n_u, nullptr);
+        bool ok = ncclCommInitAll(comms.data(), n_u, uniq.data()) == ncclSuccess;
+        for (int u = 0; ok && u < n_u; ++u) {
+            ok = hipSetDevice(uniq[u]) == hipSuccess && hipStreamCreate(&streams[u]) == hipSuccess &&
+                 hipMalloc((void **)&bufs[u], table.size() * sizeof(int64_t)) == hipSuccess;
+            if (ok && u == 0)
                 ok = hipMemcpy(bufs[0], table.data(), table.size() * sizeof(int64_t), hipMemcpyHostToDevice) == hipSuccess;
         }
         if (ok) {
             ncclGroupStart();
-            for (int d = 0; d < n_dev; ++d)
-                ok = ok && ncclBroadcast(bufs[d], bufs[d], table.size(), ncclInt64, 0, comms[d], streams[d]) == ncclSuccess;
+            for (int u = 0; u < n_u; ++u)
+                ok = ok && ncclBroadcast(bufs[u], bufs[u], table.size(), ncclInt64, 0, comms[u], streams[u]) == ncclSuccess;
             ncclGroupEnd();
         }
-        for (int d = 0; ok && d < n_dev; ++d) {
-            ok = hipSetDevice(d) == hipSuccess && hipStreamSynchronize(streams[d]) == hipSuccess;
-            /* every GPU reads ITS row from ITS copy of the table */
-            if (ok) ok = hipMemcpy(&ranges[2 * d], bufs[d] + 2 * d, 2 * sizeof(int64_t), hipMemcpyDeviceToHost) == hipSuccess;
-        }
-        for (int d = 0; d < n_dev; ++d) {
-            if (bufs[d]) { (void)hipSetDevice(d); (void)hipFree(bufs[d]); (void)hipStreamDestroy(streams[d]); }
+        for (int u = 0; ok && u < n_u; ++u)
+            ok = hipSetDevice(uniq[u]) == hipSuccess && hipStreamSynchronize(streams[u]) == hipSuccess;
+        for (int d = 0; ok && d < n_dev; ++d) /* every rank reads ITS row from the copy of the table on ITS GPU */
+            ok = hipSetDevice(dev_of[d]) == hipSuccess &&
+                 hipMemcpy(&ranges[2 * d], bufs[uidx[d]] + 2 * d, 2 * sizeof(int64_t), hipMemcpyDeviceToHost) == hipSuccess;
+        for (int u = 0; u < n_u; ++u) {
+            if (bufs[u]) { (void)hipSetDevice(uniq[u]); (void)hipFree(bufs[u]); (void)hipStreamDestroy(streams[u]); }
         }
         if (!ok) {
-            std::cerr << "no usable HIP device / RCCL broadcast of the frame ranges failed (GPUs requested: " << n_dev
+            std::cerr << "no usable HIP device / RCCL broadcast of the frame ranges failed (ranks: " << n_dev << ", GPUs: " << n_u
                       << "); there is no CPU path\n";
             return 1;
         }
-        for (int d = 0; d < n_dev; ++d) ncclCommDestroy(comms[d]);
-        (void)hipSetDevice(0);
+        for (int u = 0; u < n_u; ++u) ncclCommDestroy(comms[u]);
+        (void)hipSetDevice(uniq[0]);
     }
     for (int d = 0; d < n_dev; ++d) {
         const size_t first = (size_t)ranges[2 * d], count = (size_t)ranges[2 * d + 1];
         workers.emplace_back([&, d, first, count]() {
-            BatchMultiBevGen gen(root, argv[2], d, batch, max_pts);
+            BatchMultiBevGen gen(root, argv[2], dev_of[d], batch, max_pts);
             if (!gen.ok()) { bad[d] = 1; return; }
             ms[d] = gen.processFiles(files, first, count, png, n_dev == 1);
             failed[d] = gen.failedFrames();

@@ -171,3 +171,32 @@ def test_cli_two_gpus_write_the_same_tree_as_one(tmp_path):
     assert ra.returncode == 0 and rb.returncode == 0, ra.stderr + rb.stderr
     ta, tb = _tree(a), _tree(b)
     assert ta.keys() == tb.keys() and all(ta[k] == tb[k] for k in ta), [k for k in ta if ta.get(k) != tb.get(k)][:4]
+
+
+def test_cli_two_ranks_on_one_gpu_write_the_same_tree_as_one(tmp_path):
+    """BEV_DEVICES=2 BEV_DEVICE_MAP=0,0: the sharded path on a one-GPU machine — two host threads, two contexts, two
+    contiguous shards of the sorted file list, each rank reading its row of the frame-range table from its GPU's copy
+    (RCCL spans the distinct GPUs only: here one) -> byte-identical output tree (BatchMultiBevGen.cpp:727-757:
+    iterations are independent).  Three ranks as well: shards of unequal length."""
+    import os
+    p = bev_amd.params_for_sensor("HDL_32E")
+    a = tmp_path / "one"
+    _make_dataset(a, p, 7)
+    env = dict(os.environ, BEV_BATCH="2")
+    ra = subprocess.run([str(CLI), str(a), "HDL_32E"], capture_output=True, text=True, timeout=300, env=env)
+    assert ra.returncode == 0, ra.stderr
+    ta = _tree(a)
+    for ranks in (2, 3):
+        b = tmp_path / f"ranks{ranks}"
+        _make_dataset(b, p, 7)
+        rb = subprocess.run([str(CLI), str(b), "HDL_32E"], capture_output=True, text=True, timeout=300,
+                            env=dict(env, BEV_DEVICES=str(ranks), BEV_DEVICE_MAP=",".join(["0"] * ranks)))
+        assert rb.returncode == 0, rb.stdout + rb.stderr
+        # every file is converted exactly once, whichever rank had it
+        assert sorted(l for l in rb.stdout.splitlines() if l.startswith("Converting file: ")) == \
+            sorted(l for l in ra.stdout.splitlines() if l.startswith("Converting file: "))
+        tb = _tree(b)
+        assert ta.keys() == tb.keys() and all(ta[k] == tb[k] for k in ta), [k for k in ta if ta.get(k) != tb.get(k)][:4]
+    bad = subprocess.run([str(CLI), str(a), "HDL_32E"], capture_output=True, text=True, timeout=60,
+                         env=dict(env, BEV_DEVICES="2", BEV_DEVICE_MAP="0"))
+    assert bad.returncode == 1 and "BEV_DEVICE_MAP must list 2" in bad.stderr
