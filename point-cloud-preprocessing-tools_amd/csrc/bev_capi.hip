@@ -49,8 +49,7 @@ struct Lane {
     uint32_t *tail_list = nullptr, *tail_cnt = nullptr; /* ... and their tail points per (row, strip) (stream mode only) */
     uint32_t *winner = nullptr;
     uint32_t win_gen = 0; /* generation tag of the last sub-batch that used this set's winner table */
-    uint32_t *cand_key = nullptr;
-    float *cand_z = nullptr;
+    uint2 *cand = nullptr; /* candidate key | height */
     uint32_t *ncand = nullptr;
     uint32_t *code_main = nullptr, *ncode = nullptr; /* per-(strip, band) lists of final BEV codes */
     float *avg = nullptr;
@@ -137,7 +136,6 @@ struct bev_ctx {
     int n_lanes_active = 1; /* <= n_lanes; bev_set_lanes */
     bool staged = true;     /* two-stage pipeline, see run_pipeline; BEV_STAGED=0 falls back to free-running lanes */
     bool allow_stream = false; /* BEV_STREAM=1: sorted-prefix frames are read in place (k_probe), see bev_create */
-    bool cs_quarters = false;  /* BEV_CS_QUARTERS=1: phase B as four small workgroups per frame (see bev_create) */
     hipEvent_t fork_ev = nullptr;
     hipEvent_t stagger_ev = nullptr; /* recorded on a lane after its bandwidth-bound kernels */
     bool staggered[kMaxLanes] = {false, false, false, false};
@@ -450,8 +448,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.winner = ln.winner;
         b.win_shift = c->win_shift;
         b.ordered = d_ordered + (size_t)f0 * S;
-        b.cand_key = ln.cand_key;
-        b.cand_z = ln.cand_z;
+        b.cand = ln.cand;
         b.ncand = ln.ncand;
         b.code_main = ln.code_main;
         b.ncode = ln.ncode;
@@ -516,7 +513,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         RoctxRange rb("bev:back (cell sums, resolve, rasters)");
         {
             ProfScope ps(c, K_CELL_SUMS, nb, st);
-            launch_cell_sums(g, b, nb, c->cs_quarters, st);
+            launch_cell_sums(g, b, nb, st);
         }
         if (d_gm) {
             ProfScope ps(c, K_GROUND_MAT, nb, st);
@@ -681,11 +678,6 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
          * gather walk (+4 % on the pool's slow boxes, -5 ... -10 % on the fast ones); opt-in. */
         const char *sm = getenv("BEV_STREAM");
         c->allow_stream = sm && atoi(sm) != 0;
-        /* Phase B as four 37-KB workgroups per frame (cells by cell mod 4) is bit-identical and 17 % shorter alone, but
-         * its 1000 high-priority workgroups per sub-batch take the CUs from the front stage: 230 k instead of 260 k
-         * frames/s; opt-in until the back end is scheduled differently. */
-        const char *cq = getenv("BEV_CS_QUARTERS");
-        c->cs_quarters = cq && atoi(cq) != 0;
         const char *sg = getenv("BEV_STAGED");
         c->staged = (!sg || atoi(sg) != 0) && c->n_lanes >= 2;
     }
@@ -715,9 +707,8 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         }
         CK(hipMalloc((void **)&ln.winner, nb * S * sizeof(uint32_t)));
         CK(hipMemset(ln.winner, 0, nb * S * sizeof(uint32_t)));
-        /* (+ one segment: a quarter workgroup of k_cell_sums reads whole 64-slices from where its run starts) */
-        CK(hipMalloc((void **)&ln.cand_key, (nb * (size_t)c->geo.segs + 1) * kSeg * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.cand_z, (nb * (size_t)c->geo.segs + 1) * kSeg * sizeof(float)));
+        /* (+ one segment of slack: whole 64-slices are read past a short segment's count) */
+        CK(hipMalloc((void **)&ln.cand, (nb * (size_t)c->geo.segs + 1) * kSeg * sizeof(uint2)));
         CK(hipMalloc((void **)&ln.ncand, nb * (size_t)c->geo.segs * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.code_main, nb * (size_t)c->geo.emitters * c->geo.raster_bands * c->geo.code_cap * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.ncode, nb * (size_t)c->geo.emitters * c->geo.raster_bands * sizeof(uint32_t)));
@@ -746,7 +737,7 @@ void bev_destroy(bev_ctx_t *c)
     for (int l = 0; l < kMaxLanes; ++l) {
         Lane &ln = c->lanes[l];
         if (ln.st) (void)hipStreamSynchronize(ln.st);
-        void *ws[] = {ln.info, ln.est, ln.tail_list, ln.tail_cnt, ln.winner, ln.cand_key, ln.cand_z, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
+        void *ws[] = {ln.info, ln.est, ln.tail_list, ln.tail_cnt, ln.winner, ln.cand, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
         for (void *p : ws)
             if (p) (void)hipFree(p);
         if (ln.done) (void)hipEventDestroy(ln.done);

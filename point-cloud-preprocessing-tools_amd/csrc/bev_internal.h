@@ -67,7 +67,7 @@ constexpr int kTailBuckets = 2048;  /* (row, strip) pairs of a frame that k_prob
 constexpr int kStreamMaxRows = 128;  /* sensors with more rows go the general way (the stream walk keeps per-row estimates in LDS) */
 
 /* Workspace streams between the kernels of one sub-batch (see bev_exact.h for the candidate key):
- *   cand_key u32 / cand_z f32  [nf][segs][kSeg]   candidates, one segment per (row, strip), compacted in column order;
+ *   cand uint2 (key | height)  [nf][segs][kSeg]   candidates, one segment per (row, strip), compacted in column order;
  *                                                  segments in row-major order => concatenation = slot order
  *   ncand u32                  [nf][segs]
  *   code_main u32              [nf][emitters][bands][code_cap]   BEV codes of the slots that are NOT candidates
@@ -102,8 +102,7 @@ struct BatchPtrs {
     uint32_t win_tag;            /* generation of this sub-batch in its workspace set (0: table was cleared) */
     int win_shift;               /* bits of index+1 */
     bev_point_t *ordered;        /* [nf][S] */
-    uint32_t *cand_key;          /* [nf][segs][kSeg] */
-    float *cand_z;               /* [nf][segs][kSeg] */
+    uint2 *cand;                 /* [nf][segs][kSeg]: candidate key (bev_exact.h) | height */
     uint32_t *ncand;             /* [nf][segs] */
     uint32_t *code_main;         /* [nf][emitters][bands][code_cap] */
     uint32_t *ncode;             /* [nf][emitters][bands] */
@@ -142,8 +141,7 @@ void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int sou
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st);
 void launch_verdict(const BatchPtrs &b, int nf, hipStream_t st);
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
-/* quarters: four 37-KB workgroups per frame (cells by cell mod 4) instead of one 99-KB workgroup */
-void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, bool quarters, hipStream_t st);
+void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st);
 /* the rasters of a sub-batch from its code lists */
 void launch_bev_raster(const Geometry &g, const BatchPtrs &b, bool want_multi, bool want_single, int nf, hipStream_t st);

@@ -822,8 +822,7 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
     float zref = __uint_as_float(0x7fc00000u); /* height of the column's last candidate taken for ground (NaN: none yet) */
 
     const size_t cand_base = (size_t)f * g.segs * kSeg;
-    uint32_t *const fkey = own_sgpr(b.cand_key + cand_base);
-    float *const fz = own_sgpr(b.cand_z + cand_base);
+    uint2 *const fcand = own_sgpr(b.cand + cand_base);
     uint32_t *const fncand = own_sgpr(b.ncand + (size_t)f * g.segs);
     const uint32_t code_cap = own_sgpr(g.code_cap);
     uint32_t *const flist = own_sgpr(b.code_main + ((size_t)f * g.emitters + strip) * bands * (size_t)code_cap);
@@ -889,17 +888,10 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
         const XYZI cur{__uint_as_float(cur_lo.w[0]), __uint_as_float(cur_lo.w[1]), __uint_as_float(cur_lo.w[2]),
                        __uint_as_float(cur_hi.w[0])};
         if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
-        /* candidates of row r-2 by cell quarter (cell mod 4, the low bits of the key): a segment keeps its candidates as
-         * four consecutive runs, one per quarter, each in column order, so that phase B can be cut into four small
-         * workgroups per frame that each read one run — cells are independent, only the order inside a cell matters.
-         * A wave's four counts (at most 64 each) travel in one word. */
-        const uint32_t q2 = p2.key & 3u;
+        /* candidates of row r-2: every wave publishes its count, the write-out after the barrier ranks them */
         const bool cand2 = outcol && p2.gflag == 1;
-        const unsigned long long mq0 = __ballot(cand2 && q2 == 0u), mq1 = __ballot(cand2 && q2 == 1u),
-                                 mq2 = __ballot(cand2 && q2 == 2u), mq3 = __ballot(cand2 && q2 == 3u);
-        if (lane == 0)
-            wave_cnt[par][wv] = (uint32_t)__popcll(mq0) | ((uint32_t)__popcll(mq1) << 8) | ((uint32_t)__popcll(mq2) << 16) |
-                                ((uint32_t)__popcll(mq3) << 24);
+        const unsigned long long mc = __ballot(cand2);
+        if (lane == 0) wave_cnt[par][wv] = (uint32_t)__popcll(mc);
 #ifndef BEV_EXP_NOBARRIER
         lds_barrier();
 #endif
@@ -913,7 +905,7 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
             const bool is_cand = cand2;
             const int rr = q - (lo_row - 1);        /* only rows lo-1 .. N-1 can hold candidates */
             if (rr >= 0) {
-                uint32_t before = 0, total = 0;     /* four byte-wide counters each (a segment holds at most 252) */
+                uint32_t before = 0, total = 0;
 #pragma unroll
                 for (int w = 0; w < kWaves; ++w) {
                     const uint32_t c = wave_cnt[par][w];
@@ -922,20 +914,15 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
                 }
                 const uint32_t seg = (uint32_t)(rr * strips + strip);
                 if (is_cand) {
-                    const unsigned long long mine = q2 == 0u ? mq0 : (q2 == 1u ? mq1 : (q2 == 2u ? mq2 : mq3));
-                    const uint32_t sh = 8u * q2;
-                    /* where the quarter's run starts (byte q of total * 0x01010100 = the quarters below it: no byte
-                     * of these sums exceeds 252), the earlier waves' candidates of the quarter, the earlier lanes' */
-                    uint32_t rank = (((total * 0x01010100u) >> sh) & 0xffu) + ((before >> sh) & 0xffu) +
-                                    (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+                    /* the earlier waves' candidates, the earlier lanes' */
+                    uint32_t rank = before + (uint32_t)__popcll(mc & ((1ull << lane) - 1ull));
 #ifdef BEV_EXP_NOBARRIER /* timing experiment only: results are wrong, accesses stay in range */
                     rank &= (uint32_t)kSeg - 1u;
 #endif
                     const uint32_t at = seg * (uint32_t)kSeg + rank; /* < 2^32: a frame's segments hold fewer slots than S */
-                    store_ws(&fkey[at], p2.key);
-                    store_ws(&fz[at], __uint_as_float(p2.lo.w[2]));
+                    store_ws(&fcand[at], make_uint2(p2.key, p2.lo.w[2])); /* key | height */
                 }
-                if (tid == 2) fncand[seg] = total;  /* n0 | n1 << 8 | n2 << 16 | n3 << 24 */
+                if (tid == 2) fncand[seg] = total;
             }
             /* BEV code of the slot.  A slot that is not a candidate has its final label, so its code is final too: it
              * is appended to this strip's list of the raster band its x bin falls into (the order inside a list does
@@ -1083,6 +1070,322 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_s
     }
 }
 
+/* ------------------------------------------------------------------------- */
+/* k_walk (round 3): the column walk for the winner-table and identity sources, rebuilt around three measurements:
+ *   1. hipcc drains the memory queue (s_waitcnt vmcnt(0)) at the top of EVERY row step of k_strip_ground: gfx9-family
+ *      loads and stores retire out of order with respect to each other, so with stores pending the compiler cannot
+ *      count, and the "two rows in flight" were one row in flight plus a full round trip per step.  Here every global
+ *      READ of the row loop is an LDS-DMA load (global_load_lds: per-lane source address, data lands in LDS, no VGPR
+ *      destination the compiler could copy or spill while the load is in flight), issued two steps ahead and waited
+ *      for with a COUNTED s_waitcnt: "a load has completed once at most as many operations are outstanding as loads
+ *      were issued after it" holds whatever the stores in between do, and the stores of a step are issued BEFORE its
+ *      loads, so that the wait at the top of a step covers stores that are a whole step old and loads that are two.
+ *   2. a fifth of the walk's vector instructions were v_readlane restores of spilled scalar registers: the raster
+ *      constants came back as an 8-dword tuple for every multiplication, pointers that had been laundered through
+ *      asm turned every store into a FLAT store (which also counts on lgkmcnt, the LDS counter).  The raster
+ *      constants live in vector registers here (they only feed VALU), the power-of-two / divide choice is a template
+ *      parameter, stores go through address-space-1 pointers (global_store, scalar base + 32-bit lane offset).
+ *   3. waves without a column (the last strip of a row holds 67 of 256 threads for HDL_64E, 16 for OS1_64) end
+ *      before the row loop: an ended wave drops out of s_barrier.
+ * The arithmetic, the candidate segments, the provisional labels and the code lists are k_strip_ground's (see there). */
+template <class T> using gptr = __attribute__((address_space(1))) T *;
+__device__ __forceinline__ void glds16x2(const void *ga, uint32_t la, const void *gb, uint32_t lb)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(ga), "s"(la), "v"(gb), "s"(lb) : "memory");
+}
+__device__ __forceinline__ void glds4_nt(const void *gsrc, uint32_t lds_dst)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+/* a wave-uniform value that only feeds vector instructions: keep it out of the scalar file */
+template <class T>
+__device__ __forceinline__ T in_vgpr(T v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+/* row record of the walk: flags = (status + 1) | (ground_mat + 1) << 2 | pred << 4 | slot holds a point << 5 */
+struct WalkRow {
+    u32x4 lo, hi;
+    uint32_t code, key, fl;
+};
+__device__ __forceinline__ int wr_status(uint32_t fl) { return (int)(fl & 3u) - 1; }
+__device__ __forceinline__ int wr_gflag(uint32_t fl) { return (int)((fl >> 2) & 3u) - 1; }
+
+template <int kSrc, bool kPow2, bool kGm>
+__global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
+{
+    constexpr bool kIdentity = kSrc == kSrcIdentity;
+    static_assert(kSrc == kSrcGather || kSrc == kSrcIdentity, "the in-place source has its own kernel");
+    int f, strip;
+    if (!map_block_xcd(blockIdx.x, nf, g.strips, f, strip)) return;
+    if (!kIdentity && b.info && b.info[f].mode != want_mode) return; /* another launch of the walk has the frame */
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = g.N, H = g.H, lo_row = g.N - g.G, strips = g.strips;
+    const size_t frame_off = (size_t)f * g.S;
+    const int bands = g.raster_bands;
+
+    const int sh_right = ((lane + 2) & 63) << 2, sh_left = ((lane - 2) & 63) << 2, sh_left1 = ((lane - 1) & 63) << 2;
+    auto lane_from = [&](int sel, uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)x); };
+    auto lane_from_f = [&](int sel, float x) -> float { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)__float_as_uint(x))); };
+    const int v = strip * kStripCols + tid - 2;                      /* virtual column */
+    const bool provider = (v < H + 2) && (v >= 0 || strip == 0);     /* has a point to load */
+    const bool outcol = tid >= 2 && tid < 2 + kStripCols && v < H;   /* owns column v's outputs */
+    const int vcol = v >= H ? v - H : v;                             /* wrap; v < 0 keeps the flat rule */
+
+    constexpr int kWaves = kStripThreads / 64;
+    __shared__ u32x4 ring[3][2][kStripThreads];            /* the points of rows r, r+1, r+2 (low / high halves), by thread */
+    __shared__ uint32_t wring[3][kStripThreads];           /* raw winner words of rows r+2, r+3, r+4 */
+    __shared__ float4 edge[3][kWaves][4];                  /* rows r, r-1, (r-2): lanes 0, 1, 62, 63 of every wave */
+    __shared__ uint32_t wave_cnt[2][kWaves];               /* per-wave candidate counts of the row being written */
+    __shared__ uint32_t band_cursor[kMaxBands];            /* entries already in this strip's code list of each band */
+    __shared__ uint8_t band_tab[512];                      /* x bin -> raster band */
+    __shared__ uint32_t seen[1 << kSeenBits];              /* direct-mapped memo of codes this strip has already listed */
+    __shared__ int edge_x[kGridRows], edge_y[kGridCols];   /* BEV bin of every ground-grid row's / column's lower edge */
+    if (tid < kMaxBands) band_cursor[tid] = 0u;
+    if (tid < 2 * kWaves) wave_cnt[tid / kWaves][tid % kWaves] = 0u;
+    if (tid < 3 * kWaves * 4) (&edge[0][0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = tid; k < (1 << kSeenBits); k += kStripThreads) seen[k] = kSkip;
+    for (int x = tid; x < g.rp.mat_size; x += kStripThreads) band_tab[x] = (uint8_t)raster_band_of(x, g.rp);
+    if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
+    else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
+    lds_barrier();
+    /* a wave none of whose threads has a column ends here (its counts stay zero, nobody reads its edge lanes: the
+     * threads that would are not output columns) */
+    if (__ballot(provider) == 0ull) return;
+
+    const bev_point_t *fpts = kIdentity ? (b.pts + frame_off) : (b.pts + b.frames[f].in_offset);
+    const uint32_t *fwin = b.winner + frame_off;
+    const uint32_t win_tag = b.win_tag;
+    const int win_shift = b.win_shift;
+    /* an empty slot loads a dummy (the first point of this frame's OUTPUT: always allocated, one cached line) and is
+     * zeroed when the row is consumed: every step issues the same loads */
+    const Half *dummy = reinterpret_cast<const Half *>(b.ordered + frame_off);
+    auto has_slot = [&](int r) -> bool { return provider && r < N && r * H + vcol >= 0; };
+    /* LDS addresses of this wave's pieces of the rings */
+    const uint32_t ring_l = __builtin_amdgcn_readfirstlane(lds_addr(&ring[0][0][0])) + (uint32_t)wv * 1024u;
+    const uint32_t wring_l = __builtin_amdgcn_readfirstlane(lds_addr(&wring[0][0])) + (uint32_t)wv * 256u;
+    auto issue_winner = [&](int q, int slot) { /* raw winner word of row q */
+        if (kIdentity) return;
+        const int fl = has_slot(q) ? q * H + vcol : 0;
+        glds4_nt(&fwin[fl], wring_l + (uint32_t)slot * 1024u);
+    };
+    auto issue_points = [&](uint32_t w, int slot) { /* w: input index + 1, 0 = empty slot */
+        const Half *src = w != 0u ? reinterpret_cast<const Half *>(fpts + (w - 1u)) : dummy;
+        glds16x2(src, ring_l + (uint32_t)slot * 8192u, src + 1, ring_l + (uint32_t)slot * 8192u + 4096u);
+    };
+    auto winner_of = [&](int q, uint32_t raw) -> uint32_t { /* input index + 1 of slot (q, this column), 0 = empty */
+        if (!has_slot(q)) return 0u;
+        if (kIdentity) return (uint32_t)(q * H + vcol) + 1u;
+        return winner_index(raw, win_tag, win_shift);
+    };
+    uint32_t full = 0u; /* bit (row mod 3): the row's slot holds a point */
+    {   /* prologue: the queue the row loop expects — points of row 0, winners of row 2, points of row 1, winners of row 3 */
+        issue_winner(0, 0);
+        issue_winner(1, 1);
+        wait_vm<0>();
+        const uint32_t w0 = winner_of(0, kIdentity ? 0u : wring[0][tid]), w1 = winner_of(1, kIdentity ? 0u : wring[1][tid]);
+        full = (w0 != 0u ? 1u : 0u) | (w1 != 0u ? 2u : 0u);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the words have been read before their ring slots are refilled */
+        issue_points(w0, 0);
+        issue_winner(2, 2);
+        issue_points(w1, 1);
+        issue_winner(3, 0);
+    }
+
+    WalkRow pr[3] = {};
+    float zref = __uint_as_float(0x7fc00000u); /* height of the column's last candidate taken for ground (NaN: none yet) */
+
+    const size_t cand_base = (size_t)f * g.segs * kSeg;
+    const gptr<u32x2> fcand = (gptr<u32x2>)(b.cand + cand_base);
+    const gptr<uint32_t> fncand = (gptr<uint32_t>)(b.ncand + (size_t)f * g.segs);
+    const uint32_t code_cap = g.code_cap;
+    const gptr<uint32_t> flist = (gptr<uint32_t>)(b.code_main + ((size_t)f * g.emitters + strip) * bands * (size_t)code_cap);
+    const gptr<u32x4> fordered = (gptr<u32x4>)(b.ordered + frame_off);
+    const gptr<int8_t> fgm = (gptr<int8_t>)(kGm ? b.gm + frame_off : nullptr);
+    RasterParams rp = g.rp; /* the fields the BEV code needs, in vector registers */
+    rp.max_range_f = in_vgpr(rp.max_range_f);
+    rp.lidar_to_ground = in_vgpr(rp.lidar_to_ground);
+    rp.mat_size = in_vgpr(rp.mat_size);
+    rp.n_layers = in_vgpr(rp.n_layers);
+    if (kPow2) {
+        rp.inv_interval = in_vgpr(rp.inv_interval);
+        rp.inv_height_res = in_vgpr(rp.inv_height_res);
+    } else {
+        rp.interval = in_vgpr(rp.interval);
+        rp.height_res = in_vgpr(rp.height_res);
+        rp.inv_interval = 0.0f;
+        rp.inv_height_res = 0.0f;
+    }
+    auto bin_of = [&](float p) -> int { /* bev_bin_rp with the reciprocal / divide choice made at compile time */
+        const float s = p + rp.max_range_f;
+        return round_half_up_bin(kPow2 ? s * rp.inv_interval : s / rp.interval);
+    };
+    auto code_of = [&](float px, float py, float pz, int label) -> uint32_t { /* bev_code, BatchMultiBevGen.cpp:279-285, :343-349 */
+        const int x = bin_of(px), y = bin_of(py);
+        const bool in = (label != 0) & ((unsigned)x < (unsigned)rp.mat_size) & ((unsigned)y < (unsigned)rp.mat_size);
+        const float hq = kPow2 ? pz * rp.inv_height_res : pz / rp.height_res;
+        int layer = cvtt_f32(roundf(hq + rp.lidar_to_ground)); /* :281 */
+        int h = height_times4(pz + rp.lidar_to_ground);        /* :345 */
+        h = h < 0 ? 0 : (h > 255 ? 255 : h);                   /* :346 */
+        const uint32_t l = (layer >= 0 && layer < rp.n_layers) ? (uint32_t)layer : kNoLayer;
+        const uint32_t code = (uint32_t)(in ? x : 0) | ((uint32_t)(in ? y : 0) << 9) | ((uint32_t)h << 18) | (l << 26);
+        return in ? code : kSkip;
+    };
+    /* where a thread's point goes in its wave's 2 KiB transposition area (the ring slot the step has just consumed:
+     * 1 KiB in the low plane, 1 KiB in the high plane): points 0..31 of the wave in the first, 32..63 in the second */
+    const uint32_t xp_w = (uint32_t)(lane & 31) * 32u + (lane < 32 ? 0u : 4096u);
+
+    auto row_step = [&](auto I, const int r) {
+        constexpr int s0 = decltype(I)::value % 3;         /* ring slot of row r (and of row r + 3) */
+        constexpr int s2 = (decltype(I)::value + 2) % 3;   /* ... of row r + 2: the slot row r - 1 has left */
+        constexpr int s1 = (decltype(I)::value + 1) % 3;   /* winner ring: row r + 4 goes where row r + 1's word was */
+        WalkRow &p0 = pr[s0], &p1 = pr[s2], &p2 = pr[s1];
+        const int par = r & 1;
+        /* everything but the three newest loads (points of row r + 1, winners of row r + 3) has arrived: the points of
+         * row r and the winner words of row r + 2 (the identity source issues no winner loads: two newest) */
+        wait_vm<kIdentity ? 2 : 3>();
+        u32x4 cur_lo = ring[s0][0][tid], cur_hi = ring[s0][1][tid];
+        const uint32_t wraw = kIdentity ? 0u : wring[s2][tid];
+        if (!((full >> s0) & 1u)) { /* untouched slot: value-initialised, BatchMultiBevGen.cpp:98 */
+            cur_lo = u32x4{0u, 0u, 0u, 0u};
+            cur_hi = u32x4{0u, 0u, 0u, 0u};
+        }
+        const XYZI prev{__uint_as_float(p1.lo.x), __uint_as_float(p1.lo.y), __uint_as_float(p1.lo.z), __uint_as_float(p1.hi.x)};
+        const XYZI prevprev{__uint_as_float(p2.lo.x), __uint_as_float(p2.lo.y), __uint_as_float(p2.lo.z), __uint_as_float(p2.hi.x)};
+        const XYZI cur{__uint_as_float(cur_lo.x), __uint_as_float(cur_lo.y), __uint_as_float(cur_lo.z), __uint_as_float(cur_hi.x)};
+        if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
+        /* candidates of row r-2: every wave publishes its count, the write-out after the barrier ranks them */
+        const bool cand2 = outcol && wr_gflag(p2.fl) == 1;
+        const unsigned long long mc = __ballot(cand2);
+        if (lane == 0) wave_cnt[par][wv] = (uint32_t)__popcll(mc);
+        lds_barrier();
+
+        /* ---- write out row r-2 (first thing after the barrier: its stores are the oldest entries of the step) ---- */
+        if (r >= 2) {
+            const int q = r - 2;
+            const int rr = q - (lo_row - 1);        /* only rows lo-1 .. N-1 can hold candidates */
+            if (rr >= 0) {
+                uint32_t before = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) {
+                    const uint32_t c = wave_cnt[par][w];
+                    if (w < wv) before += c;
+                    total += c;
+                }
+                const uint32_t seg = (uint32_t)(rr * strips + strip);
+                if (cand2) {
+                    const uint32_t rank = before + (uint32_t)__popcll(mc & ((1ull << lane) - 1ull));
+                    fcand[seg * (uint32_t)kSeg + rank] = u32x2{p2.key, p2.lo.z}; /* key | height */
+                }
+                if (tid == 2) fncand[seg] = total;
+            }
+            {   /* BEV code of a slot that is not a candidate: final, appended to this strip's list of its raster band */
+                bool has = outcol && !cand2 && p2.code != kSkip;
+                const uint32_t left_code = lane_from(sh_left1, p2.code);
+                const bool left_has = lane_from(sh_left1, has ? 1u : 0u) != 0u;
+                if (lane > 0 && left_has && left_code == p2.code) has = false;
+                if (has) {
+                    const uint32_t slot = (p2.code * 0x9E3779B1u) >> (32 - kSeenBits);
+                    if (seen[slot] == p2.code) has = false;
+                    else seen[slot] = p2.code;
+                }
+                if (has) {
+                    const int band = band_tab[code_x(p2.code)];
+                    const uint32_t pos = atomicAdd(&band_cursor[band], 1u);
+                    flist[(uint32_t)band * code_cap + pos] = p2.code;
+                }
+            }
+            {   /* the ordered cloud: a wave's 64 points leave as two whole KiB (see k_strip_ground) */
+                u32x4 hi = p2.hi;
+                const bool as_ground = cand2 && !((p2.fl >> 4) & 1u);
+                if (as_ground) hi.w &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
+                char *xb = reinterpret_cast<char *>(&ring[s0][0][64 * wv]);
+                *reinterpret_cast<u32x4 *>(xb + xp_w) = p2.lo;
+                *reinterpret_cast<u32x4 *>(xb + xp_w + 16) = hi;
+                const u32x4 pa = ring[s0][0][64 * wv + lane], pb = ring[s0][1][64 * wv + lane];
+                const unsigned long long owners = __ballot(outcol);
+                const uint32_t at = (uint32_t)(q * H + (strip * kStripCols - 2 + 64 * wv)) * 2u; /* (never dereferenced below 0) */
+                if ((owners >> (lane >> 1)) & 1ull) __builtin_nontemporal_store(pa, fordered + (at + (uint32_t)lane));
+                if ((owners >> (32 + (lane >> 1))) & 1ull) __builtin_nontemporal_store(pb, fordered + (at + 64u + (uint32_t)lane));
+                if (kGm && outcol) fgm[(uint32_t)(q * H + v)] = (int8_t)wr_gflag(p2.fl);
+            }
+        }
+        /* ---- the loads of this step, behind its stores: points of row r + 2, winner words of row r + 4 ---- */
+        {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave is done reading the slots that are refilled */
+            const uint32_t wn = winner_of(r + 2, wraw);
+            full = (full & ~(1u << s2)) | (wn != 0u ? 1u << s2 : 0u);
+            issue_points(wn, s2);
+            issue_winner(r + 4, s1);
+        }
+
+        /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
+        int s_r = kSteep;
+        if (r >= lo_row && r < N) { /* workgroup-uniform */
+            XYZI right{lane_from_f(sh_right, prev.x), lane_from_f(sh_right, prev.y), lane_from_f(sh_right, prev.z), lane_from_f(sh_right, prev.i)};
+            XYZI left{lane_from_f(sh_left, prev.x), lane_from_f(sh_left, prev.y), lane_from_f(sh_left, prev.z), lane_from_f(sh_left, prev.i)};
+            const float4(*pe)[4] = edge[(r + 2) % 3];
+            if (lane >= 62 && wv + 1 < kWaves) { const float4 q = pe[wv + 1][lane - 62]; right = XYZI{q.x, q.y, q.z, q.w}; }
+            if (lane < 2 && wv > 0) { const float4 q = pe[wv - 1][lane + 2]; left = XYZI{q.x, q.y, q.z, q.w}; }
+            if (outcol) {
+                XYZI up = prev;                                  /* (r-1, c)                  :143     */
+                if (up.i == -1.0f) up = right;                   /* (r-1, (c+2) % H)          :146-149 */
+                if (up.i == -1.0f) up = left;                    /* flat (r-1)*H + c - 2      :151-154 */
+                if (up.i == -1.0f && r >= 2) up = prevprev;      /* (r-2, c)                  :157-160 */
+                if (cur.i == -1.0f || up.i == -1.0f) s_r = kInvalid; /* :162-167 */
+                else s_r = angle_is_ground_flat(up.x - cur.x, up.y - cur.y, up.z - cur.z) ? kGround : kSteep; /* :169-182 */
+            }
+        }
+
+        /* ---- ground_mat of row r-1 is now decided (closed form, see bev_exact.h) ---- */
+        int gf = 0;
+        {
+            const int q = r - 1, st1 = wr_status(p1.fl);
+            if (q >= lo_row) gf = (st1 == kInvalid) ? -1 : (st1 == kGround ? 1 : (s_r == kGround ? 1 : 0));
+            else if (q == lo_row - 1) gf = (s_r == kGround) ? 1 : 0;
+            if (!(q >= 0 && q < N)) gf = 0;
+        }
+        const bool cand1 = outcol && gf == 1;
+        bool pred1;
+        {   /* provisional label: see k_strip_ground */
+            const float zq = __uint_as_float(p1.lo.z);
+            const bool plain = (p1.hi.w & 0xffffu) == 0xfffeu;
+            pred1 = cand1 && (!plain || zq - zref >= 0.3f); /* (the comparison is false while zref is NaN) */
+            if (cand1 && !pred1) zref = zq;
+        }
+        p1.fl = (p1.fl & 3u) | ((uint32_t)(gf + 1) << 2) | (pred1 ? 16u : 0u);
+        if (cand1) {
+            const int cell = ground_cell(__uint_as_float(p1.lo.x), __uint_as_float(p1.lo.y));
+            p1.key = candidate_key_edges(cell, tid - 2, pred1, p1.code, (int)(int16_t)(p1.hi.w & 0xffffu),
+                                         edge_x[cell / kGridCols], edge_y[cell % kGridCols]);
+        }
+
+        /* ---- row r's record (the one row r-3 has left) ---- */
+        p0.lo = cur_lo;
+        p0.hi = cur_hi;
+        p0.fl = (uint32_t)(s_r + 1) | (1u << 2);
+        p0.key = 0u;
+        p0.code = code_of(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w & 0xffffu));
+    };
+    /* two extra iterations drain the pipeline */
+    for (int r0 = 0; r0 < N + 2; r0 += 3) {
+        row_step(std::integral_constant<int, 0>{}, r0);
+        if (r0 + 1 < N + 2) row_step(std::integral_constant<int, 1>{}, r0 + 1);
+        if (r0 + 2 < N + 2) row_step(std::integral_constant<int, 2>{}, r0 + 2);
+    }
+    wait_vm<0>(); /* no LDS-DMA may outlive the workgroup's LDS */
+    lds_barrier();
+    if (tid < bands) b.ncode[((size_t)f * g.emitters + strip) * bands + tid] = band_cursor[tid];
+}
+
 /* getOrderedCloud alone (bev_order_cloud): no ground work. */
 __global__ __launch_bounds__(kGatherThreads) void k_gather_only(BatchPtrs b, Geometry g, int nf)
 {
@@ -1129,27 +1432,23 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_only(BatchPtrs b, Geo
  * the first one.  No intermediate of phase B touches HBM (round 1: the sorted heights bounced through global memory). */
 constexpr int kCells = kGridCells;
 static_assert(kPartSegs * kSeg <= 4096, "a part's run start (12 bits) and length (13 bits) share a word with room to spare");
-/* kQ = 1: one workgroup per frame, all 3750 cells (99 KB of LDS: one workgroup per CU).  kQ = 4: four workgroups per
- * frame, workgroup q has the cells with cell mod 4 == q (938 of them, 37 KB: four workgroups per CU, and room beside
- * three column-walk workgroups) and reads run q of every segment (the walk keeps a segment's candidates as four runs by
- * cell quarter).  Cells are independent and a cell lies in one quarter, so the order inside a cell is the same. */
-template <int kQ>
+/* one workgroup per frame, all 3750 cells: 99 KB of LDS.  (Round 2 also had a form with four workgroups per frame, cells
+ * by cell mod 4, 37 KB each: bit-identical, 17 % shorter alone, but its 1000 high-priority workgroups per sub-batch pushed
+ * the front stage aside — 230 k instead of 260 k frames/s — and the walk paid four ballots per row for it; removed in
+ * round 3, DESIGN.md.) */
 struct SumDims {
-    static constexpr int cells = (kCells + kQ - 1) / kQ;
+    static constexpr int cells = kCells;
     static constexpr int hist_stride = ((cells + 1) / 2 + 3) / 4 * 4; /* words per wave's histogram: two 16-bit counters per word */
     static constexpr int touch_words = (cells + 31) / 32;
     static constexpr size_t lds_bytes = sizeof(uint32_t) * ((size_t)kSumWaves * hist_stride + cells + (size_t)kPartSegs * kSeg +
                                                             2 * (size_t)cells + touch_words + (cells + 1) / 2 + 16);
 };
-size_t cell_sums_lds_bytes() { return SumDims<1>::lds_bytes; }
+size_t cell_sums_lds_bytes() { return SumDims::lds_bytes; }
 
-template <int kQ>
 __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry g, int nf)
 {
-    using D = SumDims<kQ>;
+    using D = SumDims;
     constexpr int kCellsQ = D::cells, kHistStride = D::hist_stride, kTouchWords = D::touch_words;
-    constexpr int kShift = kQ == 4 ? 2 : 0; /* cell -> index inside the quarter */
-    static_assert(kQ == 1 || kQ == 4, "quarters are cell mod 4");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *hist = lds;                                 /* [kSumWaves][kHistStride]: 16-bit counts, cells 2i | 2i+1 << 16 */
     uint32_t *start = hist + kSumWaves * kHistStride;     /* [kCellsQ]: the part's runs, start | length << 16 */
@@ -1161,12 +1460,10 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     uint32_t *misc = reinterpret_cast<uint32_t *>(tlist) + (kCellsQ + 1) / 2; /* [0..1] list lengths (by part parity), [4..7] wave sums, [8] carry */
     uint16_t *hist16 = reinterpret_cast<uint16_t *>(hist); /* the same counters, cell c of wave w at [w * 2 * kHistStride + c] */
 
-    int f = blockIdx.x, quarter = 0;
-    if (kQ > 1 && !map_block_xcd(blockIdx.x, nf, kQ, f, quarter)) return; /* the quarters of a frame on one XCD: they read the same lines */
+    const int f = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int T = g.segs, P = g.parts;
-    const uint32_t *ckey = b.cand_key + (size_t)f * T * kSeg;
-    const float *cz = b.cand_z + (size_t)f * T * kSeg;
+    const uint2 *ccand = b.cand + (size_t)f * T * kSeg; /* key | height */
     const uint32_t *fn = b.ncand + (size_t)f * T;
     constexpr int kSl = kSeg / 64;
     PH_DECL;
@@ -1181,12 +1478,9 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     }
 
     /* software pipeline: counts two parts ahead, keys + heights one part ahead */
-    auto load_counts = [&](int p) -> uint32_t { /* lane j < kSegsPerWave: count (| run start << 16) of this wave's segment j of part p */
+    auto load_counts = [&](int p) -> uint32_t { /* lane j < kSegsPerWave: count of this wave's segment j of part p */
         const int t = p * kPartSegs + wv * kSegsPerWave + lane;
-        const uint32_t w = (p < P && lane < kSegsPerWave && t < T) ? fn[t] : 0u; /* four byte-wide counts: the segment's runs */
-        if (kQ == 1) return (w & 0xffu) + ((w >> 8) & 0xffu) + ((w >> 16) & 0xffu) + (w >> 24);
-        const uint32_t sh = 8u * (uint32_t)quarter;
-        return ((w >> sh) & 0xffu) | ((((w * 0x01010100u) >> sh) & 0xffu) << 16); /* this quarter's count | where its run starts << 16 */
+        return (p < P && lane < kSegsPerWave && t < T) ? fn[t] : 0u;
     };
     uint32_t key_n[kSegsPerWave][kSl]; /* next part (raw keys; lanes past the segment's count hold garbage) */
     float z_n[kSegsPerWave][kSl];
@@ -1195,21 +1489,21 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
         const int t0 = p * kPartSegs + wv * kSegsPerWave;
 #pragma unroll
         for (int j = 0; j < kSegsPerWave; ++j) {
-            const uint32_t cw = (uint32_t)__shfl((int)counts, j);
-            n_n[j] = (int)(cw & 0xffffu);
+            n_n[j] = __shfl((int)counts, j);
             /* whole 64-slices, loaded or skipped by a WAVE-UNIFORM test, and nothing but the loads inside the test: a
              * per-lane predicated load makes the compiler branch around it and wait for the data inside the branch —
              * one round trip after the other (this loop took 4 us per part that way).  Lanes past the count read stale
              * entries of the segment (allocated memory) and are masked where the values are used. */
             const int n = __builtin_amdgcn_readfirstlane(n_n[j]);
-            const size_t at = (size_t)(t0 + j) * kSeg + (cw >> 16) + lane;
+            const size_t at = (size_t)(t0 + j) * kSeg + lane;
 #pragma unroll
             for (int k = 0; k < kSl; ++k) {
                 key_n[j][k] = 0u;
                 z_n[j][k] = 0.f;
                 if (64 * k < n) {
-                    key_n[j][k] = ckey[at + 64 * k];
-                    z_n[j][k] = cz[at + 64 * k];
+                    const uint2 kz = ccand[at + 64 * k];
+                    key_n[j][k] = kz.x;
+                    z_n[j][k] = __uint_as_float(kz.y);
                 }
             }
         }
@@ -1233,7 +1527,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
             nn[j] = n_n[j];
 #pragma unroll
             for (int k = 0; k < kSl; ++k) {
-                cell[j][k] = lane + 64 * k < nn[j] ? ((key_n[j][k] & kKeyCellMask) >> kShift) : 0xfffu; /* 0xfff: no candidate */
+                cell[j][k] = lane + 64 * k < nn[j] ? (key_n[j][k] & kKeyCellMask) : 0xfffu; /* 0xfff: no candidate */
                 zz[j][k] = z_n[j][k];
             }
         }
@@ -1394,8 +1688,7 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     PHA_PRINT("cell_sums barrier0 - scan place sum request histloop looptop", tid == 0 && blockIdx.x == 100);
     PH();
     float *avg = b.avg + (size_t)f * kCells;
-    for (int c = tid; c < kCellsQ; c += kSumThreads)
-        if (c * kQ + quarter < kCells) avg[c * kQ + quarter] = sumv[c] / cntv[c]; /* :210 */
+    for (int c = tid; c < kCellsQ; c += kSumThreads) avg[c] = sumv[c] / cntv[c]; /* :210 */
     PH_PRINT("cell_sums all-parts", tid == 0 && blockIdx.x == 100);
 }
 
@@ -1452,8 +1745,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
     const int T = g.segs;
     const int t0 = (int)((long long)T * part / kResolveParts), t1 = (int)((long long)T * (part + 1) / kResolveParts);
     for (int i = tid; i < t1 - t0; i += kResolveThreads) {
-        const uint32_t w = b.ncand[(size_t)f * T + t0 + i]; /* four byte-wide counts (the segment's runs by cell quarter) */
-        cnt[i] = (uint16_t)((w & 0xffu) + ((w >> 8) & 0xffu) + ((w >> 16) & 0xffu) + (w >> 24));
+        cnt[i] = (uint16_t)b.ncand[(size_t)f * T + t0 + i];
     }
     for (int c = tid; c < kCells; c += kResolveThreads) avg[c] = b.avg[(size_t)f * kCells + c];
     if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
@@ -1465,8 +1757,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
     constexpr int kSl = kSeg / 64;
     constexpr int kWaves = kResolveThreads / 64;
     const int bands = g.raster_bands, lo_row = g.N - g.G;
-    const uint32_t *fkey = b.cand_key + (size_t)f * T * kSeg;
-    const float *fz = b.cand_z + (size_t)f * T * kSeg;
+    const uint2 *fcand = b.cand + (size_t)f * T * kSeg; /* key | height */
     uint32_t *flist = b.code_main + ((size_t)f * g.emitters + g.strips + part) * bands * (size_t)g.code_cap;
     for (int s0 = t0 + wv; s0 < t1; s0 += kWaves * kResolveBatch) {
         uint32_t key[kResolveBatch][kSl];
@@ -1481,8 +1772,9 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
                 key[j][k] = 0u;
                 z[j][k] = 0.f;
                 if (64 * k < __builtin_amdgcn_readfirstlane(n)) {
-                    key[j][k] = fkey[at];
-                    z[j][k] = fz[at];
+                    const uint2 kz = fcand[at];
+                    key[j][k] = kz.x;
+                    z[j][k] = __uint_as_float(kz.y);
                 }
             }
         }
@@ -1876,8 +2168,8 @@ __global__ __launch_bounds__(256) void k_angle_debug(const float *dx, const floa
 /* launchers                                                                  */
 hipError_t configure_kernels(const Geometry &g)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cell_sums<1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SumDims<1>::lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cell_sums),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SumDims::lds_bytes);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)raster_lds_bytes(g));
@@ -1893,19 +2185,24 @@ void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t m
     hipLaunchKernelGGL(k_order_scan, grid, dim3(256), 0, st, b.pts, b.frames, b.info, pass, b.winner, g.N, g.H, g.S,
                        b.win_tag << b.win_shift);
 }
+template <int kSrc>
+static void launch_walk(const Geometry &g, const BatchPtrs &b, int nf, uint32_t mode, int grid, hipStream_t st)
+{
+    const bool pow2 = g.rp.inv_interval != 0.0f && g.rp.inv_height_res != 0.0f; /* every configuration of the reference */
+    const dim3 gr(grid), bl(kStripThreads);
+    if (pow2 && !b.gm) hipLaunchKernelGGL((k_walk<kSrc, true, false>), gr, bl, 0, st, b, g, nf, mode);
+    else if (pow2) hipLaunchKernelGGL((k_walk<kSrc, true, true>), gr, bl, 0, st, b, g, nf, mode);
+    else if (!b.gm) hipLaunchKernelGGL((k_walk<kSrc, false, false>), gr, bl, 0, st, b, g, nf, mode);
+    else hipLaunchKernelGGL((k_walk<kSrc, false, true>), gr, bl, 0, st, b, g, nf, mode);
+}
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int source, uint32_t mode, hipStream_t st)
 {
     if (nf == 0) return;
     const int grid = xcd_grid(nf, g.strips);
-    /* experiment knob: BEV_WALK_PAD = bytes of dynamic LDS a walk workgroup asks for on top of its own (never touched):
-     * caps the walk workgroups per CU, so that the other stream's kernels find registers and LDS beside them */
-    static const unsigned pad = [] { const char *e = getenv("BEV_WALK_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
-    if (source == kSrcIdentity)
-        hipLaunchKernelGGL(k_strip_ground<kSrcIdentity>, dim3(grid), dim3(kStripThreads), pad, st, b, g, nf, mode);
+    if (source == kSrcIdentity) launch_walk<kSrcIdentity>(g, b, nf, mode, grid, st);
     else if (source == kSrcStream)
-        hipLaunchKernelGGL(k_strip_ground<kSrcStream>, dim3(grid), dim3(kStripThreads), pad, st, b, g, nf, mode);
-    else
-        hipLaunchKernelGGL(k_strip_ground<kSrcGather>, dim3(grid), dim3(kStripThreads), pad, st, b, g, nf, mode);
+        hipLaunchKernelGGL(k_strip_ground<kSrcStream>, dim3(grid), dim3(kStripThreads), 0, st, b, g, nf, mode);
+    else launch_walk<kSrcGather>(g, b, nf, mode, grid, st);
 }
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st)
 {
@@ -1922,13 +2219,10 @@ void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream
     if (nf == 0) return;
     hipLaunchKernelGGL(k_gather_only, dim3(xcd_grid(nf, g.tiles)), dim3(kGatherThreads), 0, st, b, g, nf);
 }
-void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, bool quarters, hipStream_t st)
+void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {
     if (nf == 0) return;
-    if (quarters)
-        hipLaunchKernelGGL(k_cell_sums<4>, dim3(xcd_grid(nf, 4)), dim3(kSumThreads), SumDims<4>::lds_bytes, st, b, g, nf);
-    else
-        hipLaunchKernelGGL(k_cell_sums<1>, dim3(nf), dim3(kSumThreads), SumDims<1>::lds_bytes, st, b, g, nf);
+    hipLaunchKernelGGL(k_cell_sums, dim3(nf), dim3(kSumThreads), SumDims::lds_bytes, st, b, g, nf);
 }
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st)
 {
