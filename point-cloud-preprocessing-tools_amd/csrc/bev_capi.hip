@@ -135,7 +135,7 @@ struct bev_ctx {
     int n_lanes = 1;
     int n_lanes_active = 1; /* <= n_lanes; bev_set_lanes */
     bool staged = true;     /* two-stage pipeline, see run_pipeline; BEV_STAGED=0 falls back to free-running lanes */
-    bool allow_stream = false; /* BEV_STREAM=1: sorted-prefix frames are read in place (k_probe), see bev_create */
+    bool allow_stream = true;  /* sorted-prefix frames are read in place (k_probe); BEV_STREAM=0 turns it off, see bev_create */
     hipEvent_t fork_ev = nullptr;
     hipEvent_t stagger_ev = nullptr; /* recorded on a lane after its bandwidth-bound kernels */
     bool staggered[kMaxLanes] = {false, false, false, false};
@@ -672,12 +672,13 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         int nl = e ? atoi(e) : 2;
         c->n_lanes = std::max(1, std::min(kMaxLanes, nl));
         c->n_lanes_active = c->n_lanes;
-        /* Reading sorted frames in place is complete and verified (tests/test_gpu_stream.py) and saves 5.6 MB of HBM
-         * traffic per frame, but it is a wash: its walk is bound by instruction issue and its latency chain, not by
-         * memory, and three of its workgroups fill a CU's LDS, so the back end overlaps worse than beside order scan +
-         * gather walk (+4 % on the pool's slow boxes, -5 ... -10 % on the fast ones); opt-in. */
+        /* Frames whose points are in slot order up to a tail (what the selectors write) are read in place: no order
+         * scan, no winner table, 5.6 MB less HBM traffic per HDL_64E frame.  k_probe decides per frame, the walk
+         * verifies every point it consumes, a frame that fails is redone the general way: results never depend on the
+         * mode.  Since round 3 (LDS-DMA windows, four workgroups per CU) ahead of the general path on every box measured
+         * (+3 ... +7 % frames/s, same-box A/B); BEV_STREAM=0 forces the general path for every frame. */
         const char *sm = getenv("BEV_STREAM");
-        c->allow_stream = sm && atoi(sm) != 0;
+        c->allow_stream = !(sm && atoi(sm) == 0);
         const char *sg = getenv("BEV_STAGED");
         c->staged = (!sg || atoi(sg) != 0) && c->n_lanes >= 2;
     }
@@ -702,7 +703,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipMemset(ln.info, 0, nb * sizeof(FrameInfo)));
         CK(hipMalloc((void **)&ln.est, nb * (size_t)c->geo.N * c->geo.strips * sizeof(uint32_t)));
         if (c->allow_stream && c->geo.N <= kStreamMaxRows && c->geo.N * c->geo.strips <= kTailBuckets) {
-            CK(hipMalloc((void **)&ln.tail_list, nb * (size_t)c->geo.N * c->geo.strips * kTailCap * sizeof(uint32_t)));
+            CK(hipMalloc((void **)&ln.tail_list, (nb * (size_t)c->geo.N * c->geo.strips * kTailCap + 64) * sizeof(uint32_t))); /* (+ 64: the walk fetches 64 words per list) */
             CK(hipMalloc((void **)&ln.tail_cnt, nb * (size_t)c->geo.N * c->geo.strips * sizeof(uint32_t)));
         }
         CK(hipMalloc((void **)&ln.winner, nb * S * sizeof(uint32_t)));

@@ -61,10 +61,10 @@ constexpr int kProbeStride = 127;   /* k_probe looks at every 127th point (odd: 
 constexpr int kMaxSamples = 8192;   /* => stream mode for frames of up to 2^20 points; longer ones go the general way */
 constexpr int kStreamSlack = 16;    /* positions a (row, strip) window starts before / ends after the estimate */
 constexpr int kStreamMinPrefix = 2048;
-constexpr int kTailCap = 64;         /* tail points (those after the sorted prefix) a (row, strip) can list; more: general way */
+constexpr int kTailCap = 48;         /* tail points (those after the sorted prefix) a (row, strip) can list; more: general way */
 constexpr int kTailMax = 16384;     /* ... a frame can have */
 constexpr int kTailBuckets = 2048;  /* (row, strip) pairs of a frame that k_probe can count in LDS */
-constexpr int kStreamMaxRows = 128;  /* sensors with more rows go the general way (the stream walk keeps per-row estimates in LDS) */
+constexpr int kStreamMaxRows = 64;   /* sensors with more rows go the general way (the stream walk keeps per-row estimates in LDS) */
 
 /* Workspace streams between the kernels of one sub-batch (see bev_exact.h for the candidate key):
  *   cand uint2 (key | height)  [nf][segs][kSeg]   candidates, one segment per (row, strip), compacted in column order;

@@ -117,44 +117,6 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-/* Loads the compiler does not see, and the counted waits that go with them (stream source of the column walk).
- * gfx950 retires loads in order among loads (and stores among stores) but counts both on vmcnt, so hipcc, which
- * cannot tell how many of the pending operations are stores, waits for ALL of them (vmcnt(0)) before a loaded register
- * is used in a loop that also stores — a software pipeline is drained once per iteration.  The sound rule is weaker: a
- * load has completed once at most as many operations are outstanding as LOADS were issued after it (stores only make
- * that wait longer, never wrong).  glds16 is an LDS-DMA load (global_load_lds_dwordx4): every lane gives its own source
- * address, the 64 x 16 bytes land at a wave-uniform LDS address + lane * 16, no VGPR is involved, and it counts on
- * vmcnt like any load (scripts/microbench/glds_test.hip checks both on the box). */
-__device__ __forceinline__ uint32_t lds_addr(const void *p)
-{
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
-}
-__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
-{
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void ld128(u32x4 &dst, const void *p)
-{
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
-}
-__device__ __forceinline__ void ld128_16(u32x4 &dst, const void *p) /* bytes 16 .. 31 of *p */
-{
-    asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(dst) : "v"(p));
-}
-__device__ __forceinline__ void ld32_nt(uint32_t &dst, const void *p)
-{
-    asm volatile("global_load_dword %0, %1, off nt" : "=v"(dst) : "v"(p));
-}
-/* all but the N newest memory operations have completed; the registers named are released by this wait: their uses
- * cannot be scheduled above it */
-template <int N>
-__device__ __forceinline__ void wait_loads(u32x4 &a, u32x4 &b, uint32_t &c)
-{
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
-}
-
 /* A winner entry is (tag << shift) | (input index + 1).  The tag is the sub-batch generation of the workspace set:
  * entries left by earlier sub-batches carry a smaller tag, lose every atomicMax against the current one and read as
  * "empty", so the table needs no memset between sub-batches (bev_capi.hip clears it when the tag would wrap). */
@@ -433,662 +395,68 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
 }
 
 /* ------------------------------------------------------------------------- */
-template <bool kIdentity>
-struct SlotFetch {
-    const uint32_t *win;      /* frame's winner table (unused in identity mode) */
-    const bev_point_t *pts;   /* frame's input points, or the ordered cloud itself */
-    __device__ __forceinline__ XYZI operator()(long long flat) const
-    {
-        long long idx = flat;
-        if (!kIdentity) {
-            const uint32_t w = win[flat];
-            if (w == 0u) return XYZI{0.f, 0.f, 0.f, 0.f}; /* untouched slot: value-initialised, :98 */
-            idx = (long long)w - 1;
-        }
-        const float4 a = *reinterpret_cast<const float4 *>(pts + idx);
-        const float it = reinterpret_cast<const float *>(pts + idx)[4];
-        return XYZI{a.x, a.y, a.z, it};
-    }
-};
-
-/* ------------------------------------------------------------------------- */
 /* getOrderedCloud gather + markGroundPoints phase A, as a COLUMN WALK.
  *
- * A workgroup owns kStripCols (252) adjacent columns of one frame plus two halo
- * columns on each side (256 threads) and walks the rows 0 .. N-1.  Thread tid
- * sits on virtual column v = strip*252 + tid - 2 and, in row r, on flat slot
- * index r*H + v (v >= H wraps to v - H in the SAME row, v < 0 is the flat index
- * r*H + v, i.e. the tail of row r-1 — exactly the two index rules of
- * BatchMultiBevGen.cpp:146-154).  Consequences:
- *   - every input point is loaded exactly once (winner -> point), rows arrive as
- *     8 KiB coalesced pieces, the next row's loads are issued a row ahead;
- *   - the phase-A stencil needs no second pass: "upper" is the thread's own
- *     previous row (registers), its +-2 fallbacks are the neighbours' previous
- *     rows (wave shuffles, LDS only across wave edges), row-2 is the thread's
+ * A workgroup owns kStripCols (252) adjacent columns of one frame plus two halo columns on each side (256 threads) and
+ * walks the rows 0 .. N-1.  Thread tid sits on virtual column v = strip*252 + tid - 2 and, in row r, on flat slot
+ * index r*H + v (v >= H wraps to v - H in the SAME row, v < 0 is the flat index r*H + v, i.e. the tail of row r-1 —
+ * exactly the two index rules of BatchMultiBevGen.cpp:146-154).  Consequences:
+ *   - every input point is loaded exactly once, rows arrive as 8 KiB coalesced pieces, two rows ahead;
+ *   - the phase-A stencil needs no second pass: "upper" is the thread's own previous row (registers), its +-2
+ *     fallbacks are the neighbours' previous rows (wave shuffles, LDS only across wave edges), row-2 is the thread's
  *     own row before that;
- *   - status s[r] is evaluated ONCE per slot; ground_mat(r-1) follows from
- *     s[r-1] and s[r] (closed form in bev_exact.h), so row r-1 is finished while
- *     row r is being evaluated, and row r-2 is written out (one barrier per row
- *     covers both the LDS row buffer and the candidate counts).
- * Candidates of one (row, strip) are compacted in column order into their own
- * segment; segments enumerate (row, strip) in row-major order, so the
- * concatenation of all segments is slot order — what phase B's accumulation
- * order needs. */
-struct PendingRow {
-    Half lo, hi;
-    uint32_t code;
-    int status;      /* s[row] (kInvalid / kSteep / kGround); kSteep for rows that are not tested */
-    int gflag;       /* ground_mat(row) at the end of phase A */
-    bool pred;       /* candidate the walk expects phase C to un-ground (see "provisional labels" below) */
-    uint32_t key;    /* candidate key (bev_exact.h), valid when gflag == 1 */
-};
-
-/* Narrow workspace streams (candidate keys / heights, code lists) are written with the default cache policy: a row's
- * pieces from the four waves are contiguous, so L2 merges them into whole lines before they leave (with `nt` every
- * piece left as partial lines: the walk wrote 6.5 MB per frame where 5.8 MB were needed).  The ordered cloud's stores
- * (whole 1 KiB pieces of a wave's 2 KiB row, see the write-out below) keep `nt`: with the default policy the pipeline is
- * 4-6 % slower. */
-template <class T>
-__device__ __forceinline__ void store_ws(T *p, T v) { *p = v; }
-
-enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcStream = 2 };
-/* Gives a wave-uniform value a scalar register of its own.  Kernel arguments arrive as 8-register tuples; the walk keeps
- * more uniform values alive than there are scalar registers, and the compiler spills and restores whole tuples (through
- * lanes of a vector register, one VALU instruction per dword): the raster constants came back eight at a time around
- * every use (a third of the STATIC vector instructions of the row loop; executed, about 1 %). */
-template <class T>
-__device__ __forceinline__ T own_sgpr(T v)
-{
-    asm volatile("" : "+s"(v));
-    return v;
-}
-template <int kSrc>
-__global__ __launch_bounds__(kStripThreads, kSrc == kSrcStream ? 3 : 4) void k_strip_ground(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
-{
-    constexpr bool kIdentity = kSrc == kSrcIdentity, kStream = kSrc == kSrcStream;
-    /* the strips of a frame share halo columns and the lines at their seams: one XCD (one L2) per frame */
-    int f, strip;
-    if (!map_block_xcd(blockIdx.x, nf, g.strips, f, strip)) return;
-    if (!kIdentity && b.info && b.info[f].mode != want_mode) return; /* another launch of this kernel has the frame */
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = own_sgpr(g.N), H = own_sgpr(g.H), lo_row = own_sgpr(g.N - g.G);
-    const size_t frame_off = (size_t)f * g.S;
-    const int bands = g.raster_bands;
-
-    /* lanes two to the right / left (wrapping inside the wave; the edge lanes are patched from LDS), one to the left */
-    const int sh_right = ((lane + 2) & 63) << 2, sh_left = ((lane - 2) & 63) << 2, sh_left1 = ((lane - 1) & 63) << 2;
-    auto lane_from = [&](int sel, uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)x); };
-    auto lane_from_f = [&](int sel, float x) -> float { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)__float_as_uint(x))); };
-    const int v = strip * kStripCols + tid - 2;                      /* virtual column */
-    const bool provider = (v < H + 2) && (v >= 0 || strip == 0);     /* has a point to load */
-    const bool outcol = tid >= 2 && tid < 2 + kStripCols && v < H;   /* owns column v's outputs */
-    const int vcol = v >= H ? v - H : v;                             /* wrap; v < 0 keeps the flat rule */
-    /* stream source: (row | col << 16) of the thread's slot in row 0 (the tail of row -1 for strip 0's left halo: never
-     * there; column 0xffff for threads without a slot: never there either) */
-    const uint32_t slot_rc = !provider ? 0xffff0000u : (v < 0 ? ((uint32_t)(H + v) << 16) + 0xffffffffu : (uint32_t)vcol << 16);
-
-    const bev_point_t *fpts = kIdentity ? (b.pts + frame_off) : (b.pts + b.frames[f].in_offset);
-    const uint32_t *fwin = b.winner + frame_off;
-
-    /* Neighbour exchange: lanes l+-2 of the same wave are reached with shuffles; only the two edge
-     * lanes on each side of a wave go through LDS (768 B instead of a 12 KiB row buffer, so that these
-     * workgroups can share a CU with the back end's workgroups of the other lane). */
-    constexpr int kWaves = kStripThreads / 64;
-    __shared__ float4 edge[3][kWaves][4];                  /* rows r, r-1, (r-2): lanes 0, 1, 62, 63 of every wave */
-    __shared__ u32x4 xpose[kWaves][128];                   /* a wave's 64 finished points, to be stored as two whole KiB */
-    __shared__ uint32_t wave_cnt[2][kWaves];               /* per-wave candidate counts of the row being written */
-    __shared__ uint32_t band_cursor[kMaxBands];            /* entries already in this strip's code list of each band */
-    __shared__ uint8_t band_tab[512];                      /* x bin -> raster band */
-    constexpr int kSeenB = kStream ? kSeenBits - 1 : kSeenBits; /* (the stream source needs the LDS for its row buffers) */
-    __shared__ uint32_t seen[1 << kSeenB];                 /* direct-mapped memo of codes this strip has already listed */
-    __shared__ int edge_x[kGridRows], edge_y[kGridCols];   /* BEV bin of every ground-grid row's / column's lower edge */
-    /* stream source (see below): three rows of points by column offset, the first wave's extra window positions, the
-     * second wave's tail points, the estimates and tail counts of every row */
-    __shared__ u32x4 rowbuf[3][2][kStream ? kStripThreads : 1];
-    __shared__ u32x4 xwin[kStream ? 2 : 1][2][kStream ? 64 : 1];
-    __shared__ u32x4 twin[kStream ? 2 : 1][2][kStream ? 64 : 1];
-    __shared__ uint32_t lastrc[kStream ? 2 : 1][kStripThreads / 64];
-    __shared__ int est_l[2][kStream ? kStreamMaxRows : 1];
-    __shared__ uint32_t tcnt_l[kStream ? kStreamMaxRows : 1];
-    if (tid < kMaxBands) band_cursor[tid] = 0u;
-    for (int k = tid; k < (1 << kSeenB); k += kStripThreads) seen[k] = kSkip;
-    for (int x = tid; x < g.rp.mat_size; x += kStripThreads) band_tab[x] = (uint8_t)raster_band_of(x, g.rp);
-    if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
-    else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
-    if (kStream) {
-        /* no entry of the row buffers may look like a point of the slot it stands for: row 0xffff does not exist */
-        for (int k = 0; k < 3; ++k) rowbuf[k][1][tid] = u32x4{0u, 0xffffffffu, 0u, 0u};
-        /* estimates and tail counts into LDS once: a global load the compiler sees inside the row loop would bring back
-         * the vmcnt(0) that the counted waits below are there to avoid */
-        const uint32_t *fe = b.est + (size_t)f * N * g.strips;
-        const uint32_t *fc = b.tail_cnt + (size_t)f * N * g.strips;
-        for (int r = tid; r < N; r += kStripThreads) {
-            est_l[0][r] = (int)fe[r * g.strips + strip];
-            est_l[1][r] = (int)fe[r * g.strips];
-            tcnt_l[r] = fc[r * g.strips + strip];
-        }
-    }
-
-    /* Winner words are loaded UNCONDITIONALLY from a clamped address and decoded only when they are used, two rows
-     * later: a predicated load whose result is decoded on the spot makes the compiler branch around the load and wait
-     * for it — with vmcnt(0), i.e. for every point load in flight as well — inside the branch, once per row (that was
-     * the shape of this loop in round 1: the software pipeline below existed on paper only). */
-    auto has_slot = [&](int r) -> bool { return provider && r < N && r * H + vcol >= 0; };
-    auto load_winner_raw = [&](int r, uint32_t &raw) {
-        raw = 0u;
-        if (kIdentity || kStream) return; /* the stream source has no winner table */
-        const int fl = has_slot(r) ? r * H + vcol : 0;
-        raw = load_once(&fwin[fl]);
-    };
-    auto winner_of = [&](int r, uint32_t raw) -> uint32_t { /* input index + 1 of slot (r, this column), 0 = empty */
-        if (!has_slot(r)) return 0u;
-        if (kIdentity) return (uint32_t)(r * H + vcol) + 1u;
-        return winner_index(raw, b.win_tag, b.win_shift);
-    };
-
-    /* the same for the points: an empty slot loads a dummy (the first point of this frame's OUTPUT, always allocated,
-     * one cached line) and is zeroed when the row is consumed, so that every iteration issues exactly three loads and
-     * the compiler can wait for "all but the last six" instead of for everything */
-    const Half *dummy = reinterpret_cast<const Half *>(b.ordered + frame_off);
-    auto load_point = [&](uint32_t w, u32x4 &lo, u32x4 &hi) {
-        if (kStream) return; /* window positions instead: issue_P below */
-        const Half *src = w != 0u ? reinterpret_cast<const Half *>(fpts + (w - 1u)) : dummy;
-        lo = *reinterpret_cast<const u32x4 *>(src);
-        hi = *reinterpret_cast<const u32x4 *>(src + 1);
-    };
-
-    /* software pipeline: while row r is handled, the points of rows r+1 .. r+kDepth and the raw winner words of the
-     * kDepth rows after those are in flight.  gfx950 counts loads and stores on ONE counter (vmcnt) and they complete
-     * out of order with respect to each other, so with stores pending the compiler waits for "everything" before a
-     * loaded value is used; what the second stage still buys is that row r+2's loads are issued before row r's stores.
-     * The stages live in small arrays indexed by r mod 3 / r mod 2 and the row loop is unrolled with compile-time
-     * indices: rotating the stages through variables instead ("next = next2") makes the compiler copy registers that a
-     * load is still writing, and wait for that load — the newest one — every row. */
-    constexpr int kDepth = 2;
-    u32x4 plo[3], phi[3];  /* point of row r at [r % 3] */
-    bool pfull[3];         /* the slot of that row holds a point (else: the dummy was loaded) */
-    uint32_t wraw[2];      /* raw winner word of row r at [r % 2] */
-    plo[0] = plo[1] = plo[2] = phi[0] = phi[1] = phi[2] = u32x4{0u, 0u, 0u, 0u};
-    {
-        uint32_t r0, r1;
-        load_winner_raw(0, r0);
-        load_winner_raw(1, r1);
-        load_winner_raw(2, wraw[0]);
-        load_winner_raw(3, wraw[1]);
-        const uint32_t w0 = winner_of(0, r0), w1 = winner_of(1, r1);
-        pfull[0] = w0 != 0u;
-        pfull[1] = w1 != 0u;
-        pfull[2] = false;
-        load_point(w0, plo[0], phi[0]);
-        load_point(w1, plo[1], phi[1]);
-    }
-
-    /* ---- stream source (k_probe took the first T input points for sorted, and listed the rest per (row, strip)) ----
-     * Row rho's points of this strip's 256 virtual columns are consecutive in the input; they start near
-     * est[rho][strip] (interpolated from sampled points).  Every thread owns ONE window position (est - slack + tid; the
-     * first wave also the window's last 32 positions and, for the last strip's two wrap-around halo columns, 32
-     * positions at the row's start), loads it coalesced and in place four steps before the row is needed, looks at the
-     * (row, col) the point carries and, two steps later, drops the point into the row buffer at its column offset.
-     * The tail points of the (row, strip) — at most kTailCap, listed by k_probe, none shadowed by a later one — follow
-     * one step later through the second wave, so that they overwrite prefix points of the same slot as the reference's
-     * scatter would.  One step after that the owner of each column reads its slot from the row buffer; an entry whose
-     * (row, col) is not the slot's own is an empty slot.  Steps are separated by the row barrier, three row buffers
-     * rotate, nothing but LDS is shared.
-     * Verification (results must not depend on the estimate): a position that holds a point of the strip's OWN columns
-     * counts it and checks that the position before it lies in the prefix and has a smaller slot (across wave edges
-     * one step later, through LDS).  When all T prefix points of a frame have been counted exactly once and no check has
-     * failed, the prefix is strictly ascending, every point was where its strip looked, and the result is what
-     * getOrderedCloud's scatter gives; otherwise k_verdict sends the frame through the general kernels again.
-     * Loads are asm / LDS-DMA, issued one step (the position loads: two steps) before they are used and waited for with
-     * ONE s_waitcnt vmcnt(0) at the top of a step — where the row's stores, issued right after the previous barrier, have
-     * had a whole step to complete as well.  (Counting — vmcnt(2), "all but the newest two" — measured the same.)  What
-     * matters is that the compiler never sees these loads: a load it sees in a loop that also stores is waited for with
-     * vmcnt(0) wherever its result is first touched, i.e. in the middle of the step. */
-    const uint32_t T = kStream ? b.info[f].T : 0u;
-    const bool last_strip = strip == g.strips - 1;
-    uint32_t consumed = 0u, failed = 0u;
-    const int first_col = strip * kStripCols - 2; /* virtual column of offset 0 */
-    /* tail entry of this lane, rows rho at [rho % 3]: te as the asm load delivers it (written by nothing else: a register
-     * that a load is still filling must not be redefined on one side of a branch — the compiler merges the two
-     * definitions through a copy, and a copy made while the load is in flight carries the stale word), ts after the
-     * second wave has settled it */
-    uint32_t te[3] = {0u, 0u, 0u}, ts[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
-    bool dneed = false;                           /* lane 0: the check against the previous wave's last position is due */
-    int dflat = 0;
-    const uint32_t *ftail = kStream ? b.tail_list + ((size_t)f * N * g.strips + strip) * kTailCap : nullptr;
-    const int tail_stride = g.strips * kTailCap;  /* words from one row's list to the next */
-    auto clamp_row = [&](int rho) -> int { return rho < N ? rho : N - 1; };
-    auto issue_P = [&](auto STG, int rho) { /* the thread's window position of row rho */
-        constexpr int sg = decltype(STG)::value;
-        const int q = est_l[0][clamp_row(rho)] - kStreamSlack + tid;
-        const Half *src = reinterpret_cast<const Half *>(fpts + (q >= 0 && q < (int)T ? q : 0));
-        ld128(plo[sg], src);
-        ld128_16(phi[sg], src);
-    };
-    auto issue_X = [&](int rho) { /* first wave: lanes 0 .. 31 positions 256 .. 287, lanes 32 .. 63 the row's first positions */
-        const int rc = clamp_row(rho);
-        const int q = lane < 32 ? est_l[0][rc] - kStreamSlack + kStripThreads + lane : est_l[1][rc] - (kStreamSlack - 2) + (lane - 32);
-        const Half *src = reinterpret_cast<const Half *>(fpts + (q >= 0 && q < (int)T ? q : 0));
-        glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(&xwin[rho & 1][0][0])));
-        glds16(src + 1, __builtin_amdgcn_readfirstlane(lds_addr(&xwin[rho & 1][1][0])));
-    };
-    auto issue_TE = [&](auto STG, int rho) { /* second wave: this lane's entry of the row's tail list (stale past the count) */
-        constexpr int sg = decltype(STG)::value;
-        ld32_nt(te[sg], ftail + (size_t)clamp_row(rho) * tail_stride + lane);
-    };
-    /* second wave: which of row rho's listed tail points are the last of their slot (getOrderedCloud's scatter keeps the
-     * last writer, BatchMultiBevGen.cpp:112).  Every entry counts itself in at its column offset (256 LDS counters in
-     * the buffer the row's tail points are about to be loaded into: it is idle right now); only when some offset has
-     * been taken twice — a few times per frame — those entries are compared with the others of their offset.  Entries
-     * that lose, and lanes past the list's count, become 0xffffffff. */
-    auto settle = [&](auto STG, int rho) {
-        constexpr int sg = decltype(STG)::value;
-        const bool on = rho < N && (uint32_t)lane < tcnt_l[clamp_row(rho)];
-        const uint32_t e = te[sg];
-        const uint32_t off = e & 0xffu, idx = e >> 8;
-        uint32_t *cnt = reinterpret_cast<uint32_t *>(&twin[rho & 1][0][0]); /* [256] */
-        twin[rho & 1][0][lane] = u32x4{0u, 0u, 0u, 0u};
-        const uint32_t before = on ? atomicAdd(&cnt[off], 1u) : 0u; /* (LDS operations of one wave execute in order) */
-        bool dead = !on;
-        unsigned long long crowd = __ballot(before != 0u);
-        while (crowd) { /* wave-uniform */
-            const int j = __ffsll((long long)crowd) - 1;
-            crowd &= crowd - 1ull;
-            const uint32_t ej = (uint32_t)__builtin_amdgcn_readlane((int)e, j);
-            const bool same = on && (ej & 0xffu) == off;
-            if (same && (ej >> 8) > idx) dead = true;                          /* lane j's point comes later than this one */
-            if (__ballot(same && idx > (ej >> 8)) != 0ull && lane == j) dead = true; /* ... or some other after lane j's */
-        }
-        ts[sg] = dead ? 0xffffffffu : e;
-    };
-    auto issue_TP = [&](auto STG, int rho) { /* second wave: the (settled) tail points of row rho, by LDS-DMA */
-        constexpr int sg = decltype(STG)::value;
-        const bool on = ts[sg] != 0xffffffffu;
-        const Half *src = reinterpret_cast<const Half *>(fpts + (on ? (ts[sg] >> 8) : 0u));
-        glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(&twin[rho & 1][0][0])));
-        glds16(src + 1, __builtin_amdgcn_readfirstlane(lds_addr(&twin[rho & 1][1][0])));
-    };
-    /* one window position: into the row buffer, counted and checked.  `sflat` is the position's slot, or INT_MAX when the
-     * position is outside the prefix or its point outside the range image (such a predecessor fails every check) */
-    const int own_cols = (H - first_col - 2) < kStripCols ? (H - first_col - 2) : kStripCols; /* own columns of this strip */
-    const int row_span = (H - first_col) < kStripThreads ? (H - first_col) : kStripThreads;  /* offsets that belong to the row */
-    auto slot_or_max = [&](int q, uint32_t rcw) -> int {
-        const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
-        const bool valid = (unsigned)q < T && row < (uint32_t)N && col < (uint32_t)H;
-        return valid ? (int)row * H + (int)col : 0x7fffffff;
-    };
-    auto place = [&](int rho, int q, const u32x4 &lo, const u32x4 &hi, bool first_of_group, int dwave) {
-        const int sflat = slot_or_max(q, hi.y);
-        const int off = (int)((uint32_t)sflat - (uint32_t)(rho * H + first_col));
-        /* (a window of the last strip runs into the next row: those points are not this row's wrap-around halo) */
-        const bool inr = (unsigned)off < (unsigned)row_span;
-        if (inr) {
-            rowbuf[rho % 3][0][off] = lo;
-            rowbuf[rho % 3][1][off] = hi;
-        }
-        const bool own = (unsigned)(off - 2) < (unsigned)own_cols;
-        consumed += own ? 1u : 0u;
-        /* its predecessor in the input must lie in the prefix and have a smaller slot */
-        const bool pok = (int)lane_from(sh_left1, (uint32_t)sflat) < sflat;
-        /* (straight-line: `if (a) failed = 1; else dflat = flat;` becomes a store through a selected pointer, and the
-         * variables stay in scratch memory — a load the compiler waits for with vmcnt(0) every step) */
-        const bool chk = own && q > 0;
-        const bool bad = chk && (first_of_group ? dwave < 0 /* window position 0: the estimate was too high */ : !pok);
-        const bool defer = chk && first_of_group && dwave >= 0;
-        failed |= bad ? 1u : 0u;
-        dneed = dneed | defer;
-        dflat = defer ? sflat : dflat;
-    };
-    auto scatter = [&](auto STG, int rho) { /* the prefix positions of row rho -> row buffer */
-        constexpr int sg = decltype(STG)::value;
-        /* last step's open check: the lane's point against the last position of the wave before */
-        {
-            const int pflat = (int)lastrc[(rho - 1) & 1][wv == 0 ? kStripThreads / 64 - 1 : wv - 1];
-            failed |= (dneed && !(pflat < dflat)) ? 1u : 0u;
-            dneed = false;
-        }
-        if (rho >= N) return;
-        const int est = est_l[0][rho];
-        {
-            const int q = est - kStreamSlack + tid;
-            if (lane == 63) lastrc[rho & 1][wv] = (uint32_t)slot_or_max(q, phi[sg].y);
-            place(rho, q, plo[sg], phi[sg], lane == 0, wv == 0 ? -1 : wv - 1); /* lane 0 of a later wave: checked one step later */
-        }
-        if (wv == 0) { /* wave-uniform */
-            const u32x4 xl = xwin[rho & 1][0][lane], xh = xwin[rho & 1][1][lane];
-            if (lane < 32) {
-                /* positions 256 .. 287; lane 0 follows the last wave's last position */
-                place(rho, est - kStreamSlack + kStripThreads + lane, xl, xh, lane == 0, kStripThreads / 64 - 1);
-            } else if (last_strip) { /* slots rho*H and rho*H + 1 as the wrap-around halo columns H, H + 1 */
-                const int q = est_l[1][rho] - (kStreamSlack - 2) + (lane - 32);
-                const uint32_t rcw = xh.y;
-                const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
-                const int off = H + (int)col - first_col;
-                if (q >= 0 && q < (int)T && row == (uint32_t)rho && col < 2u && (unsigned)off < (unsigned)kStripThreads) {
-                    rowbuf[rho % 3][0][off] = xl;
-                    rowbuf[rho % 3][1][off] = xh;
-                }
-            }
-        }
-    };
-    auto tail_scatter = [&](auto STG, int rho) { /* second wave: the listed tail points of row rho over the prefix's */
-        constexpr int sg = decltype(STG)::value;
-        if (rho >= N) return;
-        if (ts[sg] != 0xffffffffu) {
-            const int off = (int)(ts[sg] & 0xffu);
-            rowbuf[rho % 3][0][off] = twin[rho & 1][0][lane];
-            rowbuf[rho % 3][1][off] = twin[rho & 1][1][lane];
-        }
-    };
-    if (kStream) { /* prologue: rows 0 and 1 placed, row 0's tail over them; the steady state's loads under way */
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>;
-        lds_barrier(); /* est_l, tcnt_l, row buffers */
-        issue_P(I0{}, 0);
-        issue_P(I1{}, 1);
-        if (wv == 0) {
-            issue_X(0);
-            issue_X(1);
-        }
-        issue_TE(I0{}, 0);
-        issue_TE(I1{}, 1);
-        issue_TE(I2{}, 2);
-        wait_loads<0>(plo[0], phi[0], te[0]);
-        wait_loads<0>(plo[1], phi[1], te[1]);
-        asm volatile("" : "+v"(te[2]));
-        if (wv == 1) {
-            settle(I0{}, 0);
-            settle(I1{}, 1);
-            issue_TP(I0{}, 0);
-            issue_TP(I1{}, 1);
-        }
-        scatter(I0{}, 0);
-        lds_barrier(); /* lastrc of row 0 */
-        scatter(I1{}, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier(); /* rows 0 and 1 placed */
-        if (wv == 1) tail_scatter(I0{}, 0);
-        if (wv == 0) issue_X(2);
-        issue_P(I2{}, 2);
-        issue_P(I0{}, 3);
-        lds_barrier(); /* row 0 complete */
-    }
-
-    /* rows r-1 (ground flag still open) and r-2 (ready to write) live in pr[(r-1) % 3], pr[(r-2) % 3]; row r takes the
-     * third record.  (Handing them on through variables — p2 = p1; p1 = cur — cost 36 register moves per row.) */
-    PendingRow pr[3] = {};
-
-    float zref = __uint_as_float(0x7fc00000u); /* height of the column's last candidate taken for ground (NaN: none yet) */
-
-    const size_t cand_base = (size_t)f * g.segs * kSeg;
-    uint2 *const fcand = own_sgpr(b.cand + cand_base);
-    uint32_t *const fncand = own_sgpr(b.ncand + (size_t)f * g.segs);
-    const uint32_t code_cap = own_sgpr(g.code_cap);
-    uint32_t *const flist = own_sgpr(b.code_main + ((size_t)f * g.emitters + strip) * bands * (size_t)code_cap);
-    bev_point_t *const fordered = own_sgpr(b.ordered + frame_off);
-    int8_t *const fgm = own_sgpr(b.gm ? b.gm + frame_off : nullptr);
-    const int strips = own_sgpr(g.strips);
-    RasterParams rp = g.rp; /* only the fields the BEV code needs stay alive */
-    rp.max_range_f = own_sgpr(rp.max_range_f);
-    rp.interval = own_sgpr(rp.interval);
-    rp.inv_interval = own_sgpr(rp.inv_interval);
-    rp.height_res = own_sgpr(rp.height_res);
-    rp.inv_height_res = own_sgpr(rp.inv_height_res);
-    rp.lidar_to_ground = own_sgpr(rp.lidar_to_ground);
-    rp.mat_size = own_sgpr(rp.mat_size);
-    rp.n_layers = own_sgpr(rp.n_layers);
-
-    /* one row; I = r mod 6 (r mod 2 at depth 1) at compile time */
-    auto row_step = [&](auto I, const int r) {
-        constexpr int ic = decltype(I)::value % (kDepth + 1);              /* stage holding row r */
-        constexpr int in = (decltype(I)::value + kDepth) % (kDepth + 1);   /* stage that takes row r + kDepth */
-        constexpr int wu = (decltype(I)::value + kDepth) % 2, wl = decltype(I)::value % 2; /* winner word used / reloaded */
-        PendingRow &p0 = pr[decltype(I)::value % 3], &p1 = pr[(decltype(I)::value + 2) % 3], &p2 = pr[(decltype(I)::value + 1) % 3];
-        const XYZI prev{__uint_as_float(p1.lo.w[0]), __uint_as_float(p1.lo.w[1]), __uint_as_float(p1.lo.w[2]), __uint_as_float(p1.hi.w[0])};
-        const XYZI prevprev{__uint_as_float(p2.lo.w[0]), __uint_as_float(p2.lo.w[1]), __uint_as_float(p2.lo.w[2]), __uint_as_float(p2.hi.w[0])};
-        const int par = r & 1;
-        Half cur_lo, cur_hi;
-        if (kStream) {
-            /* everything issued in earlier steps has arrived */
-            constexpr int s2 = (decltype(I)::value + 2) % 3, s1 = (decltype(I)::value + 1) % 3, s0 = decltype(I)::value % 3;
-            /* row r from its buffer (requested before the wait for the global loads: it does not depend on them): the
-             * entry is the slot's own point, or the slot is empty (value-initialised, BatchMultiBevGen.cpp:98) */
-            const u32x4 a = rowbuf[s0][0][tid], c = rowbuf[s0][1][tid];
-            wait_loads<0>(plo[s2], phi[s2], te[s2]);
-            const uint32_t want = slot_rc + (uint32_t)r; /* row | col << 16 of this thread's slot in row r */
-            const bool hit = r < N && c.y == want;
-            cur_lo = Half{{hit ? a.x : 0u, hit ? a.y : 0u, hit ? a.z : 0u, hit ? a.w : 0u}};
-            cur_hi = Half{{hit ? c.x : 0u, hit ? c.y : 0u, hit ? c.z : 0u, hit ? c.w : 0u}};
-            scatter(std::integral_constant<int, s2>{}, r + 2);
-            if (wv == 1) tail_scatter(std::integral_constant<int, s1>{}, r + 1);
-            if (wv == 0) issue_X(r + 3);
-            if (wv == 1) settle(std::integral_constant<int, s2>{}, r + 2);
-            /* (every wave issues this load although only the second one uses it: a register that an asm load is still
-             * writing must not be defined on one side of a branch only — the compiler then merges it with its old
-             * value through a copy, and a copy made while the load is in flight carries the stale word) */
-            issue_TE(std::integral_constant<int, s0>{}, r + 3);
-            if (wv == 1) issue_TP(std::integral_constant<int, s2>{}, r + 2);
-            issue_P(std::integral_constant<int, s1>{}, r + 4);
-        } else {
-            cur_lo = Half{{plo[ic].x, plo[ic].y, plo[ic].z, plo[ic].w}};
-            cur_hi = Half{{phi[ic].x, phi[ic].y, phi[ic].z, phi[ic].w}};
-            if (!pfull[ic]) { /* untouched slot: value-initialised, BatchMultiBevGen.cpp:98 */
-                cur_lo = Half{{0, 0, 0, 0}};
-                cur_hi = Half{{0, 0, 0, 0}};
-            }
-        }
-        {
-            const uint32_t wn = winner_of(r + kDepth, wraw[wu]);
-            pfull[in] = wn != 0u;
-            load_point(wn, plo[in], phi[in]);
-        }
-        load_winner_raw(r + 2 * kDepth, wraw[wl]);
-
-        const XYZI cur{__uint_as_float(cur_lo.w[0]), __uint_as_float(cur_lo.w[1]), __uint_as_float(cur_lo.w[2]),
-                       __uint_as_float(cur_hi.w[0])};
-        if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
-        /* candidates of row r-2: every wave publishes its count, the write-out after the barrier ranks them */
-        const bool cand2 = outcol && p2.gflag == 1;
-        const unsigned long long mc = __ballot(cand2);
-        if (lane == 0) wave_cnt[par][wv] = (uint32_t)__popcll(mc);
-#ifndef BEV_EXP_NOBARRIER
-        lds_barrier();
-#endif
-
-        /* ---- write out row r-2 (its per-wave counts were published before the barrier) ---- */
-        /* (first thing after the barrier: the stores then have the whole status computation to complete in — gfx950 counts
-         * them on the same counter as the loads, and the wait at the top of the next step would otherwise sit right
-         * behind them) */
-        if (r >= 2) {
-            const int q = r - 2;
-            const bool is_cand = cand2;
-            const int rr = q - (lo_row - 1);        /* only rows lo-1 .. N-1 can hold candidates */
-            if (rr >= 0) {
-                uint32_t before = 0, total = 0;
-#pragma unroll
-                for (int w = 0; w < kWaves; ++w) {
-                    const uint32_t c = wave_cnt[par][w];
-                    if (w < wv) before += c;
-                    total += c;
-                }
-                const uint32_t seg = (uint32_t)(rr * strips + strip);
-                if (is_cand) {
-                    /* the earlier waves' candidates, the earlier lanes' */
-                    uint32_t rank = before + (uint32_t)__popcll(mc & ((1ull << lane) - 1ull));
-#ifdef BEV_EXP_NOBARRIER /* timing experiment only: results are wrong, accesses stay in range */
-                    rank &= (uint32_t)kSeg - 1u;
-#endif
-                    const uint32_t at = seg * (uint32_t)kSeg + rank; /* < 2^32: a frame's segments hold fewer slots than S */
-                    store_ws(&fcand[at], make_uint2(p2.key, p2.lo.w[2])); /* key | height */
-                }
-                if (tid == 2) fncand[seg] = total;
-            }
-            /* BEV code of the slot.  A slot that is not a candidate has its final label, so its code is final too: it
-             * is appended to this strip's list of the raster band its x bin falls into (the order inside a list does
-             * not matter: an LDS cursor per band).  Candidates' codes travel in their keys.  A lane whose left
-             * neighbour appends the very same code skips (near the sensor dozens of consecutive returns share a bin). */
-            {
-                bool has = outcol && !is_cand && p2.code != kSkip;
-                const uint32_t left_code = lane_from(sh_left1, p2.code);
-                const bool left_has = lane_from(sh_left1, has ? 1u : 0u) != 0u;
-                if (lane > 0 && left_has && left_code == p2.code) has = false;
-                /* ... and so does one whose code this strip has listed before and still remembers (rings hit the same
-                 * cells at the same heights again and again: a HDL_64E frame lists 74 k codes of which 24 k are
-                 * distinct).  The rasters are idempotent, so a stale or racing memo entry only costs a duplicate. */
-                if (has) {
-                    const uint32_t slot = (p2.code * 0x9E3779B1u) >> (32 - kSeenB);
-                    if (seen[slot] == p2.code) has = false;
-                    else seen[slot] = p2.code;
-                }
-                if (has) {
-                    const int band = band_tab[code_x(p2.code)];
-                    const uint32_t pos = atomicAdd(&band_cursor[band], 1u);
-                    store_ws(&flist[(uint32_t)band * code_cap + pos], p2.code);
-                }
-            }
-            {
-                /* The 64 points of a wave are 2 KiB of consecutive bytes of the output.  Stored as they sit in the
-                 * registers — the low halves with one instruction, the high halves with another — every 128-byte line
-                 * leaves the CU in two instalments of four 16-byte pieces, and L2 writes some lines back in between.
-                 * Through 2 KiB of LDS (wave-private, no barrier) each instruction stores 1 KiB of whole lines instead. */
-                Half hi = p2.hi;
-                const bool as_ground = is_cand && !p2.pred;
-                if (as_ground) hi.w[3] &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
-                xpose[wv][2 * lane] = u32x4{p2.lo.w[0], p2.lo.w[1], p2.lo.w[2], p2.lo.w[3]};
-                xpose[wv][2 * lane + 1] = u32x4{hi.w[0], hi.w[1], hi.w[2], hi.w[3]};
-                const u32x4 pa = xpose[wv][lane], pb = xpose[wv][64 + lane];
-                const unsigned long long owners = __ballot(outcol);
-                u32x4 *dst = reinterpret_cast<u32x4 *>(fordered + (q * H + (strip * kStripCols - 2 + 64 * wv)));
-#ifndef BEV_EXP_NOSTORE /* timing experiment: what the ordered cloud's stores cost (results are wrong without them) */
-#ifdef BEV_EXP_WBSTORE /* timing experiment: default (write-back) policy for the ordered cloud's whole-line stores */
-                if ((owners >> (lane >> 1)) & 1ull) dst[lane] = pa;
-                if ((owners >> (32 + (lane >> 1))) & 1ull) dst[64 + lane] = pb;
-#else
-                if ((owners >> (lane >> 1)) & 1ull) __builtin_nontemporal_store(pa, dst + lane);
-                if ((owners >> (32 + (lane >> 1))) & 1ull) __builtin_nontemporal_store(pb, dst + 64 + lane);
-#endif
-#else
-                if (pa.x == 0x12345678u && pb.x == 0x9abcdef0u && owners) __builtin_nontemporal_store(pa, dst + lane); /* keeps the values alive */
-#endif
-                if (outcol && fgm) fgm[(uint32_t)(q * H + v)] = (int8_t)p2.gflag;
-            }
-        }
-
-        /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
-        int s_r = kSteep;
-        if (r >= lo_row && r < N) { /* workgroup-uniform */
-            /* row r-1 of the threads two to the right / left */
-            XYZI right{lane_from_f(sh_right, prev.x), lane_from_f(sh_right, prev.y), lane_from_f(sh_right, prev.z), lane_from_f(sh_right, prev.i)};
-            XYZI left{lane_from_f(sh_left, prev.x), lane_from_f(sh_left, prev.y), lane_from_f(sh_left, prev.z), lane_from_f(sh_left, prev.i)};
-            const float4(*pe)[4] = edge[(r + 2) % 3];
-            if (lane >= 62 && wv + 1 < kWaves) { const float4 q = pe[wv + 1][lane - 62]; right = XYZI{q.x, q.y, q.z, q.w}; }
-            if (lane < 2 && wv > 0) { const float4 q = pe[wv - 1][lane + 2]; left = XYZI{q.x, q.y, q.z, q.w}; }
-            if (outcol) {
-                XYZI up = prev;                                  /* (r-1, c)                  :143     */
-                if (up.i == -1.0f) up = right;                   /* (r-1, (c+2) % H)          :146-149 */
-                if (up.i == -1.0f) up = left;                    /* flat (r-1)*H + c - 2      :151-154 */
-                if (up.i == -1.0f && r >= 2) up = prevprev;      /* (r-2, c)                  :157-160 */
-                if (cur.i == -1.0f || up.i == -1.0f) s_r = kInvalid; /* :162-167 */
-#ifndef BEV_EXP_NOANGLE
-                else s_r = angle_is_ground_flat(up.x - cur.x, up.y - cur.y, up.z - cur.z) ? kGround : kSteep; /* :169-182 */
-#else /* timing experiment */
-                else s_r = (up.x - cur.x) > 1e30f ? kGround : kSteep;
-#endif
-            }
-        }
-
-        /* ---- ground_mat of row r-1 is now decided (closed form, see bev_exact.h) ---- */
-        {
-            const int q = r - 1;
-            int gf = 0;
-            if (q >= lo_row) gf = (p1.status == kInvalid) ? -1 : (p1.status == kGround ? 1 : (s_r == kGround ? 1 : 0));
-            else if (q == lo_row - 1) gf = (s_r == kGround) ? 1 : 0;
-            p1.gflag = (q >= 0 && q < N) ? gf : 0;
-        }
-        const bool cand1 = outcol && p1.gflag == 1;
-        /* Provisional labels.  Phase C un-grounds a candidate that lies 0.30 m above a neighbour cell's average ground
-         * height — known only after the whole frame has been summed.  The walk GUESSES: a candidate 0.30 m above the last
-         * candidate of its column that it took for ground is written with its own label, every other candidate with
-         * label 0; k_ground_resolve tests every candidate exactly and patches the wrong guesses in either direction.
-         * The guess only decides how many sparse 2-byte patches are needed (benchmark frames: 1.3 k instead of 7.9 k per
-         * frame). */
-        {
-            const float zq = __uint_as_float(p1.lo.w[2]);
-            /* a candidate whose label is not the -2 every producer writes (MulranPointCloudSelect.cpp:126) keeps its
-             * label whatever the guess: phase C can then always patch without looking the input point up again (the
-             * key says "-2" or the patch is a 0) */
-            const bool plain = (p1.hi.w[3] & 0xffffu) == 0xfffeu;
-            p1.pred = cand1 && (!plain || zq - zref >= 0.3f); /* (the comparison is false while zref is NaN) */
-            if (cand1 && !p1.pred) zref = zq;
-        }
-        if (cand1) {
-            const int cell = ground_cell(__uint_as_float(p1.lo.w[0]), __uint_as_float(p1.lo.w[1]));
-            p1.key = candidate_key_edges(cell, tid - 2, p1.pred, p1.code, (int)(int16_t)(p1.hi.w[3] & 0xffffu),
-                                         edge_x[cell / kGridCols], edge_y[cell % kGridCols]);
-        }
-
-        /* ---- row r's record (the one row r-3 has left) ---- */
-        p0.lo = cur_lo;
-        p0.hi = cur_hi;
-        p0.status = s_r;
-        p0.gflag = 0;
-        p0.pred = false;
-        p0.key = 0u;
-#ifndef BEV_EXP_NOCODE
-        p0.code = bev_code(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w[3] & 0xffffu), rp);
-#else /* timing experiment */
-        p0.code = kSkip;
-#endif
-    };
-    /* two extra iterations drain the pipeline */
-    /* (the stream source has no stage that rotates with period 2: three copies of the step instead of six) */
-    constexpr int kUnroll = kStream ? 3 : 6;
-    for (int r0 = 0; r0 < N + 2; r0 += kUnroll) {
-        row_step(std::integral_constant<int, 0>{}, r0);
-        if (r0 + 1 < N + 2) row_step(std::integral_constant<int, 1>{}, r0 + 1);
-        if (r0 + 2 < N + 2) row_step(std::integral_constant<int, 2>{}, r0 + 2);
-        if (kUnroll == 6) {
-            if (r0 + 3 < N + 2) row_step(std::integral_constant<int, 3>{}, r0 + 3);
-            if (r0 + 4 < N + 2) row_step(std::integral_constant<int, 4>{}, r0 + 4);
-            if (r0 + 5 < N + 2) row_step(std::integral_constant<int, 5>{}, r0 + 5);
-        }
-    }
-    if (kStream) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* no LDS-DMA may outlive the workgroup's LDS */
-    lds_barrier();
-    if (tid < bands) b.ncode[((size_t)f * g.emitters + strip) * bands + tid] = band_cursor[tid];
-    if (kStream) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            consumed += __shfl_xor(consumed, d);
-            failed |= __shfl_xor(failed, d);
-        }
-        if (lane == 0) {
-            atomicAdd(&b.info[f].consumed, consumed);
-            if (failed) atomicOr(&b.info[f].failed, 1u);
-        }
-    }
-}
-
-/* ------------------------------------------------------------------------- */
-/* k_walk (round 3): the column walk for the winner-table and identity sources, rebuilt around three measurements:
- *   1. hipcc drains the memory queue (s_waitcnt vmcnt(0)) at the top of EVERY row step of k_strip_ground: gfx9-family
- *      loads and stores retire out of order with respect to each other, so with stores pending the compiler cannot
- *      count, and the "two rows in flight" were one row in flight plus a full round trip per step.  Here every global
- *      READ of the row loop is an LDS-DMA load (global_load_lds: per-lane source address, data lands in LDS, no VGPR
- *      destination the compiler could copy or spill while the load is in flight), issued two steps ahead and waited
- *      for with a COUNTED s_waitcnt: "a load has completed once at most as many operations are outstanding as loads
- *      were issued after it" holds whatever the stores in between do, and the stores of a step are issued BEFORE its
- *      loads, so that the wait at the top of a step covers stores that are a whole step old and loads that are two.
+ *   - status s[r] is evaluated ONCE per slot; ground_mat(r-1) follows from s[r-1] and s[r] (closed form in
+ *     bev_exact.h), so row r-1 is finished while row r is being evaluated, and row r-2 is written out.
+ * Candidates of one (row, strip) are compacted in column order into their own segment; segments enumerate (row, strip)
+ * in row-major order, so the concatenation of all segments is slot order — what phase B's accumulation order needs.
+ *
+ * Round 3 rebuilt the kernel around three measurements:
+ *   1. hipcc drained the memory queue (s_waitcnt vmcnt(0)) at the top of EVERY row step: gfx9-family loads and stores
+ *      retire out of order with respect to each other, so with stores pending the compiler cannot count, and the "two
+ *      rows in flight" were one row in flight plus a full round trip per step.  Every global READ of the row loop is
+ *      now an LDS-DMA load (global_load_lds: per-lane source address, the data lands in LDS, no VGPR destination the
+ *      compiler could copy or spill while the load is in flight), issued two steps ahead and waited for with a COUNTED
+ *      s_waitcnt: "a load has completed once at most as many operations are outstanding as loads were issued after it"
+ *      holds whatever the stores in between do; the stores of a step are issued BEFORE its loads, so that the wait at
+ *      the top of a step covers stores that are a whole step old and loads that are two.
  *   2. a fifth of the walk's vector instructions were v_readlane restores of spilled scalar registers: the raster
- *      constants came back as an 8-dword tuple for every multiplication, pointers that had been laundered through
- *      asm turned every store into a FLAT store (which also counts on lgkmcnt, the LDS counter).  The raster
- *      constants live in vector registers here (they only feed VALU), the power-of-two / divide choice is a template
- *      parameter, stores go through address-space-1 pointers (global_store, scalar base + 32-bit lane offset).
- *   3. waves without a column (the last strip of a row holds 67 of 256 threads for HDL_64E, 16 for OS1_64) end
- *      before the row loop: an ended wave drops out of s_barrier.
- * The arithmetic, the candidate segments, the provisional labels and the code lists are k_strip_ground's (see there). */
+ *      constants came back as an 8-dword tuple for every multiplication, and pointers laundered through asm turned
+ *      every store into a FLAT store (which also counts on lgkmcnt, the LDS counter).  The raster constants live in
+ *      vector registers (they only feed VALU), the power-of-two / divide choice is a template parameter, stores go
+ *      through address-space-1 pointers (global_store, scalar base + 32-bit lane offset).
+ *   3. waves without a column (the last strip of a row holds 67 of 256 threads for HDL_64E, 16 for OS1_64) end before
+ *      the row loop: an ended wave drops out of s_barrier.
+ *
+ * Three sources of the points (template parameter):
+ *   kSrcGather    through the winner table of the order scan (any input);
+ *   kSrcIdentity  b.pts already is an ordered cloud (bev_mark_ground);
+ *   kSrcInPlace   the input's first T points are in strictly ascending slot order (k_probe): they are read IN PLACE,
+ *                 coalesced, once — no order scan, no winner table.  Row rho's points of this strip's 256 virtual
+ *                 columns are consecutive in the input and start near est[rho][strip]; the workgroup DMAs a window of
+ *                 272 positions (est - 12 ...) into LDS, every thread looks at the (row, col) its window position
+ *                 carries and enters the position into an index row at the point's column offset; the points listed for
+ *                 the (row, strip) after the prefix ("tail", at most kTailCap, k_probe) are DMAed beside the window and
+ *                 entered with a key that beats every prefix entry and every EARLIER tail point (LDS atomicMax: the
+ *                 reference's scatter keeps the last writer, BatchMultiBevGen.cpp:112); after the step's barrier each
+ *                 column's owner follows its index entry to its point; an entry whose (row, col) is not the slot's own
+ *                 is an empty slot.  Nothing of this is trusted: a position holding a point of the strip's OWN columns
+ *                 counts it and checks that its predecessor in the input lies in the prefix and has a smaller slot;
+ *                 when all T prefix points of a frame have been counted exactly once and no check has failed, the
+ *                 prefix is strictly ascending, every point was where its strip looked, and the result is what
+ *                 getOrderedCloud's scatter gives; otherwise k_verdict sends the frame through the general kernels. */
 template <class T> using gptr = __attribute__((address_space(1))) T *;
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+/* LDS-DMA: every lane gives its own source address, the 64 x 16 (x 4) bytes land at a wave-uniform LDS address +
+ * lane * 16 (* 4); counts on vmcnt like any load (scripts/microbench/glds_test.hip checks both on the box) */
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ void glds16x2(const void *ga, uint32_t la, const void *gb, uint32_t lb)
 {
     uint32_t keep;
@@ -1103,7 +471,8 @@ __device__ __forceinline__ void glds4_nt(const void *gsrc, uint32_t lds_dst)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm()
+{ asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
 /* a wave-uniform value that only feeds vector instructions: keep it out of the scalar file */
 template <class T>
 __device__ __forceinline__ T in_vgpr(T v)
@@ -1111,7 +480,7 @@ __device__ __forceinline__ T in_vgpr(T v)
     asm volatile("" : "+v"(v));
     return v;
 }
-/* row record of the walk: flags = (status + 1) | (ground_mat + 1) << 2 | pred << 4 | slot holds a point << 5 */
+/* row record of the walk: flags = (status + 1) | (ground_mat + 1) << 2 | pred << 4 */
 struct WalkRow {
     u32x4 lo, hi;
     uint32_t code, key, fl;
@@ -1119,11 +488,21 @@ struct WalkRow {
 __device__ __forceinline__ int wr_status(uint32_t fl) { return (int)(fl & 3u) - 1; }
 __device__ __forceinline__ int wr_gflag(uint32_t fl) { return (int)((fl >> 2) & 3u) - 1; }
 
+enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcInPlace = 2 };
+constexpr int kWinPos = 272;       /* in-place source: window positions of a (row, strip): est - kWinLead ... */
+constexpr int kWinLead = 12;
+constexpr int kWrapPos = 16;       /* ... the last strip's wrap-around halo: positions around the row's start */
+constexpr int kWrapLead = 6;
+/* bytes of one ring slot: window (272 x 32 B) + wrap-around positions (16 x 32 B) = 9 DMA pieces of 1 KiB, + tail points */
+constexpr int kInPlaceSlot = (kWinPos + kWrapPos + kTailCap) * 32;
+constexpr uint32_t kIdxTail = 1u << 30;
+constexpr int kTailLoads = kTailCap > 32 ? 5 : 4; /* loads per step of the in-place source's fourth wave: 2 window pieces, 1 list, 1 or 2 tail pieces */
+
 template <int kSrc, bool kPow2, bool kGm>
 __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
-    constexpr bool kIdentity = kSrc == kSrcIdentity;
-    static_assert(kSrc == kSrcGather || kSrc == kSrcIdentity, "the in-place source has its own kernel");
+    constexpr bool kIdentity = kSrc == kSrcIdentity, kInPlace = kSrc == kSrcInPlace;
+    static_assert((kWinPos + kWrapPos) * 32 == 9 * 1024 && kTailCap <= 64 && kTailCap % 16 == 0, "DMA pieces of the in-place source");
     int f, strip;
     if (!map_block_xcd(blockIdx.x, nf, g.strips, f, strip)) return;
     if (!kIdentity && b.info && b.info[f].mode != want_mode) return; /* another launch of the walk has the frame */
@@ -1132,34 +511,54 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
     const size_t frame_off = (size_t)f * g.S;
     const int bands = g.raster_bands;
 
+    /* lanes two to the right / left (wrapping inside the wave; the edge lanes are patched from LDS), one to the left */
     const int sh_right = ((lane + 2) & 63) << 2, sh_left = ((lane - 2) & 63) << 2, sh_left1 = ((lane - 1) & 63) << 2;
     auto lane_from = [&](int sel, uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)x); };
     auto lane_from_f = [&](int sel, float x) -> float { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)__float_as_uint(x))); };
     const int v = strip * kStripCols + tid - 2;                      /* virtual column */
-    const bool provider = (v < H + 2) && (v >= 0 || strip == 0);     /* has a point to load */
+    const bool provider = (v < H + 2) && (v >= 0 || strip == 0);     /* has a slot */
     const bool outcol = tid >= 2 && tid < 2 + kStripCols && v < H;   /* owns column v's outputs */
     const int vcol = v >= H ? v - H : v;                             /* wrap; v < 0 keeps the flat rule */
 
     constexpr int kWaves = kStripThreads / 64;
-    __shared__ u32x4 ring[3][2][kStripThreads];            /* the points of rows r, r+1, r+2 (low / high halves), by thread */
-    __shared__ uint32_t wring[3][kStripThreads];           /* raw winner words of rows r+2, r+3, r+4 */
+    constexpr int kSlotBytes = kInPlace ? kInPlaceSlot : 8192;
+    constexpr int kSeenB = kInPlace ? 8 : kSeenBits;       /* (the in-place source needs the LDS for its windows) */
+    /* the points of rows r, r+1, r+2.  Gather / identity: by thread, low halves in the first 4 KiB, high halves in the
+     * second.  In place: by window position, 32 B each, then the wrap-around positions, then the tail points */
+    __shared__ __attribute__((aligned(16))) char ring[3 * kSlotBytes];
+    __shared__ uint32_t wring[kSrc == kSrcGather ? 3 : 1][kStripThreads]; /* raw winner words of rows r+2, r+3, r+4 */
+    __shared__ uint32_t idx[kInPlace ? 2 : 1][kInPlace ? kStripThreads : 1]; /* column offset -> position + 1 | tail key */
+    __shared__ uint32_t tlist[kInPlace ? 3 : 1][kInPlace ? 64 : 1];       /* tail lists of rows r+2, r+3, r+4 */
+    __shared__ int est_l[2][kInPlace ? kStreamMaxRows : 1];
+    __shared__ uint8_t tcnt_l[kInPlace ? kStreamMaxRows : 1];
     __shared__ float4 edge[3][kWaves][4];                  /* rows r, r-1, (r-2): lanes 0, 1, 62, 63 of every wave */
     __shared__ uint32_t wave_cnt[2][kWaves];               /* per-wave candidate counts of the row being written */
     __shared__ uint32_t band_cursor[kMaxBands];            /* entries already in this strip's code list of each band */
     __shared__ uint8_t band_tab[512];                      /* x bin -> raster band */
-    __shared__ uint32_t seen[1 << kSeenBits];              /* direct-mapped memo of codes this strip has already listed */
+    __shared__ uint32_t seen[1 << kSeenB];                 /* direct-mapped memo of codes this strip has already listed */
     __shared__ int edge_x[kGridRows], edge_y[kGridCols];   /* BEV bin of every ground-grid row's / column's lower edge */
     if (tid < kMaxBands) band_cursor[tid] = 0u;
     if (tid < 2 * kWaves) wave_cnt[tid / kWaves][tid % kWaves] = 0u;
     if (tid < 3 * kWaves * 4) (&edge[0][0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = tid; k < (1 << kSeenBits); k += kStripThreads) seen[k] = kSkip;
+    for (int k = tid; k < (1 << kSeenB); k += kStripThreads) seen[k] = kSkip;
     for (int x = tid; x < g.rp.mat_size; x += kStripThreads) band_tab[x] = (uint8_t)raster_band_of(x, g.rp);
     if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
     else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
+    if constexpr (kInPlace) {
+        idx[0][tid] = 0u;
+        idx[1][tid] = 0u;
+        const uint32_t *fe = b.est + (size_t)f * N * strips;
+        const uint32_t *fc = b.tail_cnt + (size_t)f * N * strips;
+        for (int r = tid; r < N; r += kStripThreads) {
+            est_l[0][r] = (int)fe[r * strips + strip];
+            est_l[1][r] = (int)fe[r * strips];
+            tcnt_l[r] = (uint8_t)fc[r * strips + strip];
+        }
+    }
     lds_barrier();
     /* a wave none of whose threads has a column ends here (its counts stay zero, nobody reads its edge lanes: the
-     * threads that would are not output columns) */
-    if (__ballot(provider) == 0ull) return;
+     * threads that would are not output columns; the in-place source needs every wave for its windows) */
+    if (!kInPlace && __ballot(provider) == 0ull) return;
 
     const bev_point_t *fpts = kIdentity ? (b.pts + frame_off) : (b.pts + b.frames[f].in_offset);
     const uint32_t *fwin = b.winner + frame_off;
@@ -1169,17 +568,21 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
      * zeroed when the row is consumed: every step issues the same loads */
     const Half *dummy = reinterpret_cast<const Half *>(b.ordered + frame_off);
     auto has_slot = [&](int r) -> bool { return provider && r < N && r * H + vcol >= 0; };
-    /* LDS addresses of this wave's pieces of the rings */
-    const uint32_t ring_l = __builtin_amdgcn_readfirstlane(lds_addr(&ring[0][0][0])) + (uint32_t)wv * 1024u;
+    const uint32_t ring_l = __builtin_amdgcn_readfirstlane(lds_addr(&ring[0]));
     const uint32_t wring_l = __builtin_amdgcn_readfirstlane(lds_addr(&wring[0][0])) + (uint32_t)wv * 256u;
-    auto issue_winner = [&](int q, int slot) { /* raw winner word of row q */
-        if (kIdentity) return;
-        const int fl = has_slot(q) ? q * H + vcol : 0;
-        glds4_nt(&fwin[fl], wring_l + (uint32_t)slot * 1024u);
+    auto clamp_row = [&](int q) -> int { return q < N ? q : N - 1; };
+
+    /* ---- gather / identity: winner words two steps before the points, points two steps before the row ---- */
+    auto issue_winner = [&](int q, int slot) {
+        if constexpr (kSrc == kSrcGather) {
+            const int fl = has_slot(q) ? q * H + vcol : 0;
+            glds4_nt(&fwin[fl], wring_l + (uint32_t)slot * 1024u);
+        }
     };
     auto issue_points = [&](uint32_t w, int slot) { /* w: input index + 1, 0 = empty slot */
         const Half *src = w != 0u ? reinterpret_cast<const Half *>(fpts + (w - 1u)) : dummy;
-        glds16x2(src, ring_l + (uint32_t)slot * 8192u, src + 1, ring_l + (uint32_t)slot * 8192u + 4096u);
+        const uint32_t at = ring_l + (uint32_t)slot * kSlotBytes + (uint32_t)wv * 1024u;
+        glds16x2(src, at, src + 1, at + 4096u);
     };
     auto winner_of = [&](int q, uint32_t raw) -> uint32_t { /* input index + 1 of slot (q, this column), 0 = empty */
         if (!has_slot(q)) return 0u;
@@ -1187,11 +590,135 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         return winner_index(raw, win_tag, win_shift);
     };
     uint32_t full = 0u; /* bit (row mod 3): the row's slot holds a point */
-    {   /* prologue: the queue the row loop expects — points of row 0, winners of row 2, points of row 1, winners of row 3 */
+
+    /* ---- in place ---- */
+    const uint32_t T = kInPlace ? b.info[f].T : 0u;
+    const bool last_strip = strip == strips - 1;
+    const int first_col = strip * kStripCols - 2; /* virtual column of offset 0 */
+    const int own_cols = (H - first_col - 2) < kStripCols ? (H - first_col - 2) : kStripCols; /* own columns of this strip */
+    const int row_span = (H - first_col) < kStripThreads ? (H - first_col) : kStripThreads;  /* offsets that belong to the row */
+    /* (row | col << 16) of the thread's slot in row 0 (the tail of row -1 for strip 0's left halo: never there; column
+     * 0xffff for threads without a slot: never there either) */
+    const uint32_t slot_rc = !provider ? 0xffff0000u : (v < 0 ? ((uint32_t)(H + v) << 16) + 0xffffffffu : (uint32_t)vcol << 16);
+    const uint32_t *ftail = kInPlace ? b.tail_list + ((size_t)f * N * strips + strip) * kTailCap : nullptr;
+    const int tail_stride = strips * kTailCap;  /* words from one row's list to the next */
+    const uint32_t tlist_l = __builtin_amdgcn_readfirstlane(lds_addr(&tlist[0][0]));
+    uint32_t te[3] = {0u, 0u, 0u}; /* wave 3: this lane's tail entry of rows q at [q % 3] (column offset | input index << 8) */
+    uint32_t consumed = 0u, failed = 0u;
+    auto src_of = [&](int q, int half) -> const Half * { /* half of the point at input position q, or of position 0 outside the prefix */
+        return reinterpret_cast<const Half *>(fpts + ((unsigned)q < T ? q : 0)) + half;
+    };
+    auto issue_window = [&](int q, int slot) { /* this wave's two pieces of row q's window (32 positions each) */
+        const int e = est_l[0][clamp_row(q)] - kWinLead;
+        const uint32_t at = ring_l + (uint32_t)slot * kSlotBytes + (uint32_t)wv * 2048u;
+        glds16x2(src_of(e + wv * 64 + (lane >> 1), lane & 1), at, src_of(e + wv * 64 + 32 + (lane >> 1), lane & 1), at + 1024u);
+    };
+    auto issue_extra = [&](int q, int slot) { /* wave 0: positions 256 .. 271 of the window and the wrap-around positions */
+        const int rc = clamp_row(q);
+        const int pos = lane < 32 ? est_l[0][rc] - kWinLead + 256 + (lane >> 1) : est_l[1][rc] - kWrapLead + ((lane - 32) >> 1);
+        glds16(src_of(pos, lane & 1), ring_l + (uint32_t)slot * kSlotBytes + 8192u);
+    };
+    auto issue_tail_list = [&](int q, int slot) { /* wave 3: the (row, strip)'s list, 64 words (stale past the count) */
+        glds4_nt(ftail + (size_t)clamp_row(q) * tail_stride + lane, tlist_l + (uint32_t)slot * 256u);
+    };
+    auto issue_tail_points = [&](int q, int slot, int tslot) { /* wave 3: the listed points of row q beside its window */
+        const int n = q < N ? (int)tcnt_l[clamp_row(q)] : 0;
+        te[tslot] = tlist[tslot][lane];
+        const uint32_t ea = tlist[tslot][lane >> 1], eb = tlist[tslot][32 + (lane >> 1)];
+        const uint32_t at = ring_l + (uint32_t)slot * kSlotBytes + (uint32_t)(kWinPos + kWrapPos) * 32u;
+        glds16(reinterpret_cast<const Half *>(fpts + ((lane >> 1) < n ? (ea >> 8) : 0u)) + (lane & 1), at);
+        if (kTailCap > 32 && lane < 2 * (kTailCap - 32)) /* (the piece ends with the slot) */
+            glds16(reinterpret_cast<const Half *>(fpts + (32 + (lane >> 1) < n ? (eb >> 8) : 0u)) + (lane & 1), at + 1024u);
+    };
+    auto slot_or_max = [&](int q, uint32_t rcw) -> int { /* slot of input position q, INT_MAX outside the prefix / the range image */
+        const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
+        const bool valid = (unsigned)q < T && row < (uint32_t)N && col < (uint32_t)H;
+        return valid ? (int)row * H + (int)col : 0x7fffffff;
+    };
+    /* one window position into the index row, counted and checked.  Its predecessor in the input must lie in the prefix
+     * and have a smaller slot; window position 0 cannot be checked (the estimate was too high).  The first position of a
+     * wave's piece follows a position that ANOTHER wave's DMA brings: that check is made after the step's barrier. */
+    bool dneed = false;
+    int dflat = 0, dq = 0, dp = 0;
+    auto enter = [&](int rho, const char *slot_b, uint32_t *irow, int p) {
+        const int q = est_l[0][rho] - kWinLead + p;
+        const uint32_t rcw = *reinterpret_cast<const uint32_t *>(slot_b + p * 32 + 20);
+        const uint32_t rcp = *reinterpret_cast<const uint32_t *>(slot_b + (p > 0 ? p - 1 : 0) * 32 + 20);
+        const int sflat = slot_or_max(q, rcw);
+        const int off = (int)((uint32_t)sflat - (uint32_t)(rho * H + first_col));
+        /* (a window of the last strip runs into the next row: those points are not this row's wrap-around halo) */
+        if ((unsigned)off < (unsigned)row_span) atomicMax(&irow[off], (uint32_t)p + 1u);
+        const bool own = (unsigned)(off - 2) < (unsigned)own_cols;
+        consumed += own ? 1u : 0u;
+        const bool chk = own && q > 0;
+        const bool foreign = (p & 63) == 0 && p > 0; /* position p - 1 is another wave's */
+        failed |= (chk && !foreign && (p == 0 || !(slot_or_max(q - 1, rcp) < sflat))) ? 1u : 0u;
+        if (foreign) {
+            dneed = chk;
+            dflat = sflat;
+            dq = q;
+            dp = p;
+        }
+    };
+    auto deferred_check = [&](const char *slot_b) { /* after the barrier: every wave's pieces of the row have arrived */
+        const uint32_t rcp = *reinterpret_cast<const uint32_t *>(slot_b + (dp > 0 ? dp - 1 : 0) * 32 + 20);
+        failed |= (dneed && !(slot_or_max(dq - 1, rcp) < dflat)) ? 1u : 0u;
+        dneed = false;
+    };
+    auto index_row = [&](int rho, int slot, int tslot) { /* row rho's window, wrap-around and tail positions -> idx[rho & 1] */
+        if (rho >= N) return;
+        const char *slot_b = &ring[slot * kSlotBytes];
+        uint32_t *irow = idx[rho & 1];
+        enter(rho, slot_b, irow, tid);
+        if (wv == 0) { /* wave-uniform */
+            if (lane < kWinPos - 256) {
+                enter(rho, slot_b, irow, 256 + lane);
+            } else if (last_strip && lane >= 32 && lane < 32 + kWrapPos) { /* slots rho*H and rho*H + 1 as the halo columns H, H + 1 */
+                const int p = kWinPos + (lane - 32);
+                const int q = est_l[1][rho] - kWrapLead + (lane - 32);
+                const uint32_t rcw = *reinterpret_cast<const uint32_t *>(slot_b + p * 32 + 20);
+                const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
+                const int off = H + (int)col - first_col;
+                if ((unsigned)q < T && row == (uint32_t)rho && col < 2u && (unsigned)off < (unsigned)kStripThreads)
+                    atomicMax(&irow[off], (uint32_t)p + 1u);
+            }
+        }
+        if (wv == 3 && lane < (int)tcnt_l[rho]) { /* later input index beats earlier, any tail point beats the prefix */
+            const uint32_t e = te[tslot];
+            atomicMax(&irow[e & 0xffu], kIdxTail | ((e >> 8) << 6) | (uint32_t)lane);
+        }
+    };
+
+    /* ---- prologue: the queue the row loop expects ---- */
+    if constexpr (kInPlace) {
+        if (wv == 3) {
+            issue_tail_list(0, 0);
+            issue_tail_list(1, 1);
+        }
+        wait_vm<0>();
+        issue_window(0, 0);
+        if (wv == 0) issue_extra(0, 0);
+        if (wv == 3) {
+            issue_tail_points(0, 0, 0);
+            issue_tail_list(2, 2);
+        }
+        issue_window(1, 1);
+        if (wv == 0) issue_extra(1, 1);
+        if (wv == 3) {
+            issue_tail_points(1, 1, 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* list 0 has been read before its slot is refilled */
+            issue_tail_list(3, 0);
+        }
+    } else {
         issue_winner(0, 0);
         issue_winner(1, 1);
         wait_vm<0>();
-        const uint32_t w0 = winner_of(0, kIdentity ? 0u : wring[0][tid]), w1 = winner_of(1, kIdentity ? 0u : wring[1][tid]);
+        uint32_t r0 = 0u, r1 = 0u;
+        if constexpr (kSrc == kSrcGather) {
+            r0 = wring[0][tid];
+            r1 = wring[1][tid];
+        }
+        const uint32_t w0 = winner_of(0, r0), w1 = winner_of(1, r1);
         full = (w0 != 0u ? 1u : 0u) | (w1 != 0u ? 2u : 0u);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the words have been read before their ring slots are refilled */
         issue_points(w0, 0);
@@ -1221,8 +748,6 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
     } else {
         rp.interval = in_vgpr(rp.interval);
         rp.height_res = in_vgpr(rp.height_res);
-        rp.inv_interval = 0.0f;
-        rp.inv_height_res = 0.0f;
     }
     auto bin_of = [&](float p) -> int { /* bev_bin_rp with the reciprocal / divide choice made at compile time */
         const float s = p + rp.max_range_f;
@@ -1232,47 +757,87 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         const int x = bin_of(px), y = bin_of(py);
         const bool in = (label != 0) & ((unsigned)x < (unsigned)rp.mat_size) & ((unsigned)y < (unsigned)rp.mat_size);
         const float hq = kPow2 ? pz * rp.inv_height_res : pz / rp.height_res;
-        int layer = cvtt_f32(roundf(hq + rp.lidar_to_ground)); /* :281 */
-        int h = height_times4(pz + rp.lidar_to_ground);        /* :345 */
-        h = h < 0 ? 0 : (h > 255 ? 255 : h);                   /* :346 */
+        const int layer = cvtt_f32(roundf(hq + rp.lidar_to_ground)); /* :281 */
+        int h = height_times4(pz + rp.lidar_to_ground);              /* :345 */
+        h = h < 0 ? 0 : (h > 255 ? 255 : h);                         /* :346 */
         const uint32_t l = (layer >= 0 && layer < rp.n_layers) ? (uint32_t)layer : kNoLayer;
         const uint32_t code = (uint32_t)(in ? x : 0) | ((uint32_t)(in ? y : 0) << 9) | ((uint32_t)h << 18) | (l << 26);
         return in ? code : kSkip;
     };
-    /* where a thread's point goes in its wave's 2 KiB transposition area (the ring slot the step has just consumed:
-     * 1 KiB in the low plane, 1 KiB in the high plane): points 0..31 of the wave in the first, 32..63 in the second */
-    const uint32_t xp_w = (uint32_t)(lane & 31) * 32u + (lane < 32 ? 0u : 4096u);
+    /* A wave's 64 finished points are 2 KiB of consecutive bytes of the output.  Stored as they sit in the registers — the
+     * low halves with one instruction, the high halves with another — every 128-byte line leaves the CU in two
+     * instalments and L2 writes some lines back in between (WRITE_SIZE 5.39 MB where 4.9 MB were stored).  Transposed
+     * through 2 KiB of LDS each instruction stores 1 KiB of whole lines.  The 2 KiB are a piece of a ring slot that is
+     * idle right now and that only this wave's own DMA refills: gather / identity: the slot of the row just consumed
+     * (this wave's two 1-KiB pieces, points 0..31 in the first); in place: the slot row r-1 has left (this wave's two
+     * consecutive window pieces). */
+    const uint32_t xp_w = kInPlace ? (uint32_t)wv * 2048u + (uint32_t)lane * 32u
+                                   : (uint32_t)wv * 1024u + (uint32_t)(lane & 31) * 32u + (lane < 32 ? 0u : 4096u);
+    const uint32_t xp_r1 = kInPlace ? (uint32_t)wv * 2048u + 1024u : (uint32_t)wv * 1024u + 4096u; /* second KiB */
+    const uint32_t xp_r0 = kInPlace ? (uint32_t)wv * 2048u : (uint32_t)wv * 1024u;
 
     auto row_step = [&](auto I, const int r) {
         constexpr int s0 = decltype(I)::value % 3;         /* ring slot of row r (and of row r + 3) */
         constexpr int s2 = (decltype(I)::value + 2) % 3;   /* ... of row r + 2: the slot row r - 1 has left */
-        constexpr int s1 = (decltype(I)::value + 1) % 3;   /* winner ring: row r + 4 goes where row r + 1's word was */
+        constexpr int s1 = (decltype(I)::value + 1) % 3;   /* winner / list ring: row r + 4 goes where row r + 1's was */
         WalkRow &p0 = pr[s0], &p1 = pr[s2], &p2 = pr[s1];
         const int par = r & 1;
-        /* everything but the three newest loads (points of row r + 1, winners of row r + 3) has arrived: the points of
-         * row r and the winner words of row r + 2 (the identity source issues no winner loads: two newest) */
-        wait_vm<kIdentity ? 2 : 3>();
-        u32x4 cur_lo = ring[s0][0][tid], cur_hi = ring[s0][1][tid];
-        const uint32_t wraw = kIdentity ? 0u : wring[s2][tid];
-        if (!((full >> s0) & 1u)) { /* untouched slot: value-initialised, BatchMultiBevGen.cpp:98 */
-            cur_lo = u32x4{0u, 0u, 0u, 0u};
-            cur_hi = u32x4{0u, 0u, 0u, 0u};
+        u32x4 cur_lo, cur_hi;
+        uint32_t wraw = 0u;
+        /* Everything but the newest step's loads has arrived: the points (window) of row r, the winner words (tail list)
+         * of row r + 2.  A wave waits for as many operations as it issues loads per step. */
+        if constexpr (kInPlace) {
+            if (wv == 0) wait_vm<3>();
+            else if (wv == 3) wait_vm<kTailLoads>();
+            else wait_vm<2>();
+            index_row(r, s0, s0);
+        } else {
+            wait_vm<kIdentity ? 2 : 3>();
+            const char *mine = &ring[s0 * kSlotBytes + tid * 16];
+            cur_lo = *reinterpret_cast<const u32x4 *>(mine);
+            cur_hi = *reinterpret_cast<const u32x4 *>(mine + 4096);
+            if constexpr (kSrc == kSrcGather) wraw = wring[s2][tid];
+            if (!((full >> s0) & 1u)) { /* untouched slot: value-initialised, BatchMultiBevGen.cpp:98 */
+                cur_lo = u32x4{0u, 0u, 0u, 0u};
+                cur_hi = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        /* What the waves exchange per step: row r's edge lanes (read by the NEXT step's status) and the per-wave counts of
+         * row r-2's candidates (read by this step's write-out).  Gather / identity: published here, before the step's
+         * barrier.  In place: the point of row r is known only after the barrier (it makes the index row visible), so
+         * both are published at the END of the previous step instead (measured on the gather source, that order costs
+         * 7 %: a wave reaches the barrier straight from its memory wait). */
+        if constexpr (!kInPlace) {
+            if (lane < 2 || lane >= 62)
+                edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(__uint_as_float(cur_lo.x), __uint_as_float(cur_lo.y), __uint_as_float(cur_lo.z), __uint_as_float(cur_hi.x));
+            const unsigned long long m2 = __ballot(outcol && wr_gflag(p2.fl) == 1);
+            if (lane == 0) wave_cnt[par][wv] = (uint32_t)__popcll(m2);
+        }
+        lds_barrier();
+        if constexpr (kInPlace) {
+            /* the column's owner follows its index entry: a window / wrap-around position, or a tail point; an entry
+             * whose (row, col) is not the slot's own is an empty slot (value-initialised, BatchMultiBevGen.cpp:98) */
+            if (lane == 0) deferred_check(&ring[s0 * kSlotBytes]);
+            const uint32_t e = idx[par][tid];
+            idx[par][tid] = 0u; /* (the row after next enters here, two barriers from now) */
+            const uint32_t pos = (e & kIdxTail) ? (uint32_t)(kWinPos + kWrapPos) + (e & 63u) : (e ? e - 1u : 0u);
+            const char *src = &ring[s0 * kSlotBytes] + pos * 32u;
+            const u32x4 a = *reinterpret_cast<const u32x4 *>(src), c = *reinterpret_cast<const u32x4 *>(src + 16);
+            const bool hit = e != 0u && r < N && c.y == slot_rc + (uint32_t)r;
+            cur_lo = u32x4{hit ? a.x : 0u, hit ? a.y : 0u, hit ? a.z : 0u, hit ? a.w : 0u};
+            cur_hi = u32x4{hit ? c.x : 0u, hit ? c.y : 0u, hit ? c.z : 0u, hit ? c.w : 0u};
         }
         const XYZI prev{__uint_as_float(p1.lo.x), __uint_as_float(p1.lo.y), __uint_as_float(p1.lo.z), __uint_as_float(p1.hi.x)};
         const XYZI prevprev{__uint_as_float(p2.lo.x), __uint_as_float(p2.lo.y), __uint_as_float(p2.lo.z), __uint_as_float(p2.hi.x)};
         const XYZI cur{__uint_as_float(cur_lo.x), __uint_as_float(cur_lo.y), __uint_as_float(cur_lo.z), __uint_as_float(cur_hi.x)};
-        if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
-        /* candidates of row r-2: every wave publishes its count, the write-out after the barrier ranks them */
-        const bool cand2 = outcol && wr_gflag(p2.fl) == 1;
-        const unsigned long long mc = __ballot(cand2);
-        if (lane == 0) wave_cnt[par][wv] = (uint32_t)__popcll(mc);
-        lds_barrier();
 
         /* ---- write out row r-2 (first thing after the barrier: its stores are the oldest entries of the step) ---- */
+        const bool cand2 = outcol && wr_gflag(p2.fl) == 1;
         if (r >= 2) {
             const int q = r - 2;
             const int rr = q - (lo_row - 1);        /* only rows lo-1 .. N-1 can hold candidates */
             if (rr >= 0) {
+                const unsigned long long mc = __ballot(cand2);
                 uint32_t before = 0, total = 0;
 #pragma unroll
                 for (int w = 0; w < kWaves; ++w) {
@@ -1287,13 +852,19 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
                 }
                 if (tid == 2) fncand[seg] = total;
             }
-            {   /* BEV code of a slot that is not a candidate: final, appended to this strip's list of its raster band */
+            {   /* BEV code of the slot.  A slot that is not a candidate has its final label, so its code is final too: it
+                 * is appended to this strip's list of the raster band its x bin falls into (the order inside a list does
+                 * not matter: an LDS cursor per band).  Candidates' codes travel in their keys.  A lane whose left
+                 * neighbour appends the very same code skips (near the sensor dozens of consecutive returns share a bin),
+                 * and so does one whose code this strip has listed before and still remembers (rings hit the same cells
+                 * at the same heights again and again: a HDL_64E frame lists 74 k codes of which 24 k are distinct).  The
+                 * rasters are idempotent, so a stale or racing memo entry only costs a duplicate. */
                 bool has = outcol && !cand2 && p2.code != kSkip;
                 const uint32_t left_code = lane_from(sh_left1, p2.code);
                 const bool left_has = lane_from(sh_left1, has ? 1u : 0u) != 0u;
                 if (lane > 0 && left_has && left_code == p2.code) has = false;
                 if (has) {
-                    const uint32_t slot = (p2.code * 0x9E3779B1u) >> (32 - kSeenBits);
+                    const uint32_t slot = (p2.code * 0x9E3779B1u) >> (32 - kSeenB);
                     if (seen[slot] == p2.code) has = false;
                     else seen[slot] = p2.code;
                 }
@@ -1303,24 +874,37 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
                     flist[(uint32_t)band * code_cap + pos] = p2.code;
                 }
             }
-            {   /* the ordered cloud: a wave's 64 points leave as two whole KiB (see k_strip_ground) */
+            {   /* the ordered cloud, as whole lines */
                 u32x4 hi = p2.hi;
                 const bool as_ground = cand2 && !((p2.fl >> 4) & 1u);
                 if (as_ground) hi.w &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
-                char *xb = reinterpret_cast<char *>(&ring[s0][0][64 * wv]);
+                char *xb = &ring[(kInPlace ? s2 : s0) * kSlotBytes];
                 *reinterpret_cast<u32x4 *>(xb + xp_w) = p2.lo;
                 *reinterpret_cast<u32x4 *>(xb + xp_w + 16) = hi;
-                const u32x4 pa = ring[s0][0][64 * wv + lane], pb = ring[s0][1][64 * wv + lane];
+                const u32x4 pa = *reinterpret_cast<const u32x4 *>(xb + xp_r0 + lane * 16);
+                const u32x4 pb = *reinterpret_cast<const u32x4 *>(xb + xp_r1 + lane * 16);
                 const unsigned long long owners = __ballot(outcol);
                 const uint32_t at = (uint32_t)(q * H + (strip * kStripCols - 2 + 64 * wv)) * 2u; /* (never dereferenced below 0) */
+#ifndef BEV_EXP_NOSTORE /* timing experiment: what the ordered cloud's stores cost (results are wrong without them) */
                 if ((owners >> (lane >> 1)) & 1ull) __builtin_nontemporal_store(pa, fordered + (at + (uint32_t)lane));
                 if ((owners >> (32 + (lane >> 1))) & 1ull) __builtin_nontemporal_store(pb, fordered + (at + 64u + (uint32_t)lane));
+#else
+                if (pa.x == 0x12345678u && pb.x == 0x9abcdef0u && owners) __builtin_nontemporal_store(pa, fordered + (at + (uint32_t)lane)); /* keeps the values alive */
+#endif
                 if (kGm && outcol) fgm[(uint32_t)(q * H + v)] = (int8_t)wr_gflag(p2.fl);
             }
         }
-        /* ---- the loads of this step, behind its stores: points of row r + 2, winner words of row r + 4 ---- */
-        {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave is done reading the slots that are refilled */
+        /* ---- the loads of this step, behind its stores: row r + 2 (and the winner words / tail list of row r + 4) ---- */
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave is done reading the pieces it refills */
+        if constexpr (kInPlace) {
+            issue_window(r + 2, s2);
+            if (wv == 0) issue_extra(r + 2, s2);
+            if (wv == 3) {
+                issue_tail_points(r + 2, s2, s2);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                issue_tail_list(r + 4, s1);
+            }
+        } else {
             const uint32_t wn = winner_of(r + 2, wraw);
             full = (full & ~(1u << s2)) | (wn != 0u ? 1u << s2 : 0u);
             issue_points(wn, s2);
@@ -1330,6 +914,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
         int s_r = kSteep;
         if (r >= lo_row && r < N) { /* workgroup-uniform */
+            /* row r-1 of the threads two to the right / left */
             XYZI right{lane_from_f(sh_right, prev.x), lane_from_f(sh_right, prev.y), lane_from_f(sh_right, prev.z), lane_from_f(sh_right, prev.i)};
             XYZI left{lane_from_f(sh_left, prev.x), lane_from_f(sh_left, prev.y), lane_from_f(sh_left, prev.z), lane_from_f(sh_left, prev.i)};
             const float4(*pe)[4] = edge[(r + 2) % 3];
@@ -1354,8 +939,16 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
             if (!(q >= 0 && q < N)) gf = 0;
         }
         const bool cand1 = outcol && gf == 1;
+        /* Provisional labels.  Phase C un-grounds a candidate that lies 0.30 m above a neighbour cell's average ground
+         * height — known only after the whole frame has been summed.  The walk GUESSES: a candidate 0.30 m above the last
+         * candidate of its column that it took for ground is written with its own label, every other candidate with
+         * label 0; k_ground_resolve tests every candidate exactly and patches the wrong guesses in either direction.
+         * The guess only decides how many sparse 2-byte patches are needed (benchmark frames: 1.3 k instead of 7.9 k per
+         * frame).  A candidate whose label is not the -2 every producer writes (MulranPointCloudSelect.cpp:126) keeps its
+         * label whatever the guess: phase C can then always patch without looking the input point up again (the key says
+         * "-2" or the patch is a 0). */
         bool pred1;
-        {   /* provisional label: see k_strip_ground */
+        {
             const float zq = __uint_as_float(p1.lo.z);
             const bool plain = (p1.hi.w & 0xffffu) == 0xfffeu;
             pred1 = cand1 && (!plain || zq - zref >= 0.3f); /* (the comparison is false while zref is NaN) */
@@ -1374,6 +967,13 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         p0.fl = (uint32_t)(s_r + 1) | (1u << 2);
         p0.key = 0u;
         p0.code = code_of(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w & 0xffffu));
+
+        /* ---- in place: published for the next step: row r's edge lanes, the candidates of row r-1 per wave ---- */
+        if constexpr (kInPlace) {
+            if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
+            const unsigned long long m1 = __ballot(cand1);
+            if (lane == 0) wave_cnt[par ^ 1][wv] = (uint32_t)__popcll(m1);
+        }
     };
     /* two extra iterations drain the pipeline */
     for (int r0 = 0; r0 < N + 2; r0 += 3) {
@@ -1384,6 +984,17 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
     wait_vm<0>(); /* no LDS-DMA may outlive the workgroup's LDS */
     lds_barrier();
     if (tid < bands) b.ncode[((size_t)f * g.emitters + strip) * bands + tid] = band_cursor[tid];
+    if constexpr (kInPlace) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            consumed += __shfl_xor(consumed, d);
+            failed |= __shfl_xor(failed, d);
+        }
+        if (lane == 0) {
+            atomicAdd(&b.info[f].consumed, consumed);
+            if (failed) atomicOr(&b.info[f].failed, 1u);
+        }
+    }
 }
 
 /* getOrderedCloud alone (bev_order_cloud): no ground work. */
@@ -2200,8 +1811,7 @@ void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int sou
     if (nf == 0) return;
     const int grid = xcd_grid(nf, g.strips);
     if (source == kSrcIdentity) launch_walk<kSrcIdentity>(g, b, nf, mode, grid, st);
-    else if (source == kSrcStream)
-        hipLaunchKernelGGL(k_strip_ground<kSrcStream>, dim3(grid), dim3(kStripThreads), 0, st, b, g, nf, mode);
+    else if (source == kSrcInPlace) launch_walk<kSrcInPlace>(g, b, nf, mode, grid, st);
     else launch_walk<kSrcGather>(g, b, nf, mode, grid, st);
 }
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st)

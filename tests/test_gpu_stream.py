@@ -32,7 +32,9 @@ def _run(p, ctx, frames):
 @pytest.mark.parametrize("sensor", ["HDL_64E", "HDL_32E", "OS1_64"])
 def test_sorted_sweeps_are_read_in_place(sensor):
     p = bev_amd.params_for_sensor(sensor)
-    frames = [synth.sweep(p, 70 + i, keep=k, n_dup=d) for i, (k, d) in enumerate([(0.98, 5000), (1.0, 0), (0.6, 300), (0.9, 0)])]
+    # (appended points per frame in proportion to the sensor: a (row, strip) lists at most 48 of them, bev_internal.h kTailCap)
+    dup = 5000 * p.slots // 133312
+    frames = [synth.sweep(p, 70 + i, keep=k, n_dup=d) for i, (k, d) in enumerate([(0.98, dup), (1.0, 0), (0.6, 300), (0.9, 0)])]
     ctx = bev_amd.BevContext(p, device=0, max_batch=8, max_points=max(len(f) for f in frames))
     try:
         info = _run(p, ctx, frames)
@@ -119,8 +121,8 @@ def test_stream_and_general_frames_mixed_in_one_sub_batch_and_the_knob():
     import os
     p = bev_amd.params_for_sensor("HDL_32E")
     # (9000 appended points over 32 rows x 5 strips: more than a (row, strip) can list -> that frame goes the general way)
-    frames = [synth.sweep(p, 1), synth.firing_order(p, 2), synth.sweep(p, 3, keep=0.5, n_dup=3000), np.empty(0, bev_amd.POINT_DTYPE),
-              synth.sweep(p, 5), synth.sweep(p, 6, keep=0.5, n_dup=9000)]
+    frames = [synth.sweep(p, 1, n_dup=1200), synth.firing_order(p, 2), synth.sweep(p, 3, keep=0.5, n_dup=1500), np.empty(0, bev_amd.POINT_DTYPE),
+              synth.sweep(p, 5, n_dup=1200), synth.sweep(p, 6, keep=0.5, n_dup=9000)]
     ctx = bev_amd.BevContext(p, device=0, max_batch=16, max_points=max(len(f) for f in frames))
     try:
         info = _run(p, ctx, frames)
