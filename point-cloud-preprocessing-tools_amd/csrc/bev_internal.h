@@ -18,8 +18,9 @@ constexpr int kGatherThreads = 256;
 constexpr int kSlotsPerThread = 4;
 constexpr int kTile = kGatherThreads * kSlotsPerThread; /* slots per workgroup of the gather kernel */
 constexpr int kMaxTiles = 1024;   /* => at most 2^20 slots per frame (bev_create checks) */
-constexpr int kStripThreads = 256;              /* column-walk workgroup: 252 columns + 2 halo columns each side */
-constexpr int kStripCols = kStripThreads - 4;
+constexpr int kStripThreads = 256;              /* column-walk workgroup: 236 columns + 2 halo columns each side = 240 virtual columns */
+constexpr int kStripCols = 236;                 /* (256 input positions cover them with 16 to spare: the in-place source's window, one per thread) */
+constexpr int kStripVirt = kStripCols + 4;
 constexpr int kSeg = 256;                       /* capacity of one candidate segment = one (row, strip) */
 constexpr int kMaxSegs = 1024;                  /* (G + 1) * strips must not exceed this (bev_create checks) */
 constexpr int kSumWaves = 4;      /* waves of the per-frame cell-sum workgroup: the size of a column-walk workgroup */
@@ -34,7 +35,7 @@ constexpr int kResolveParts = 4;  /* workgroups per frame in k_ground_resolve, e
 constexpr int kRasterThreads = BEV_RASTER_THREADS;
 constexpr int kRasterSplit = 8;   /* x-bands per frame in the raster kernel at the reference's 224 x 224 (see raster_bands_for) */
 constexpr int kMaxBands = 32;     /* coarse + fine raster bands (see RasterParams) */
-constexpr int kMaxStrips = 264;   /* ceil(65535 / kStripCols) rounded up */
+constexpr int kMaxStrips = 280;   /* ceil(65535 / kStripCols) rounded up */
 
 /* per-frame launch metadata, copied H2D once per sub-batch */
 struct FrameDesc {
@@ -57,11 +58,11 @@ struct FrameInfo {
     uint32_t consumed; /* prefix points the stream walk has found in their own (row, strip) window */
     uint32_t failed;   /* != 0: a consumed point was not above its predecessor, or could not be checked */
 };
-constexpr int kProbeStride = 127;   /* k_probe looks at every 127th point (odd: no resonance with firing orders of 2^k beams) */
+constexpr int kProbeStride = 63;    /* k_probe looks at every 63rd point (odd: no resonance with firing orders of 2^k beams); the position of a
+                                     * slot between two samples is interpolated: its error grows with the root of the stride */
 constexpr int kMaxSamples = 8192;   /* => stream mode for frames of up to 2^20 points; longer ones go the general way */
-constexpr int kStreamSlack = 16;    /* positions a (row, strip) window starts before / ends after the estimate */
 constexpr int kStreamMinPrefix = 2048;
-constexpr int kTailCap = 48;         /* tail points (those after the sorted prefix) a (row, strip) can list; more: general way */
+constexpr int kTailCap = 64;         /* tail points (those after the sorted prefix) a (row, strip) can list; more: general way */
 constexpr int kTailMax = 16384;     /* ... a frame can have */
 constexpr int kTailBuckets = 2048;  /* (row, strip) pairs of a frame that k_probe can count in LDS */
 constexpr int kStreamMaxRows = 64;   /* sensors with more rows go the general way (the stream walk keeps per-row estimates in LDS) */

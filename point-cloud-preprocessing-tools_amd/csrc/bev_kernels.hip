@@ -489,20 +489,20 @@ __device__ __forceinline__ int wr_status(uint32_t fl) { return (int)(fl & 3u) - 
 __device__ __forceinline__ int wr_gflag(uint32_t fl) { return (int)((fl >> 2) & 3u) - 1; }
 
 enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcInPlace = 2 };
-constexpr int kWinPos = 272;       /* in-place source: window positions of a (row, strip): est - kWinLead ... */
+constexpr int kWinPos = kStripThreads; /* in-place source: window positions of a (row, strip), one per thread: est - kWinLead ... */
 constexpr int kWinLead = 12;
 constexpr int kWrapPos = 16;       /* ... the last strip's wrap-around halo: positions around the row's start */
 constexpr int kWrapLead = 6;
-/* bytes of one ring slot: window (272 x 32 B) + wrap-around positions (16 x 32 B) = 9 DMA pieces of 1 KiB, + tail points */
+/* bytes of one ring slot: the window's low halves (4 KiB), its high halves (4 KiB), then, 32 B each, the wrap-around
+ * positions and the tail points */
 constexpr int kInPlaceSlot = (kWinPos + kWrapPos + kTailCap) * 32;
 constexpr uint32_t kIdxTail = 1u << 30;
-constexpr int kTailLoads = kTailCap > 32 ? 5 : 4; /* loads per step of the in-place source's fourth wave: 2 window pieces, 1 list, 1 or 2 tail pieces */
 
 template <int kSrc, bool kPow2, bool kGm>
 __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
     constexpr bool kIdentity = kSrc == kSrcIdentity, kInPlace = kSrc == kSrcInPlace;
-    static_assert((kWinPos + kWrapPos) * 32 == 9 * 1024 && kTailCap <= 64 && kTailCap % 16 == 0, "DMA pieces of the in-place source");
+    static_assert(kWinPos == 256 && kStripVirt + 16 <= kWinPos && kTailCap == 64 && kWrapPos == 16, "DMA pieces of the in-place source");
     int f, strip;
     if (!map_block_xcd(blockIdx.x, nf, g.strips, f, strip)) return;
     if (!kIdentity && b.info && b.info[f].mode != want_mode) return; /* another launch of the walk has the frame */
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
     auto lane_from = [&](int sel, uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)x); };
     auto lane_from_f = [&](int sel, float x) -> float { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)__float_as_uint(x))); };
     const int v = strip * kStripCols + tid - 2;                      /* virtual column */
-    const bool provider = (v < H + 2) && (v >= 0 || strip == 0);     /* has a slot */
+    const bool provider = tid < kStripVirt && (v < H + 2) && (v >= 0 || strip == 0); /* has a slot */
     const bool outcol = tid >= 2 && tid < 2 + kStripCols && v < H;   /* owns column v's outputs */
     const int vcol = v >= H ? v - H : v;                             /* wrap; v < 0 keeps the flat rule */
 
@@ -527,7 +527,8 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
      * second.  In place: by window position, 32 B each, then the wrap-around positions, then the tail points */
     __shared__ __attribute__((aligned(16))) char ring[3 * kSlotBytes];
     __shared__ uint32_t wring[kSrc == kSrcGather ? 3 : 1][kStripThreads]; /* raw winner words of rows r+2, r+3, r+4 */
-    __shared__ uint32_t idx[kInPlace ? 2 : 1][kInPlace ? kStripThreads : 1]; /* column offset -> position + 1 | tail key */
+    __shared__ uint32_t idx[kInPlace ? 2 : 1][kInPlace ? kStripThreads + 1 : 1]; /* column offset -> position + 1 | tail key ([256]: nowhere) */
+    __shared__ u32x4 zero16[kInPlace ? 1 : 1];                               /* what an empty slot reads */
     __shared__ uint32_t tlist[kInPlace ? 3 : 1][kInPlace ? 64 : 1];       /* tail lists of rows r+2, r+3, r+4 */
     __shared__ int est_l[2][kInPlace ? kStreamMaxRows : 1];
     __shared__ uint8_t tcnt_l[kInPlace ? kStreamMaxRows : 1];
@@ -547,6 +548,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
     if constexpr (kInPlace) {
         idx[0][tid] = 0u;
         idx[1][tid] = 0u;
+        if (tid == 0) zero16[0] = u32x4{0u, 0u, 0u, 0u};
         const uint32_t *fe = b.est + (size_t)f * N * strips;
         const uint32_t *fc = b.tail_cnt + (size_t)f * N * strips;
         for (int r = tid; r < N; r += kStripThreads) {
@@ -596,97 +598,88 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
     const bool last_strip = strip == strips - 1;
     const int first_col = strip * kStripCols - 2; /* virtual column of offset 0 */
     const int own_cols = (H - first_col - 2) < kStripCols ? (H - first_col - 2) : kStripCols; /* own columns of this strip */
-    const int row_span = (H - first_col) < kStripThreads ? (H - first_col) : kStripThreads;  /* offsets that belong to the row */
-    /* (row | col << 16) of the thread's slot in row 0 (the tail of row -1 for strip 0's left halo: never there; column
-     * 0xffff for threads without a slot: never there either) */
-    const uint32_t slot_rc = !provider ? 0xffff0000u : (v < 0 ? ((uint32_t)(H + v) << 16) + 0xffffffffu : (uint32_t)vcol << 16);
+    const int row_span = (H - first_col) < kStripVirt ? (H - first_col) : kStripVirt;        /* offsets that belong to the row */
     const uint32_t *ftail = kInPlace ? b.tail_list + ((size_t)f * N * strips + strip) * kTailCap : nullptr;
     const int tail_stride = strips * kTailCap;  /* words from one row's list to the next */
     const uint32_t tlist_l = __builtin_amdgcn_readfirstlane(lds_addr(&tlist[0][0]));
     uint32_t te[3] = {0u, 0u, 0u}; /* wave 3: this lane's tail entry of rows q at [q % 3] (column offset | input index << 8) */
     uint32_t consumed = 0u, failed = 0u;
-    auto src_of = [&](int q, int half) -> const Half * { /* half of the point at input position q, or of position 0 outside the prefix */
-        return reinterpret_cast<const Half *>(fpts + ((unsigned)q < T ? q : 0)) + half;
+    const char *fbytes = reinterpret_cast<const char *>(fpts);
+    auto pos_addr = [&](int q) -> const char * { /* the point at input position q, or position 0 outside the prefix */
+        return fbytes + (size_t)((unsigned)q < T ? q : 0) * 32u;
     };
-    auto issue_window = [&](int q, int slot) { /* this wave's two pieces of row q's window (32 positions each) */
+    auto issue_window = [&](int q, int slot) { /* this wave's 64 positions of row q's window: low halves, high halves */
         const int e = est_l[0][clamp_row(q)] - kWinLead;
-        const uint32_t at = ring_l + (uint32_t)slot * kSlotBytes + (uint32_t)wv * 2048u;
-        glds16x2(src_of(e + wv * 64 + (lane >> 1), lane & 1), at, src_of(e + wv * 64 + 32 + (lane >> 1), lane & 1), at + 1024u);
+        const uint32_t at = ring_l + (uint32_t)slot * kSlotBytes + (uint32_t)wv * 1024u;
+        const char *src = (e >= 0 && e + kWinPos <= (int)T) ? fbytes + (size_t)(uint32_t)(e + tid) * 32u /* wave-uniform test */
+                                                            : pos_addr(e + tid);
+        glds16x2(src, at, src + 16, at + 4096u);
     };
-    auto issue_extra = [&](int q, int slot) { /* wave 0: positions 256 .. 271 of the window and the wrap-around positions */
-        const int rc = clamp_row(q);
-        const int pos = lane < 32 ? est_l[0][rc] - kWinLead + 256 + (lane >> 1) : est_l[1][rc] - kWrapLead + ((lane - 32) >> 1);
-        glds16(src_of(pos, lane & 1), ring_l + (uint32_t)slot * kSlotBytes + 8192u);
+    auto issue_wrap = [&](int q, int slot) { /* last strip, wave 2: the positions around the row's start, 32 B each */
+        if (lane < 2 * kWrapPos)
+            glds16(pos_addr(est_l[1][clamp_row(q)] - kWrapLead + (lane >> 1)) + 16 * (lane & 1), ring_l + (uint32_t)slot * kSlotBytes + 8192u);
     };
     auto issue_tail_list = [&](int q, int slot) { /* wave 3: the (row, strip)'s list, 64 words (stale past the count) */
         glds4_nt(ftail + (size_t)clamp_row(q) * tail_stride + lane, tlist_l + (uint32_t)slot * 256u);
     };
-    auto issue_tail_points = [&](int q, int slot, int tslot) { /* wave 3: the listed points of row q beside its window */
+    auto issue_tail_points = [&](int q, int slot, int tslot) { /* wave 3: the listed points of row q beside its window, 32 B each */
         const int n = q < N ? (int)tcnt_l[clamp_row(q)] : 0;
         te[tslot] = tlist[tslot][lane];
         const uint32_t ea = tlist[tslot][lane >> 1], eb = tlist[tslot][32 + (lane >> 1)];
-        const uint32_t at = ring_l + (uint32_t)slot * kSlotBytes + (uint32_t)(kWinPos + kWrapPos) * 32u;
-        glds16(reinterpret_cast<const Half *>(fpts + ((lane >> 1) < n ? (ea >> 8) : 0u)) + (lane & 1), at);
-        if (kTailCap > 32 && lane < 2 * (kTailCap - 32)) /* (the piece ends with the slot) */
-            glds16(reinterpret_cast<const Half *>(fpts + (32 + (lane >> 1) < n ? (eb >> 8) : 0u)) + (lane & 1), at + 1024u);
+        const uint32_t at = ring_l + (uint32_t)slot * kSlotBytes + 8192u + (uint32_t)kWrapPos * 32u;
+        glds16x2(fbytes + (size_t)((lane >> 1) < n ? (ea >> 8) : 0u) * 32u + 16 * (lane & 1), at,
+                 fbytes + (size_t)(32 + (lane >> 1) < n ? (eb >> 8) : 0u) * 32u + 16 * (lane & 1), at + 1024u);
     };
+    /* Row rho's positions -> idx[rho & 1].  Every thread enters ITS window position, counts and checks it: the predecessor
+     * in the input must lie in the prefix and have a smaller slot (the lane to the left has it; window position 0 cannot
+     * be checked: the estimate was too high).  The first lane of a wave follows a position that ANOTHER wave's DMA brings:
+     * that check is made after the step's barrier.  Written without branches: an entry that belongs nowhere goes to the
+     * spare word idx[.][256]. */
+    bool dneed = false;
+    int dflat = 0, dq = 0;
     auto slot_or_max = [&](int q, uint32_t rcw) -> int { /* slot of input position q, INT_MAX outside the prefix / the range image */
         const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
-        const bool valid = (unsigned)q < T && row < (uint32_t)N && col < (uint32_t)H;
-        return valid ? (int)row * H + (int)col : 0x7fffffff;
+        const bool valid = ((unsigned)q < T) & (row < (uint32_t)N) & (col < (uint32_t)H);
+        return valid ? (int)(row * (uint32_t)H + col) : 0x7fffffff;
     };
-    /* one window position into the index row, counted and checked.  Its predecessor in the input must lie in the prefix
-     * and have a smaller slot; window position 0 cannot be checked (the estimate was too high).  The first position of a
-     * wave's piece follows a position that ANOTHER wave's DMA brings: that check is made after the step's barrier. */
-    bool dneed = false;
-    int dflat = 0, dq = 0, dp = 0;
-    auto enter = [&](int rho, const char *slot_b, uint32_t *irow, int p) {
-        const int q = est_l[0][rho] - kWinLead + p;
-        const uint32_t rcw = *reinterpret_cast<const uint32_t *>(slot_b + p * 32 + 20);
-        const uint32_t rcp = *reinterpret_cast<const uint32_t *>(slot_b + (p > 0 ? p - 1 : 0) * 32 + 20);
-        const int sflat = slot_or_max(q, rcw);
-        const int off = (int)((uint32_t)sflat - (uint32_t)(rho * H + first_col));
-        /* (a window of the last strip runs into the next row: those points are not this row's wrap-around halo) */
-        if ((unsigned)off < (unsigned)row_span) atomicMax(&irow[off], (uint32_t)p + 1u);
-        const bool own = (unsigned)(off - 2) < (unsigned)own_cols;
-        consumed += own ? 1u : 0u;
-        const bool chk = own && q > 0;
-        const bool foreign = (p & 63) == 0 && p > 0; /* position p - 1 is another wave's */
-        failed |= (chk && !foreign && (p == 0 || !(slot_or_max(q - 1, rcp) < sflat))) ? 1u : 0u;
-        if (foreign) {
-            dneed = chk;
-            dflat = sflat;
-            dq = q;
-            dp = p;
-        }
-    };
-    auto deferred_check = [&](const char *slot_b) { /* after the barrier: every wave's pieces of the row have arrived */
-        const uint32_t rcp = *reinterpret_cast<const uint32_t *>(slot_b + (dp > 0 ? dp - 1 : 0) * 32 + 20);
-        failed |= (dneed && !(slot_or_max(dq - 1, rcp) < dflat)) ? 1u : 0u;
-        dneed = false;
-    };
-    auto index_row = [&](int rho, int slot, int tslot) { /* row rho's window, wrap-around and tail positions -> idx[rho & 1] */
+    auto index_row = [&](int rho, int slot, int tslot) {
         if (rho >= N) return;
         const char *slot_b = &ring[slot * kSlotBytes];
         uint32_t *irow = idx[rho & 1];
-        enter(rho, slot_b, irow, tid);
-        if (wv == 0) { /* wave-uniform */
-            if (lane < kWinPos - 256) {
-                enter(rho, slot_b, irow, 256 + lane);
-            } else if (last_strip && lane >= 32 && lane < 32 + kWrapPos) { /* slots rho*H and rho*H + 1 as the halo columns H, H + 1 */
-                const int p = kWinPos + (lane - 32);
-                const int q = est_l[1][rho] - kWrapLead + (lane - 32);
-                const uint32_t rcw = *reinterpret_cast<const uint32_t *>(slot_b + p * 32 + 20);
-                const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
-                const int off = H + (int)col - first_col;
-                if ((unsigned)q < T && row == (uint32_t)rho && col < 2u && (unsigned)off < (unsigned)kStripThreads)
-                    atomicMax(&irow[off], (uint32_t)p + 1u);
-            }
+        const uint32_t base = (uint32_t)(rho * H + first_col);
+        {
+            const int q = est_l[0][rho] - kWinLead + tid;
+            const u32x4 hi = *reinterpret_cast<const u32x4 *>(slot_b + 4096 + tid * 16); /* (conflict-free; only .y is used) */
+            const int sflat = slot_or_max(q, hi.y);
+            const uint32_t off = (uint32_t)sflat - base;
+            /* (a window of the last strip runs into the next row: those points are not this row's wrap-around halo) */
+            atomicMax(&irow[off < (uint32_t)row_span ? off : (uint32_t)kStripThreads], (uint32_t)tid + 1u);
+            const bool own = (off - 2u) < (uint32_t)own_cols;
+            consumed += own ? 1u : 0u;
+            const int pflat = __builtin_amdgcn_update_dpp(0x7fffffff, sflat, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const bool chk = own & (q > 0);
+            failed |= (chk & ((tid == 0) | ((lane != 0) & !(pflat < sflat)))) ? 1u : 0u;
+            dneed = chk & (lane == 0) & (tid != 0);
+            dflat = sflat;
+            dq = q;
         }
-        if (wv == 3 && lane < (int)tcnt_l[rho]) { /* later input index beats earlier, any tail point beats the prefix */
+        if (last_strip && wv == 2) { /* wave-uniform: slots rho*H and rho*H + 1 as the halo columns H, H + 1 */
+            const int k = lane & (kWrapPos - 1);
+            const int q = est_l[1][rho] - kWrapLead + k;
+            const uint32_t rcw = *reinterpret_cast<const uint32_t *>(slot_b + 8192 + k * 32 + 20);
+            const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
+            const uint32_t off = (uint32_t)(H - first_col) + col;
+            const bool ok = (lane < kWrapPos) & ((unsigned)q < T) & (row == (uint32_t)rho) & (col < 2u) & (off < (uint32_t)kStripVirt);
+            atomicMax(&irow[ok ? off : (uint32_t)kStripThreads], (uint32_t)(kWinPos + k) + 1u);
+        }
+        if (wv == 3) { /* later input index beats earlier, any tail point beats the prefix */
             const uint32_t e = te[tslot];
-            atomicMax(&irow[e & 0xffu], kIdxTail | ((e >> 8) << 6) | (uint32_t)lane);
+            atomicMax(&irow[lane < (int)tcnt_l[rho] ? (e & 0xffu) : (uint32_t)kStripThreads], kIdxTail | ((e >> 8) << 6) | (uint32_t)lane);
         }
+    };
+    auto deferred_check = [&](const char *slot_b) { /* after the barrier: every wave's pieces of the row have arrived */
+        const uint32_t rcp = *reinterpret_cast<const uint32_t *>(slot_b + 4096 + (tid > 0 ? tid - 1 : 0) * 16 + 4);
+        failed |= (dneed && !(slot_or_max(dq - 1, rcp) < dflat)) ? 1u : 0u;
     };
 
     /* ---- prologue: the queue the row loop expects ---- */
@@ -697,13 +690,13 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         }
         wait_vm<0>();
         issue_window(0, 0);
-        if (wv == 0) issue_extra(0, 0);
+        if (last_strip && wv == 2) issue_wrap(0, 0);
         if (wv == 3) {
             issue_tail_points(0, 0, 0);
             issue_tail_list(2, 2);
         }
         issue_window(1, 1);
-        if (wv == 0) issue_extra(1, 1);
+        if (last_strip && wv == 2) issue_wrap(1, 1);
         if (wv == 3) {
             issue_tail_points(1, 1, 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* list 0 has been read before its slot is refilled */
@@ -769,12 +762,9 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
      * instalments and L2 writes some lines back in between (WRITE_SIZE 5.39 MB where 4.9 MB were stored).  Transposed
      * through 2 KiB of LDS each instruction stores 1 KiB of whole lines.  The 2 KiB are a piece of a ring slot that is
      * idle right now and that only this wave's own DMA refills: gather / identity: the slot of the row just consumed
-     * (this wave's two 1-KiB pieces, points 0..31 in the first); in place: the slot row r-1 has left (this wave's two
-     * consecutive window pieces). */
-    const uint32_t xp_w = kInPlace ? (uint32_t)wv * 2048u + (uint32_t)lane * 32u
-                                   : (uint32_t)wv * 1024u + (uint32_t)(lane & 31) * 32u + (lane < 32 ? 0u : 4096u);
-    const uint32_t xp_r1 = kInPlace ? (uint32_t)wv * 2048u + 1024u : (uint32_t)wv * 1024u + 4096u; /* second KiB */
-    const uint32_t xp_r0 = kInPlace ? (uint32_t)wv * 2048u : (uint32_t)wv * 1024u;
+     * (this wave's two 1-KiB pieces, points 0..31 in the first); in place: the same pieces of the slot row r-1 has left. */
+    const uint32_t xp_w = (uint32_t)wv * 1024u + (uint32_t)(lane & 31) * 32u + (lane < 32 ? 0u : 4096u);
+    const uint32_t xp_r0 = (uint32_t)wv * 1024u, xp_r1 = (uint32_t)wv * 1024u + 4096u; /* first, second KiB */
 
     auto row_step = [&](auto I, const int r) {
         constexpr int s0 = decltype(I)::value % 3;         /* ring slot of row r (and of row r + 3) */
@@ -787,8 +777,8 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         /* Everything but the newest step's loads has arrived: the points (window) of row r, the winner words (tail list)
          * of row r + 2.  A wave waits for as many operations as it issues loads per step. */
         if constexpr (kInPlace) {
-            if (wv == 0) wait_vm<3>();
-            else if (wv == 3) wait_vm<kTailLoads>();
+            if (wv == 3) wait_vm<5>();                    /* 2 window pieces, 1 list, 2 tail pieces */
+            else if (last_strip && wv == 2) wait_vm<3>(); /* 2 window pieces, the wrap-around positions */
             else wait_vm<2>();
             index_row(r, s0, s0);
         } else {
@@ -820,12 +810,15 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
             if (lane == 0) deferred_check(&ring[s0 * kSlotBytes]);
             const uint32_t e = idx[par][tid];
             idx[par][tid] = 0u; /* (the row after next enters here, two barriers from now) */
-            const uint32_t pos = (e & kIdxTail) ? (uint32_t)(kWinPos + kWrapPos) + (e & 63u) : (e ? e - 1u : 0u);
-            const char *src = &ring[s0 * kSlotBytes] + pos * 32u;
-            const u32x4 a = *reinterpret_cast<const u32x4 *>(src), c = *reinterpret_cast<const u32x4 *>(src + 16);
-            const bool hit = e != 0u && r < N && c.y == slot_rc + (uint32_t)r;
-            cur_lo = u32x4{hit ? a.x : 0u, hit ? a.y : 0u, hit ? a.z : 0u, hit ? a.w : 0u};
-            cur_hi = u32x4{hit ? c.x : 0u, hit ? c.y : 0u, hit ? c.z : 0u, hit ? c.w : 0u};
+            const uint32_t pos = (e & kIdxTail) ? (uint32_t)(kWinPos + kWrapPos) + (e & 63u) : e - 1u;
+            const bool inwin = pos < (uint32_t)kWinPos;
+            const uint32_t lo_at = inwin ? pos * 16u : 8192u + (pos - (uint32_t)kWinPos) * 32u;
+            const char *slot_b = &ring[s0 * kSlotBytes];
+            const bool have = (e != 0u) & (r < N);
+            /* (an entry leads to a point whose (row, col) ARE this slot's: the offset it was entered at was computed from
+             * them; in a frame where that fails — two prefix points of one slot — the order check fails as well) */
+            cur_lo = *(have ? reinterpret_cast<const u32x4 *>(slot_b + lo_at) : &zero16[0]);
+            cur_hi = *(have ? reinterpret_cast<const u32x4 *>(slot_b + lo_at + (inwin ? 4096u : 16u)) : &zero16[0]);
         }
         const XYZI prev{__uint_as_float(p1.lo.x), __uint_as_float(p1.lo.y), __uint_as_float(p1.lo.z), __uint_as_float(p1.hi.x)};
         const XYZI prevprev{__uint_as_float(p2.lo.x), __uint_as_float(p2.lo.y), __uint_as_float(p2.lo.z), __uint_as_float(p2.hi.x)};
@@ -898,7 +891,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave is done reading the pieces it refills */
         if constexpr (kInPlace) {
             issue_window(r + 2, s2);
-            if (wv == 0) issue_extra(r + 2, s2);
+            if (last_strip && wv == 2) issue_wrap(r + 2, s2);
             if (wv == 3) {
                 issue_tail_points(r + 2, s2, s2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
