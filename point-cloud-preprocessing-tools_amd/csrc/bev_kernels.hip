@@ -54,6 +54,9 @@ using namespace bevx;
 #define PHA_PRINT(name, cond)
 #endif
 
+#ifndef BEV_SEENB
+#define BEV_SEENB 8
+#endif
 namespace bevk {
 
 static const char *const kNames[K_COUNT] = {
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
 
     constexpr int kWaves = kStripThreads / 64;
     constexpr int kSlotBytes = kInPlace ? kInPlaceSlot : 8192;
-    constexpr int kSeenB = kInPlace ? 8 : kSeenBits;       /* (the in-place source needs the LDS for its windows) */
+    constexpr int kSeenB = kInPlace ? BEV_SEENB : kSeenBits;       /* (the in-place source needs the LDS for its windows) */
     /* the points of rows r, r+1, r+2.  Gather / identity: by thread, low halves in the first 4 KiB, high halves in the
      * second.  In place: by window position, 32 B each, then the wrap-around positions, then the tail points */
     __shared__ __attribute__((aligned(16))) char ring[3 * kSlotBytes];
@@ -721,6 +724,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
     }
 
     WalkRow pr[3] = {};
+    PHA_DECL;
     float zref = __uint_as_float(0x7fc00000u); /* height of the column's last candidate taken for ground (NaN: none yet) */
 
     const size_t cand_base = (size_t)f * g.segs * kSeg;
@@ -774,15 +778,19 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         const int par = r & 1;
         u32x4 cur_lo, cur_hi;
         uint32_t wraw = 0u;
+        PHA(7);
         /* Everything but the newest step's loads has arrived: the points (window) of row r, the winner words (tail list)
          * of row r + 2.  A wave waits for as many operations as it issues loads per step. */
         if constexpr (kInPlace) {
             if (wv == 3) wait_vm<5>();                    /* 2 window pieces, 1 list, 2 tail pieces */
             else if (last_strip && wv == 2) wait_vm<3>(); /* 2 window pieces, the wrap-around positions */
             else wait_vm<2>();
+            PHA(0);
             index_row(r, s0, s0);
+            PHA(1);
         } else {
             wait_vm<kIdentity ? 2 : 3>();
+            PHA(0);
             const char *mine = &ring[s0 * kSlotBytes + tid * 16];
             cur_lo = *reinterpret_cast<const u32x4 *>(mine);
             cur_hi = *reinterpret_cast<const u32x4 *>(mine + 4096);
@@ -804,6 +812,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
             if (lane == 0) wave_cnt[par][wv] = (uint32_t)__popcll(m2);
         }
         lds_barrier();
+        PHA(2);
         if constexpr (kInPlace) {
             /* the column's owner follows its index entry: a window / wrap-around position, or a tail point; an entry
              * whose (row, col) is not the slot's own is an empty slot (value-initialised, BatchMultiBevGen.cpp:98) */
@@ -825,6 +834,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         const XYZI cur{__uint_as_float(cur_lo.x), __uint_as_float(cur_lo.y), __uint_as_float(cur_lo.z), __uint_as_float(cur_hi.x)};
 
         /* ---- write out row r-2 (first thing after the barrier: its stores are the oldest entries of the step) ---- */
+        PHA(3);
         const bool cand2 = outcol && wr_gflag(p2.fl) == 1;
         if (r >= 2) {
             const int q = r - 2;
@@ -888,6 +898,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
             }
         }
         /* ---- the loads of this step, behind its stores: row r + 2 (and the winner words / tail list of row r + 4) ---- */
+        PHA(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave is done reading the pieces it refills */
         if constexpr (kInPlace) {
             issue_window(r + 2, s2);
@@ -905,6 +916,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         }
 
         /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
+        PHA(5);
         int s_r = kSteep;
         if (r >= lo_row && r < N) { /* workgroup-uniform */
             /* row r-1 of the threads two to the right / left */
@@ -924,6 +936,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         }
 
         /* ---- ground_mat of row r-1 is now decided (closed form, see bev_exact.h) ---- */
+        PHA(6);
         int gf = 0;
         {
             const int q = r - 1, st1 = wr_status(p1.fl);
@@ -975,6 +988,8 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         if (r0 + 2 < N + 2) row_step(std::integral_constant<int, 2>{}, r0 + 2);
     }
     wait_vm<0>(); /* no LDS-DMA may outlive the workgroup's LDS */
+    PHA_PRINT(kInPlace ? "walk_inplace vmwait index barrier acquire writeout issue status rest" : "walk_gather vmwait - barrier acquire writeout issue status rest",
+              lane == 0 && blockIdx.x == 1000);
     lds_barrier();
     if (tid < bands) b.ncode[((size_t)f * g.emitters + strip) * bands + tid] = band_cursor[tid];
     if constexpr (kInPlace) {
