@@ -483,6 +483,28 @@ __device__ __forceinline__ T in_vgpr(T v)
     asm volatile("" : "+v"(v));
     return v;
 }
+/* bev_code / bev_code_from_bins (bev_exact.h) with the reciprocal / divide choice made at compile time: interval and
+ * height_res are powers of two in every configuration of the reference, and x / 2^k == x * 2^-k bit for bit */
+template <bool kPow2>
+__device__ __forceinline__ uint32_t code_from_bins_t(int x, int y, float pz, const RasterParams &rp)
+{
+    const float hq = kPow2 ? pz * rp.inv_height_res : pz / rp.height_res;
+    const int layer = cvtt_f32(roundf(hq + rp.lidar_to_ground)); /* BatchMultiBevGen.cpp:281 */
+    int h = height_times4(pz + rp.lidar_to_ground);              /* :345 */
+    h = h < 0 ? 0 : (h > 255 ? 255 : h);                         /* :346 */
+    const uint32_t l = (layer >= 0 && layer < rp.n_layers) ? (uint32_t)layer : kNoLayer;
+    return (uint32_t)x | ((uint32_t)y << 9) | ((uint32_t)h << 18) | (l << 26);
+}
+template <bool kPow2>
+__device__ __forceinline__ uint32_t code_t(float px, float py, float pz, int label, const RasterParams &rp)
+{
+    const float sx = px + rp.max_range_f, sy = py + rp.max_range_f;
+    const int x = round_half_up_bin(kPow2 ? sx * rp.inv_interval : sx / rp.interval); /* :279, :343 */
+    const int y = round_half_up_bin(kPow2 ? sy * rp.inv_interval : sy / rp.interval); /* :280, :344 */
+    const bool in = (label != 0) & ((unsigned)x < (unsigned)rp.mat_size) & ((unsigned)y < (unsigned)rp.mat_size); /* :285, :349 */
+    const uint32_t code = code_from_bins_t<kPow2>(in ? x : 0, in ? y : 0, pz, rp);
+    return in ? code : kSkip;
+}
 /* row record of the walk: flags = (status + 1) | (ground_mat + 1) << 2 | pred << 4 */
 struct WalkRow {
     u32x4 lo, hi;
@@ -746,21 +768,6 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         rp.interval = in_vgpr(rp.interval);
         rp.height_res = in_vgpr(rp.height_res);
     }
-    auto bin_of = [&](float p) -> int { /* bev_bin_rp with the reciprocal / divide choice made at compile time */
-        const float s = p + rp.max_range_f;
-        return round_half_up_bin(kPow2 ? s * rp.inv_interval : s / rp.interval);
-    };
-    auto code_of = [&](float px, float py, float pz, int label) -> uint32_t { /* bev_code, BatchMultiBevGen.cpp:279-285, :343-349 */
-        const int x = bin_of(px), y = bin_of(py);
-        const bool in = (label != 0) & ((unsigned)x < (unsigned)rp.mat_size) & ((unsigned)y < (unsigned)rp.mat_size);
-        const float hq = kPow2 ? pz * rp.inv_height_res : pz / rp.height_res;
-        const int layer = cvtt_f32(roundf(hq + rp.lidar_to_ground)); /* :281 */
-        int h = height_times4(pz + rp.lidar_to_ground);              /* :345 */
-        h = h < 0 ? 0 : (h > 255 ? 255 : h);                         /* :346 */
-        const uint32_t l = (layer >= 0 && layer < rp.n_layers) ? (uint32_t)layer : kNoLayer;
-        const uint32_t code = (uint32_t)(in ? x : 0) | ((uint32_t)(in ? y : 0) << 9) | ((uint32_t)h << 18) | (l << 26);
-        return in ? code : kSkip;
-    };
     /* A wave's 64 finished points are 2 KiB of consecutive bytes of the output.  Stored as they sit in the registers — the
      * low halves with one instruction, the high halves with another — every 128-byte line leaves the CU in two
      * instalments and L2 writes some lines back in between (WRITE_SIZE 5.39 MB where 4.9 MB were stored).  Transposed
@@ -972,7 +979,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         p0.hi = cur_hi;
         p0.fl = (uint32_t)(s_r + 1) | (1u << 2);
         p0.key = 0u;
-        p0.code = code_of(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w & 0xffffu));
+        p0.code = code_t<kPow2>(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w & 0xffffu), rp);
 
         /* ---- in place: published for the next step: row r's edge lanes, the candidates of row r-1 per wave ---- */
         if constexpr (kInPlace) {
@@ -1351,7 +1358,9 @@ __global__ __launch_bounds__(256) void k_cloud_codes(const bev_point_t *__restri
  * kResolveParts workgroups per frame, each takes a contiguous quarter of the segments; a wave requests kResolveBatch
  * segments (x 4 slices of 64 candidates) at a time. */
 constexpr int kResolveBatch = 4;
-template <bool kIdentity>
+/* (round 3: the raster constants in vector registers and stores through address-space-1 pointers, as in the walk — a
+ * quarter of this kernel's vector instructions were v_readlane restores of spilled 8-dword argument tuples) */
+template <bool kPow2>
 __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b, Geometry g)
 {
     __shared__ float avg[kCells];                        /* the frame's 75 x 50 averages: 4 look-ups per candidate */
@@ -1360,12 +1369,10 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
     __shared__ uint8_t band_tab[512];                    /* x bin -> raster band */
     __shared__ uint16_t cnt[kMaxSegs / kResolveParts + 8];
     const int f = blockIdx.x / kResolveParts, part = blockIdx.x - f * kResolveParts;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = g.segs;
     const int t0 = (int)((long long)T * part / kResolveParts), t1 = (int)((long long)T * (part + 1) / kResolveParts);
-    for (int i = tid; i < t1 - t0; i += kResolveThreads) {
-        cnt[i] = (uint16_t)b.ncand[(size_t)f * T + t0 + i];
-    }
+    for (int i = tid; i < t1 - t0; i += kResolveThreads) cnt[i] = (uint16_t)b.ncand[(size_t)f * T + t0 + i];
     for (int c = tid; c < kCells; c += kResolveThreads) avg[c] = b.avg[(size_t)f * kCells + c];
     if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
     else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
@@ -1375,9 +1382,26 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
 
     constexpr int kSl = kSeg / 64;
     constexpr int kWaves = kResolveThreads / 64;
-    const int bands = g.raster_bands, lo_row = g.N - g.G;
+    const int bands = g.raster_bands, lo_row = g.N - g.G, H = g.H, strips = g.strips;
     const uint2 *fcand = b.cand + (size_t)f * T * kSeg; /* key | height */
-    uint32_t *flist = b.code_main + ((size_t)f * g.emitters + g.strips + part) * bands * (size_t)g.code_cap;
+    const uint32_t code_cap = g.code_cap;
+    const gptr<uint32_t> flist = (gptr<uint32_t>)(b.code_main + ((size_t)f * g.emitters + g.strips + part) * bands * (size_t)code_cap);
+    const gptr<uint16_t> flabel = (gptr<uint16_t>)(b.ordered + (size_t)f * g.S); /* label @28 of point i: [16 * i + 14] */
+    const bev_point_t *fordered = b.ordered + (size_t)f * g.S;
+    RasterParams rp = g.rp; /* the fields the BEV code needs, in vector registers */
+    rp.max_range_f = in_vgpr(rp.max_range_f);
+    rp.lidar_to_ground = in_vgpr(rp.lidar_to_ground);
+    rp.mat_size = in_vgpr(rp.mat_size);
+    rp.n_layers = in_vgpr(rp.n_layers);
+    if (kPow2) {
+        rp.inv_interval = in_vgpr(rp.inv_interval);
+        rp.inv_height_res = in_vgpr(rp.inv_height_res);
+    } else {
+        rp.interval = in_vgpr(rp.interval);
+        rp.height_res = in_vgpr(rp.height_res);
+        rp.inv_interval = 0.0f;
+        rp.inv_height_res = 0.0f;
+    }
     for (int s0 = t0 + wv; s0 < t1; s0 += kWaves * kResolveBatch) {
         uint32_t key[kResolveBatch][kSl];
         float z[kResolveBatch][kSl];
@@ -1401,8 +1425,8 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
         for (int j = 0; j < kResolveBatch; ++j) {
             const int sg = s0 + j * kWaves;
             const int n = sg < t1 ? (int)cnt[sg - t0] : 0;
-            const int rr = sg / g.strips, strip = sg - rr * g.strips;
-            const size_t slot0 = (size_t)f * g.S + (size_t)(rr + lo_row - 1) * g.H + (size_t)strip * kStripCols;
+            const int rr = sg / strips, strip = sg - rr * strips;
+            const uint32_t slot0 = (uint32_t)((rr + lo_row - 1) * H + strip * kStripCols);
 #pragma unroll
             for (int k = 0; k < kSl; ++k) {
                 if (64 * k >= n) break; /* wave-uniform */
@@ -1413,26 +1437,25 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
                 const bool pred = (kk & kKeyPredBit) != 0u;
                 const bool wrong = have && hit != pred;
                 if (!__ballot(hit || wrong)) continue; /* wave-uniform */
-                const size_t idx = slot0 + ((kk >> kKeyColShift) & 0xffu);
+                const uint32_t idx = slot0 + ((kk >> kKeyColShift) & 0xffu);
                 if (hit && !(kk & kKeyNoCodeBit)) {
                     uint32_t code;
                     if (!candidate_key_escapes(kk)) {
-                        code = bev_code_from_bins(edge_x[cell / kGridCols] + (int)((kk >> kKeyDxShift) & 3u),
-                                                  edge_y[cell % kGridCols] + (int)((kk >> kKeyDyShift) & 3u), z[j][k], g.rp);
+                        code = code_from_bins_t<kPow2>(edge_x[cell / kGridCols] + (int)((kk >> kKeyDxShift) & 3u),
+                                                       edge_y[cell % kGridCols] + (int)((kk >> kKeyDyShift) & 3u), z[j][k], rp);
                     } else { /* cell clamped or bins not next to the cell's edge: x, y from the point itself */
-                        const float4 a = *reinterpret_cast<const float4 *>(b.ordered + idx);
-                        code = bev_code(a.x, a.y, a.z, 1 /* not 0: no kKeyNoCodeBit */, g.rp);
+                        const float4 a = *reinterpret_cast<const float4 *>(fordered + idx);
+                        code = code_t<kPow2>(a.x, a.y, a.z, 1 /* not 0: no kKeyNoCodeBit */, rp);
                     }
                     if (code != kSkip) {
                         const int band = band_tab[code_x(code)];
-                        flist[(size_t)band * g.code_cap + atomicAdd(&band_cursor[band], 1u)] = code;
+                        flist[(uint32_t)band * code_cap + atomicAdd(&band_cursor[band], 1u)] = code;
                     }
                 }
                 if (wrong) { /* the walk's provisional label differs */
                     /* not un-grounded: label = 0, BatchMultiBevGen.cpp:245; un-grounded: the point's own label back —
                      * which is -2: the walk guesses "stays ground" only for points that carry it */
-                    const uint16_t label = hit ? (uint16_t)(int16_t)-2 : (uint16_t)0;
-                    reinterpret_cast<uint16_t *>(b.ordered + idx)[14] = label; /* label @28 */
+                    flabel[16u * idx + 14u] = hit ? (uint16_t)(int16_t)-2 : (uint16_t)0;
                 }
             }
         }
@@ -1495,9 +1518,13 @@ __device__ __forceinline__ void store_planes(const uint32_t *mask, const uint32_
                 uint32_t w[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    /* byte = 255 where bit l of the mask is set */
-                    w[q] = (((mk[4 * q] >> l) & 1u) * 0xffu) | (((mk[4 * q + 1] >> l) & 1u) * 0xff00u) |
-                           (((mk[4 * q + 2] >> l) & 1u) * 0xff0000u) | (((mk[4 * q + 3] >> l) & 1u) * 0xff000000u);
+                    /* byte = 255 where bit l of the mask is set: the bit, sign-extended, is 0 or 0xffffffff (v_bfe_i32);
+                     * three byte permutes put one byte of each of the four cells side by side (7 instructions per word
+                     * where shift / and / multiply / or took 15) */
+                    const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)mk[4 * q], l, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)mk[4 * q + 1], l, 1);
+                    const uint32_t m2 = (uint32_t)__builtin_amdgcn_sbfe((int)mk[4 * q + 2], l, 1), m3 = (uint32_t)__builtin_amdgcn_sbfe((int)mk[4 * q + 3], l, 1);
+                    const uint32_t t01 = __builtin_amdgcn_perm(m1, m0, 0x0c0c0400u), t23 = __builtin_amdgcn_perm(m3, m2, 0x0c0c0400u);
+                    w[q] = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
                 }
                 store_stream(reinterpret_cast<uint4 *>(mout + (size_t)l * plane), make_uint4(w[0], w[1], w[2], w[3]));
             }
@@ -1844,11 +1871,11 @@ void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t
 }
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st)
 {
+    (void)identity; /* (the escape branch reads the point from the ordered cloud either way) */
     if (nf == 0) return;
-    if (identity)
-        hipLaunchKernelGGL(k_ground_resolve<true>, dim3(nf * kResolveParts), dim3(kResolveThreads), 0, st, b, g);
-    else
-        hipLaunchKernelGGL(k_ground_resolve<false>, dim3(nf * kResolveParts), dim3(kResolveThreads), 0, st, b, g);
+    const bool pow2 = g.rp.inv_interval != 0.0f && g.rp.inv_height_res != 0.0f;
+    if (pow2) hipLaunchKernelGGL(k_ground_resolve<true>, dim3(nf * kResolveParts), dim3(kResolveThreads), 0, st, b, g);
+    else hipLaunchKernelGGL(k_ground_resolve<false>, dim3(nf * kResolveParts), dim3(kResolveThreads), 0, st, b, g);
 }
 void launch_bev_raster(const Geometry &g, const BatchPtrs &b, bool want_multi, bool want_single, int nf, hipStream_t st)
 {
