@@ -87,6 +87,22 @@ BEVX_HD bool angle_is_ground(float dx, float dy, float dz)
     return ((a == 0.0f) & (s == 0.0f)) | (q <= bits_to_float(kTanThresholdBits)); /* atan2f(+-0, +0) = +-0 */
 }
 BEVX_HD bool angle_is_ground_flat(float dx, float dy, float dz) { return angle_is_ground(dx, dy, dz); }
+/* The same predicate without the division (a dozen instructions on the device).  With T = kTanThreshold (odd mantissa)
+ * and T' its successor, fl32(a / s) <= T  <=>  a / s < M = (T + T') / 2: below the midpoint the quotient rounds to T or
+ * less, AT the midpoint the tie goes to the even neighbour T', above it to T' or more.  For s > 0 that is a < M * s, and
+ * in double the product of the 25-bit M and a 24-bit float is exact.  s = 0: a < 0 is false like a / 0 = inf <= T
+ * (a > 0) — the (0, 0) case is the explicit first clause, as above; a NaN anywhere compares false on both sides; an
+ * infinite s gives 0 <= T on one side and a < inf on the other.  tests/hostcheck: hc_angle_nodiv_check (random and
+ * threshold-straddling pairs, 0 mismatches). */
+BEVX_HD bool angle_is_ground_nodiv(float dx, float dy, float dz)
+{
+    const float xx = dx * dx;
+    const float yy = dy * dy;
+    const float s = sqrtf(xx + yy);
+    const float a = fabsf(dz);
+    const double mid = 0.5 * ((double)bits_to_float(kTanThresholdBits) + (double)bits_to_float(kTanThresholdBits + 1u));
+    return ((a == 0.0f) & (s == 0.0f)) | ((double)a < mid * (double)s);
+}
 
 /* getBelongingGrid, BatchMultiBevGen.h:73-99 -> cell = row * 50 + col.
  * The reference mixes float and double here; every step has an exact float-only equivalent
@@ -109,6 +125,18 @@ BEVX_HD int ground_cell(float x, float y)
     if (r < 0) r = 0;
     if (c >= kGridCols) c = kGridCols - 1; /* :91-96 */
     if (c < 0) c = 0;
+    return r * kGridCols + c;
+}
+
+/* the same, row and column of the cell separately (the walk looks both up in per-row / per-column tables) */
+BEVX_HD int ground_cell_rc(float x, float y, int *row, int *col)
+{
+    int r = floor_half_to_int(x + 75.0f); /* :78, :81 */
+    int c = floor_half_to_int(y + 50.0f); /* :79, :82 */
+    r = r >= kGridRows ? kGridRows - 1 : (r < 0 ? 0 : r); /* :84-89 */
+    c = c >= kGridCols ? kGridCols - 1 : (c < 0 ? 0 : c); /* :91-96 */
+    *row = r;
+    *col = c;
     return r * kGridCols + c;
 }
 
@@ -203,6 +231,18 @@ BEVX_HD int round_half_up_bin(float v)
     int t = (int)f + (nonneg ? 1 : 0);
     t = (!nonneg && v >= -0.5f) ? (v >= -0x1p-55f ? 1 : 0) : t;
     return ok ? t : kIntMin;
+}
+/* round_half_up_bin(v) for callers that only want bins in [0, M), 2 <= M <= 4096: true and *bin if it is one.  From the
+ * case analysis above: the bin is floor(v) + 1 for v >= 0 — in range iff v < M - 1 —, 0 for -1 < v < -2^-55, 1 for
+ * -2^-55 <= v < 0, and negative for v <= -1.  floor(v) + 1 gives 0 on all of (-1, 0): only the sliver below zero needs a
+ * patch.  Checked against round_half_up_bin for all 2^32 floats (tests/test_exact_forms.py). */
+BEVX_HD bool bin_in_range(float v, int M, int *bin)
+{
+    const bool in = (v > -1.0f) & (v < (float)(M - 1)); /* (false for NaN) */
+    const float w = in ? v : 0.0f;
+    const int t = (int)floorf(w) + 1;
+    *bin = ((w < 0.0f) & (w >= -0x1p-55f)) ? 1 : t;
+    return in;
 }
 BEVX_HD int bev_bin(float p, float max_range_f, float interval)
 {

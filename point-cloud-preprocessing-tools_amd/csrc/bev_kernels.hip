@@ -499,9 +499,10 @@ template <bool kPow2>
 __device__ __forceinline__ uint32_t code_t(float px, float py, float pz, int label, const RasterParams &rp)
 {
     const float sx = px + rp.max_range_f, sy = py + rp.max_range_f;
-    const int x = round_half_up_bin(kPow2 ? sx * rp.inv_interval : sx / rp.interval); /* :279, :343 */
-    const int y = round_half_up_bin(kPow2 ? sy * rp.inv_interval : sy / rp.interval); /* :280, :344 */
-    const bool in = (label != 0) & ((unsigned)x < (unsigned)rp.mat_size) & ((unsigned)y < (unsigned)rp.mat_size); /* :285, :349 */
+    int x, y; /* (bin_in_range: round_half_up_bin for callers that only want bins inside the image) */
+    const bool inx = bin_in_range(kPow2 ? sx * rp.inv_interval : sx / rp.interval, rp.mat_size, &x); /* :279, :343 */
+    const bool iny = bin_in_range(kPow2 ? sy * rp.inv_interval : sy / rp.interval, rp.mat_size, &y); /* :280, :344 */
+    const bool in = (label != 0) & inx & iny; /* :285, :349 */
     const uint32_t code = code_from_bins_t<kPow2>(in ? x : 0, in ? y : 0, pz, rp);
     return in ? code : kSkip;
 }
@@ -932,13 +933,13 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
             const float4(*pe)[4] = edge[(r + 2) % 3];
             if (lane >= 62 && wv + 1 < kWaves) { const float4 q = pe[wv + 1][lane - 62]; right = XYZI{q.x, q.y, q.z, q.w}; }
             if (lane < 2 && wv > 0) { const float4 q = pe[wv - 1][lane + 2]; left = XYZI{q.x, q.y, q.z, q.w}; }
-            if (outcol) {
+            {   /* (every thread evaluates it: only output columns' statuses are ever used) */
                 XYZI up = prev;                                  /* (r-1, c)                  :143     */
                 if (up.i == -1.0f) up = right;                   /* (r-1, (c+2) % H)          :146-149 */
                 if (up.i == -1.0f) up = left;                    /* flat (r-1)*H + c - 2      :151-154 */
-                if (up.i == -1.0f && r >= 2) up = prevprev;      /* (r-2, c)                  :157-160 */
-                if (cur.i == -1.0f || up.i == -1.0f) s_r = kInvalid; /* :162-167 */
-                else s_r = angle_is_ground_flat(up.x - cur.x, up.y - cur.y, up.z - cur.z) ? kGround : kSteep; /* :169-182 */
+                if ((up.i == -1.0f) & (r >= 2)) up = prevprev;   /* (r-2, c)                  :157-160 */
+                const bool ground = angle_is_ground_nodiv(up.x - cur.x, up.y - cur.y, up.z - cur.z); /* :169-182 */
+                s_r = ((cur.i == -1.0f) | (up.i == -1.0f)) ? kInvalid : (ground ? kGround : kSteep); /* :162-167 */
             }
         }
 
@@ -969,9 +970,9 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         }
         p1.fl = (p1.fl & 3u) | ((uint32_t)(gf + 1) << 2) | (pred1 ? 16u : 0u);
         if (cand1) {
-            const int cell = ground_cell(__uint_as_float(p1.lo.x), __uint_as_float(p1.lo.y));
-            p1.key = candidate_key_edges(cell, tid - 2, pred1, p1.code, (int)(int16_t)(p1.hi.w & 0xffffu),
-                                         edge_x[cell / kGridCols], edge_y[cell % kGridCols]);
+            int cr, cc;
+            const int cell = ground_cell_rc(__uint_as_float(p1.lo.x), __uint_as_float(p1.lo.y), &cr, &cc);
+            p1.key = candidate_key_edges(cell, tid - 2, pred1, p1.code, (int)(int16_t)(p1.hi.w & 0xffffu), edge_x[cr], edge_y[cc]);
         }
 
         /* ---- row r's record (the one row r-3 has left) ---- */

@@ -136,6 +136,44 @@ uint64_t hc_angle_vs_libm(uint64_t n, uint64_t seed)
     return bad;
 }
 
+/* angle_is_ground_nodiv against angle_is_ground (the division form): n random bit patterns, n pairs of moderate
+ * magnitude, and n pairs (a, s) with a within a few ulps of the cut M * s for s over 60 binades; returns mismatches */
+uint64_t hc_angle_nodiv_check(uint64_t n)
+{
+    uint64_t bad = 0;
+    const double mid = 0.5 * ((double)bits_to_float(kTanThresholdBits) + (double)bits_to_float(kTanThresholdBits + 1u));
+#pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        uint64_t z = 0x243f6a8885a308d3ULL + 0x9e3779b97f4a7c15ULL * (uint64_t)(i + 1);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; z ^= z >> 31;
+        uint64_t z2 = (z + 0x9e3779b97f4a7c15ULL); z2 = (z2 ^ (z2 >> 30)) * 0xbf58476d1ce4e5b9ULL; z2 ^= z2 >> 29;
+        {   /* any bit patterns: dx, dy, dz */
+            const float dx = bits_to_float((uint32_t)z), dy = bits_to_float((uint32_t)(z >> 32)), dz = bits_to_float((uint32_t)z2);
+            if (angle_is_ground(dx, dy, dz) != angle_is_ground_nodiv(dx, dy, dz)) ++bad;
+            if (angle_is_ground(dx, 0.0f, dz) != angle_is_ground_nodiv(dx, 0.0f, dz)) ++bad;
+        }
+        {   /* the walk's magnitudes */
+            const float dx = ((int)((z >> 8) & 0xfffff) - 524288) / 4096.0f, dy = ((int)((z >> 28) & 0xfffff) - 524288) / 4096.0f;
+            const float dz = ((int)(z2 & 0xfffff) - 524288) / 16384.0f;
+            if (angle_is_ground(dx, dy, dz) != angle_is_ground_nodiv(dx, dy, dz)) ++bad;
+        }
+        {   /* straddling the cut: s = dx exactly (dy = 0), dz = fl32(M * s) +- k ulps */
+            const float sc = std::ldexp(1.0f, (int)((z >> 4) % 60) - 30);
+            const float s = sc * (1.0f + (float)((z >> 16) & 0x7fffff) / 8388608.0f);
+            float a = (float)(mid * (double)s);
+            int k = (int)((z2 >> 3) % 9) - 4;
+            for (; k > 0; --k) a = std::nextafter(a, INFINITY);
+            for (; k < 0; ++k) a = std::nextafter(a, -INFINITY);
+            if (angle_is_ground(s, 0.0f, a) != angle_is_ground_nodiv(s, 0.0f, a)) ++bad;
+            if (angle_is_ground(0.0f, -s, -a) != angle_is_ground_nodiv(0.0f, -s, -a)) ++bad;
+        }
+    }
+    const float sp[] = {0.0f, -0.0f, 1.0f, -1.0f, INFINITY, -INFINITY, NAN, 1e-45f, -1e-45f, 3.4e38f, -3.4e38f, 1e-38f, 2.0f, 0.5f, 0.17632698f};
+    for (float x : sp) for (float y : sp) for (float zz : sp)
+        if (angle_is_ground(x, y, zz) != angle_is_ground_nodiv(x, y, zz)) ++bad;
+    return bad;
+}
+
 int hc_ground_cell(float x, float y) { return ground_cell(x, y); }
 
 /* exact_reciprocal (bev_exact.h): for every power of two v it accepts, x / v == x * (1 / v) bit for bit over `samples`
@@ -199,11 +237,12 @@ uint32_t hc_bev_code(const bev_params_t *p, float x, float y, float z, int label
  *   1: floor_half_to_int(n) vs cvttsd2si(floor((double)n / 2.0))
  *   2: round_half_up_bin(v) vs cvttsd2si(round((double)v + 0.5))  (compared after mapping out-of-[0,4096) to -1)
  *   3: height_times4(t)     vs cvttsd2si((double)t * 4.0)
- *   4: d >= 0.3f            vs (double)d > 0.30 */
+ *   4: d >= 0.3f            vs (double)d > 0.30
+ *   5: bin_in_range(v, M)   vs round_half_up_bin(v) in [0, M), M = 2, 112, 224, 448, 512, 4096 */
 void hc_exhaustive_exact_forms(uint64_t *out)
 {
-    uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
-#pragma omp parallel for reduction(+ : m0, m1, m2, m3, m4) schedule(static)
+    uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
+#pragma omp parallel for reduction(+ : m0, m1, m2, m3, m4, m5) schedule(static)
     for (int64_t u = 0; u <= 0xffffffffLL; ++u) {
         const float f = bits_to_float((uint32_t)u);
         {
@@ -223,8 +262,17 @@ void hc_exhaustive_exact_forms(uint64_t *out)
         }
         if (height_times4(f) != cvtt_f64((double)f * 4.0)) ++m3;
         if ((f >= 0.3f) != ((double)f > 0.30)) ++m4;
+        {
+            const int full = round_half_up_bin(f);
+            for (int M : {2, 112, 224, 448, 512, 4096}) {
+                int b = -7;
+                const bool in = bin_in_range(f, M, &b);
+                const bool want = full >= 0 && full < M;
+                if (in != want || (in && b != full)) ++m5;
+            }
+        }
     }
-    out[0] = m0; out[1] = m1; out[2] = m2; out[3] = m3; out[4] = m4;
+    out[0] = m0; out[1] = m1; out[2] = m2; out[3] = m3; out[4] = m4; out[5] = m5;
 }
 
 /* bev_libm.h against the host libm: out[0] = atanf mismatches over ALL 2^32 floats,

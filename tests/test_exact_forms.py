@@ -7,9 +7,10 @@ import hostcheck_lib as hc
 
 
 def test_float_only_forms_equal_the_literal_expressions_for_every_float():
-    out = (C.c_uint64 * 5)()
+    out = (C.c_uint64 * 6)()
     hc.lib().hc_exhaustive_exact_forms(out)
-    names = ["x + 75.0f / y + 50.0f", "floor(n / 2.0)", "round(v + 0.5) bin", "(z + 2) * 4 height", "d > 0.30"]
+    names = ["x + 75.0f / y + 50.0f", "floor(n / 2.0)", "round(v + 0.5) bin", "(z + 2) * 4 height", "d > 0.30",
+             "bin_in_range (six image sizes)"]
     assert {n: int(v) for n, v in zip(names, out)} == {n: 0 for n in names}
 
 
@@ -19,3 +20,10 @@ def test_exact_reciprocal_is_a_division():
     results included; any other divisor keeps the division."""
     import hostcheck_lib as hc
     assert hc.lib().hc_exact_reciprocal_check(200000) == 0
+
+
+def test_angle_predicate_without_the_division():
+    """bev_exact.h angle_is_ground_nodiv (what the column walk evaluates: a double multiply and compare against the
+    midpoint between the threshold and its successor) against the division form, BatchMultiBevGen.cpp:173-179: random
+    bit patterns, the walk's magnitudes, pairs straddling the cut by up to four ulps over sixty binades, special values."""
+    assert hc.lib().hc_angle_nodiv_check(40_000_000) == 0
