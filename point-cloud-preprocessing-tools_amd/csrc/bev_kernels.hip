@@ -537,9 +537,8 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
     const size_t frame_off = (size_t)f * g.S;
     const int bands = g.raster_bands;
 
-    /* lanes two to the right / left (wrapping inside the wave; the edge lanes are patched from LDS), one to the left */
-    const int sh_right = ((lane + 2) & 63) << 2, sh_left = ((lane - 2) & 63) << 2, sh_left1 = ((lane - 1) & 63) << 2;
-    auto lane_from = [&](int sel, uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)x); };
+    /* lanes two to the right / left (wrapping inside the wave; the edge lanes are patched from LDS) */
+    const int sh_right = ((lane + 2) & 63) << 2, sh_left = ((lane - 2) & 63) << 2;
     auto lane_from_f = [&](int sel, float x) -> float { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)__float_as_uint(x))); };
     const int v = strip * kStripCols + tid - 2;                      /* virtual column */
     const bool provider = tid < kStripVirt && (v < H + 2) && (v >= 0 || strip == 0); /* has a slot */
@@ -559,7 +558,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
     __shared__ int est_l[2][kInPlace ? kStreamMaxRows : 1];
     __shared__ uint8_t tcnt_l[kInPlace ? kStreamMaxRows : 1];
     __shared__ float4 edge[3][kWaves][4];                  /* rows r, r-1, (r-2): lanes 0, 1, 62, 63 of every wave */
-    __shared__ uint32_t wave_cnt[2][kWaves];               /* per-wave candidate counts of the row being written */
+    __shared__ __attribute__((aligned(16))) uint32_t wave_cnt[2][kWaves]; /* per-wave candidate counts of the row being written */
     __shared__ uint32_t band_cursor[kMaxBands];            /* entries already in this strip's code list of each band */
     __shared__ uint8_t band_tab[512];                      /* x bin -> raster band */
     __shared__ uint32_t seen[1 << kSeenB];                 /* direct-mapped memo of codes this strip has already listed */
@@ -849,13 +848,10 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
             const int rr = q - (lo_row - 1);        /* only rows lo-1 .. N-1 can hold candidates */
             if (rr >= 0) {
                 const unsigned long long mc = __ballot(cand2);
-                uint32_t before = 0, total = 0;
-#pragma unroll
-                for (int w = 0; w < kWaves; ++w) {
-                    const uint32_t c = wave_cnt[par][w];
-                    if (w < wv) before += c;
-                    total += c;
-                }
+                static_assert(kWaves == 4, "the four counts are read as one 16-byte word");
+                const u32x4 wc = *reinterpret_cast<const u32x4 *>(&wave_cnt[par][0]);
+                const uint32_t total = wc.x + wc.y + wc.z + wc.w;
+                const uint32_t before = (wv > 0 ? wc.x : 0u) + (wv > 1 ? wc.y : 0u) + (wv > 2 ? wc.z : 0u);
                 const uint32_t seg = (uint32_t)(rr * strips + strip);
                 if (cand2) {
                     const uint32_t rank = before + (uint32_t)__popcll(mc & ((1ull << lane) - 1ull));
@@ -871,16 +867,17 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
                  * at the same heights again and again: a HDL_64E frame lists 74 k codes of which 24 k are distinct).  The
                  * rasters are idempotent, so a stale or racing memo entry only costs a duplicate. */
                 bool has = outcol && !cand2 && p2.code != kSkip;
-                const uint32_t left_code = lane_from(sh_left1, p2.code);
-                const bool left_has = lane_from(sh_left1, has ? 1u : 0u) != 0u;
-                if (lane > 0 && left_has && left_code == p2.code) has = false;
+                /* (the left neighbour's code and flag by DPP: no LDS round trip) */
+                const uint32_t left_code = (uint32_t)__builtin_amdgcn_update_dpp((int)kSkip, (int)p2.code, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                const bool left_has = __builtin_amdgcn_update_dpp(0, has ? 1 : 0, 0x138, 0xf, 0xf, false) != 0;
+                has = has & !((lane > 0) & left_has & (left_code == p2.code));
+                /* the memo entry and the band of the code are requested together, then one cursor atomic */
+                const uint32_t slot = (p2.code * 0x9E3779B1u) >> (32 - kSeenB);
+                const uint32_t remembered = seen[slot];
+                const int band = band_tab[code_x(p2.code) & 511];
+                has = has & (remembered != p2.code);
                 if (has) {
-                    const uint32_t slot = (p2.code * 0x9E3779B1u) >> (32 - kSeenB);
-                    if (seen[slot] == p2.code) has = false;
-                    else seen[slot] = p2.code;
-                }
-                if (has) {
-                    const int band = band_tab[code_x(p2.code)];
+                    seen[slot] = p2.code;
                     const uint32_t pos = atomicAdd(&band_cursor[band], 1u);
                     flist[(uint32_t)band * code_cap + pos] = p2.code;
                 }
