@@ -57,6 +57,7 @@ using namespace bevx;
 #ifndef BEV_SEENB
 #define BEV_SEENB 8
 #endif
+
 namespace bevk {
 
 static const char *const kNames[K_COUNT] = {
@@ -524,10 +525,20 @@ constexpr int kWrapLead = 6;
 constexpr int kInPlaceSlot = (kWinPos + kWrapPos + kTailCap) * 32;
 constexpr uint32_t kIdxTail = 1u << 30;
 
+#ifdef BEV_EXP_WALK3 /* timing experiment: three walk workgroups per CU (by registers), LDS left for the other stream */
+#define BEV_WALK_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
+#define BEV_WALK_WAVES 3
+#else
+#define BEV_WALK_OCC
+#define BEV_WALK_WAVES 4
+#endif
 template <int kSrc, bool kPow2, bool kGm>
-__global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
+__global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
     constexpr bool kIdentity = kSrc == kSrcIdentity, kInPlace = kSrc == kSrcInPlace;
+#ifdef BEV_EXP_WALK3
+    asm volatile("" ::: "v135"); /* 136 registers: three waves per SIMD */
+#endif
     static_assert(kWinPos == 256 && kStripVirt + 16 <= kWinPos && kTailCap == 64 && kWrapPos == 16, "DMA pieces of the in-place source");
     int f, strip;
     if (!map_block_xcd(blockIdx.x, nf, g.strips, f, strip)) return;
@@ -537,9 +548,11 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
     const size_t frame_off = (size_t)f * g.S;
     const int bands = g.raster_bands;
 
-    /* lanes two to the right / left (wrapping inside the wave; the edge lanes are patched from LDS) */
+    /* the value two lanes to the right / left (wrapping inside the wave; the edge lanes are patched from LDS).  (Two DPP
+     * wave shifts instead of each ds_bpermute measured the same.) */
     const int sh_right = ((lane + 2) & 63) << 2, sh_left = ((lane - 2) & 63) << 2;
-    auto lane_from_f = [&](int sel, float x) -> float { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)__float_as_uint(x))); };
+    auto from_right2 = [&](float x) -> float { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sh_right, (int)__float_as_uint(x))); };
+    auto from_left2 = [&](float x) -> float { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sh_left, (int)__float_as_uint(x))); };
     const int v = strip * kStripCols + tid - 2;                      /* virtual column */
     const bool provider = tid < kStripVirt && (v < H + 2) && (v >= 0 || strip == 0); /* has a slot */
     const bool outcol = tid >= 2 && tid < 2 + kStripCols && v < H;   /* owns column v's outputs */
@@ -774,8 +787,14 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
      * through 2 KiB of LDS each instruction stores 1 KiB of whole lines.  The 2 KiB are a piece of a ring slot that is
      * idle right now and that only this wave's own DMA refills: gather / identity: the slot of the row just consumed
      * (this wave's two 1-KiB pieces, points 0..31 in the first); in place: the same pieces of the slot row r-1 has left. */
+    /* (a point's halves swap places in every second group of four points: eight lanes' 16-byte writes at a stride of
+     * 32 B then fall into eight different bank quads instead of four — the writes were a two-way conflict) */
+    const uint32_t xp_sw = ((uint32_t)lane >> 2) & 1u;
     const uint32_t xp_w = (uint32_t)wv * 1024u + (uint32_t)(lane & 31) * 32u + (lane < 32 ? 0u : 4096u);
-    const uint32_t xp_r0 = (uint32_t)wv * 1024u, xp_r1 = (uint32_t)wv * 1024u + 4096u; /* first, second KiB */
+    const uint32_t xp_wlo = xp_w + 16u * xp_sw, xp_whi = xp_w + 16u * (xp_sw ^ 1u);
+    /* reader lane j wants 16-byte unit j of the KiB = half (j & 1) of point j >> 1 */
+    const uint32_t xp_unit = ((uint32_t)lane & ~1u) | (((uint32_t)lane & 1u) ^ (((uint32_t)lane >> 3) & 1u));
+    const uint32_t xp_r0 = (uint32_t)wv * 1024u + xp_unit * 16u, xp_r1 = xp_r0 + 4096u; /* first, second KiB */
 
     auto row_step = [&](auto I, const int r) {
         constexpr int s0 = decltype(I)::value % 3;         /* ring slot of row r (and of row r + 3) */
@@ -876,8 +895,9 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
                 const uint32_t remembered = seen[slot];
                 const int band = band_tab[code_x(p2.code) & 511];
                 has = has & (remembered != p2.code);
+                if (has) seen[slot] = p2.code;
+                /* (one cursor atomic per wave and band instead of one per code — a ballot loop — measured 2 % slower) */
                 if (has) {
-                    seen[slot] = p2.code;
                     const uint32_t pos = atomicAdd(&band_cursor[band], 1u);
                     flist[(uint32_t)band * code_cap + pos] = p2.code;
                 }
@@ -887,10 +907,10 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
                 const bool as_ground = cand2 && !((p2.fl >> 4) & 1u);
                 if (as_ground) hi.w &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
                 char *xb = &ring[(kInPlace ? s2 : s0) * kSlotBytes];
-                *reinterpret_cast<u32x4 *>(xb + xp_w) = p2.lo;
-                *reinterpret_cast<u32x4 *>(xb + xp_w + 16) = hi;
-                const u32x4 pa = *reinterpret_cast<const u32x4 *>(xb + xp_r0 + lane * 16);
-                const u32x4 pb = *reinterpret_cast<const u32x4 *>(xb + xp_r1 + lane * 16);
+                *reinterpret_cast<u32x4 *>(xb + xp_wlo) = p2.lo;
+                *reinterpret_cast<u32x4 *>(xb + xp_whi) = hi;
+                const u32x4 pa = *reinterpret_cast<const u32x4 *>(xb + xp_r0);
+                const u32x4 pb = *reinterpret_cast<const u32x4 *>(xb + xp_r1);
                 const unsigned long long owners = __ballot(outcol);
                 const uint32_t at = (uint32_t)(q * H + (strip * kStripCols - 2 + 64 * wv)) * 2u; /* (never dereferenced below 0) */
 #ifndef BEV_EXP_NOSTORE /* timing experiment: what the ordered cloud's stores cost (results are wrong without them) */
@@ -925,11 +945,17 @@ __global__ __launch_bounds__(kStripThreads, 4) void k_walk(BatchPtrs b, Geometry
         int s_r = kSteep;
         if (r >= lo_row && r < N) { /* workgroup-uniform */
             /* row r-1 of the threads two to the right / left */
-            XYZI right{lane_from_f(sh_right, prev.x), lane_from_f(sh_right, prev.y), lane_from_f(sh_right, prev.z), lane_from_f(sh_right, prev.i)};
-            XYZI left{lane_from_f(sh_left, prev.x), lane_from_f(sh_left, prev.y), lane_from_f(sh_left, prev.z), lane_from_f(sh_left, prev.i)};
+            XYZI right{from_right2(prev.x), from_right2(prev.y), from_right2(prev.z), from_right2(prev.i)};
+            XYZI left{from_left2(prev.x), from_left2(prev.y), from_left2(prev.z), from_left2(prev.i)};
             const float4(*pe)[4] = edge[(r + 2) % 3];
-            if (lane >= 62 && wv + 1 < kWaves) { const float4 q = pe[wv + 1][lane - 62]; right = XYZI{q.x, q.y, q.z, q.w}; }
-            if (lane < 2 && wv > 0) { const float4 q = pe[wv - 1][lane + 2]; left = XYZI{q.x, q.y, q.z, q.w}; }
+            if (lane >= 62) { /* (the last wave's two have no right neighbour: the value is never used, it is not an output column's) */
+                const float4 q = pe[wv + 1 < kWaves ? wv + 1 : wv][lane - 62];
+                right = XYZI{q.x, q.y, q.z, q.w};
+            }
+            if (lane < 2) {
+                const float4 q = pe[wv > 0 ? wv - 1 : 0][lane + 2];
+                left = XYZI{q.x, q.y, q.z, q.w};
+            }
             {   /* (every thread evaluates it: only output columns' statuses are ever used) */
                 XYZI up = prev;                                  /* (r-1, c)                  :143     */
                 if (up.i == -1.0f) up = right;                   /* (r-1, (c+2) % H)          :146-149 */
