@@ -25,7 +25,12 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO / "point-cloud-preprocessing-tools_amd"))
 sys.path.insert(0, str(REPO / "tests"))
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy kernel reaches
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# What byte-moving kernels reach on the pool's boxes (scripts/microbench/copyshapes.hip, tileshapes.hip; raw output under
+# profiles/r03_copy_ceiling_box1.txt, r03_tile_shapes_box1.txt): a no-loop 16-B-per-thread copy, and the column walk's
+# geometry (a 64-row loop over 8 KiB row pieces, whole-line stores) as a pure copy.
+COPY_CEILING_GBPS = 6610.0
+WALK_SHAPE_CEILING_GBPS = 5010.0
 
 
 def main() -> int:
@@ -172,6 +177,16 @@ def main() -> int:
     fence()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, world, device=dev, force_collective=use_dist)
+    # the same steps once more, each one fenced by itself: the median step next to the mean of the timed region
+    # (SURVEY.md 8(d) asks for the median; a fence per step costs the pipeline its overlap across steps)
+    per_step = []
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        step()
+        fence()
+        per_step.append(time.perf_counter() - ts)
+    per_step.sort()
+    median_step = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     total_frames = shard.sum_over_ranks(float(count * args.steps), world, device=dev, force_collective=use_dist)
 
     # ---- profile passes (after the timed region, which carries no events): (1) the same steps again, still pipelined,
@@ -203,9 +218,9 @@ def main() -> int:
     # whose read of it cannot be avoided — the column walk when P ~ S (it gathers every point it writes), the order scan
     # when P >> S (oxford_concat: 2 M points into 33,792 slots; the walk then only gathers the S winners)
     if args.workload == "oxford_concat":
-        own_bytes = {"k_order_scan": 32.0 * mean_pts, "k_strip_ground": 32.0 * S, "k_bev_raster": float(L * M * M + M * M)}
+        own_bytes = {"k_order_scan": 32.0 * mean_pts, "k_walk": 32.0 * S, "k_bev_raster": float(L * M * M + M * M)}
     else:
-        own_bytes = {"k_strip_ground": 32.0 * mean_pts + 32.0 * S, "k_bev_raster": float(L * M * M + M * M)}
+        own_bytes = {"k_walk": 32.0 * mean_pts + 32.0 * S, "k_bev_raster": float(L * M * M + M * M)}
     roofline = None
     kernels = []
     kernels_pipelined = [{"name": s["name"], "launches": s["launches"], "avg_launch_ms": s["total_ms"] / s["launches"],
@@ -231,28 +246,32 @@ def main() -> int:
         # THIS command line (scripts/profile_round.sh; 1000 frames, sub-batch 256), per frame, scaled to this launch.
         traffic, traffic_src, traffic_total = None, None, None
         if args.workload == "hdl64_sweep":
-            for name in ("r02_pmc_traffic.json", "r01_final_pmc_traffic.json"):
+            for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
                 pmc_file = REPO / "profiles" / name
                 if not pmc_file.exists():
                     continue
                 pmc = json.loads(pmc_file.read_text())
                 for kname, kv in pmc["kernels"].items():
-                    if kname.split("<")[0] == dom["name"]:
+                    if kname.split("<")[0] == dom["name"] and kv.get("hbm_bytes_per_frame", 0) > 1e5:  # (the in-place instantiation, not the empty redo launch)
                         traffic = kv["hbm_bytes_per_frame"] * per_launch_frames
                         traffic_src = f"profiles/{name}: {pmc.get('source', 'rocprofv3 --pmc')}"
                 traffic_total = pmc.get("hbm_bytes_per_frame_all_kernels")
                 break
         # whole hot path against the wall clock of the timed region (this rank): B_frame * frames / time
         pipe_achieved = b_frame * (count * args.steps) / elapsed / 1e9
+        frames_per_s = count * args.steps / elapsed
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+            "copy_ceiling_gbps": COPY_CEILING_GBPS, "walk_shape_ceiling_gbps": WALK_SHAPE_CEILING_GBPS,
+            "ceiling_source": "profiles/r03_copy_ceiling_box1.txt, profiles/r03_tile_shapes_box1.txt (no-loop copy; the walk's geometry as a pure copy)",
             "kernel": dom["name"], "frames_per_launch": per_launch_frames,
             "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": avg_ms,
             "note": "kernel durations from a one-lane pass of the same steps right after the timed region (back-to-back launches); "
                     "the timed region itself runs the two-stage pipeline (front of sub-batch k+1 beside the back of sub-batch k)",
             "pipeline": {"bytes_per_frame": b_frame, "achieved": pipe_achieved, "frac": pipe_achieved / HBM_PEAK_GBPS,
                          "hbm_traffic_per_frame_all_kernels": traffic_total,
+                         "real_traffic_gbps": (traffic_total * frames_per_s / 1e9) if traffic_total else None,
                          "definition": "algorithmic bytes of the whole hot path / wall time of the timed region, this GPU"},
         }
 
@@ -335,6 +354,7 @@ def main() -> int:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_median_fenced": median_step * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -134,7 +134,7 @@ const char *kernel_name(int id);
 int raster_bands_for(int mat_size);
 
 /* launchers (bev_kernels.hip) — all asynchronous on `st` */
-/* pass 0: general frames whole, stream frames from their T on; pass 1: redo frames whole */
+/* pass 0: general frames only (frames read in place have no winner entries: their tail is listed by k_probe); pass 1: redo frames, whole */
 void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, int pass, hipStream_t st);
 /* the column walk.  source 0: through the winner table, frames of mode `mode`; 1: identity, b.pts already is the ordered
  * cloud (bev_mark_ground); 2: stream frames */

@@ -61,7 +61,7 @@ using namespace bevx;
 namespace bevk {
 
 static const char *const kNames[K_COUNT] = {
-    "k_order_scan", "k_strip_ground", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
+    "k_order_scan", "k_walk", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project", "k_transform",
     "k_probe",
 };
@@ -301,8 +301,7 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
     const uint32_t block0 = blockIdx.x * (256u * kScanPerThread);
     const uint32_t base = block0 + threadIdx.x;
     if (block0 >= fd.n_pts) return;
-    /* which points of this frame this pass scatters: [first, n) */
-    uint32_t first = 0u;
+    /* pass 0: general frames only (a frame read in place has its tail listed by k_probe); pass 1: redo frames, whole */
     if (info) {
         const FrameInfo fi = info[f];
         if (pass == 0) {
@@ -313,7 +312,6 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
     } else if (pass != 0) {
         return;
     }
-    if (block0 + 256u * kScanPerThread <= first) return;
     const bev_point_t *fp = pts + fd.in_offset;
     uint32_t slot[kScanPerThread];
     bool spread = false; /* does any wave-instruction's worth of 64 points straddle far-apart slots? */
@@ -327,7 +325,7 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
     for (int k = 0; k < kScanPerThread; ++k) {
         const uint32_t i = base + 256u * k;
         const uint32_t row = rcw[k] & 0xffffu, col = rcw[k] >> 16;
-        slot[k] = (i >= first && i < fd.n_pts && row < (uint32_t)N && col < (uint32_t)H) ? row * (uint32_t)H + col
+        slot[k] = (i < fd.n_pts && row < (uint32_t)N && col < (uint32_t)H) ? row * (uint32_t)H + col
                                                                                          : 0xffffffffu; /* :106-111 ("< 0" is dead: u16) */
     }
     uint32_t *fw = winner + (size_t)f * S;

@@ -8,7 +8,7 @@ usage: python scripts/make_profiles.py gpurun_out/<tag> profiles/<prefix> [frame
 import collections, csv, glob, json, os, shutil, sys
 
 src, prefix = sys.argv[1], sys.argv[2]
-pmc_frames = int(sys.argv[3]) if len(sys.argv) > 3 else 2000  # bench.py --frames 1000 --steps 1 --warmup 1
+pmc_frames = int(sys.argv[3]) if len(sys.argv) > 3 else 3000  # bench.py --frames 1000 --steps 1 --warmup 1: warm-up, timed step, fenced step
 
 
 def last_json_line(path):

@@ -15,5 +15,5 @@ for f in glob.glob(sys.argv[1]+'/pmc/**/*counter_collection.csv',recursive=True)
         if 'bevk' not in k: continue
         agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
 for k,v in agg.items():
-    print(f"{k[:34]:34s}", " ".join(f"{c[3:]}={x/2000.0/1e3:.1f}k" for c,x in sorted(v.items())))
+    print(f"{k[:34]:34s}", " ".join(f"{c[3:]}={x/3000.0/1e3:.1f}k" for c,x in sorted(v.items())))
 PY

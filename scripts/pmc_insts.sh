@@ -13,7 +13,7 @@ for f in glob.glob(sys.argv[1]+'/pmc/**/*counter_collection.csv',recursive=True)
         k=r['Kernel_Name'].split('(')[0]
         if 'bevk' not in k: continue
         agg[k][r['Counter_Name']]+=float(r['Counter_Value'])
-frames=2000.0  # 1 warm-up + 1 step of 1000 frames
+frames=3000.0  # 1 warm-up + 1 timed step + 1 fenced step of 1000 frames
 for k,v in agg.items():
     w=v.get('SQ_WAVES',1)
     print(f"{k[:34]:34s} per frame: valu {v['SQ_INSTS_VALU']/frames/1e3:7.1f}k salu {v['SQ_INSTS_SALU']/frames/1e3:7.1f}k lds {v['SQ_INSTS_LDS']/frames/1e3:6.1f}k vmem_rd {v['SQ_INSTS_VMEM_RD']/frames/1e3:5.1f}k wr {v['SQ_INSTS_VMEM_WR']/frames/1e3:5.1f}k waves {w/frames:6.1f}  valu/wave {v['SQ_INSTS_VALU']/w:7.0f}")
