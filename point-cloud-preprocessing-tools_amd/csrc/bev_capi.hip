@@ -135,6 +135,7 @@ struct bev_ctx {
     int n_lanes = 1;
     int n_lanes_active = 1; /* <= n_lanes; bev_set_lanes */
     bool staged = true;     /* two-stage pipeline, see run_pipeline; BEV_STAGED=0 falls back to free-running lanes */
+    int back_chunk = 1 << 30;  /* frames per launch of the back-stage kernels (BEV_BACK_CHUNK: experiment knob; default: the whole sub-batch) */
     bool allow_stream = true;  /* sorted-prefix frames are read in place (k_probe); BEV_STREAM=0 turns it off, see bev_create */
     hipEvent_t fork_ev = nullptr;
     hipEvent_t stagger_ev = nullptr; /* recorded on a lane after its bandwidth-bound kernels */
@@ -511,21 +512,37 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             }
         }
         RoctxRange rb("bev:back (cell sums, resolve, rasters)");
-        {
-            ProfScope ps(c, K_CELL_SUMS, nb, st);
-            launch_cell_sums(g, b, nb, st);
-        }
-        if (d_gm) {
-            ProfScope ps(c, K_GROUND_MAT, nb, st);
-            launch_ground_mat(g, b, d_gm + (size_t)f0 * S, nb, st);
-        }
-        {   /* phase C for the candidates: labels, codes of the un-grounded ones */
-            ProfScope ps(c, K_GROUND_RESOLVE, nb, st);
-            launch_ground_resolve(g, b, nb, identity, st);
-        }
-        if (d_multi || d_single) {
-            ProfScope ps(c, K_BEV_RASTER, nb, st);
-            launch_bev_raster(g, b, d_multi != nullptr, d_single != nullptr, nb, st);
+        /* (BEV_BACK_CHUNK cuts the back stage into pieces of that many frames: measured with 512-frame sub-batches and
+         * pieces of 256 — one k_cell_sums workgroup per CU and piece — the serialised pieces cost more than the second
+         * round of workgroups they avoid: 270 k against 287 k frames/s) */
+        for (int c0 = 0; c0 < nb; c0 += c->back_chunk) {
+            const int cn = std::min(c->back_chunk, nb - c0);
+            BatchPtrs bc = b;
+            bc.cand = b.cand + (size_t)c0 * g.segs * kSeg;
+            bc.ncand = b.ncand + (size_t)c0 * g.segs;
+            bc.avg = b.avg + (size_t)c0 * bevx::kGridCells;
+            bc.code_main = b.code_main + (size_t)c0 * g.emitters * g.raster_bands * g.code_cap;
+            bc.ncode = b.ncode + (size_t)c0 * g.emitters * g.raster_bands;
+            bc.ordered = b.ordered + (size_t)c0 * S;
+            bc.gm = b.gm ? b.gm + (size_t)c0 * S : nullptr;
+            bc.multi = b.multi ? b.multi + (size_t)c0 * c->multi_bytes : nullptr;
+            bc.single = b.single ? b.single + (size_t)c0 * c->single_bytes : nullptr;
+            {
+                ProfScope ps(c, K_CELL_SUMS, cn, st);
+                launch_cell_sums(g, bc, cn, st);
+            }
+            if (d_gm) {
+                ProfScope ps(c, K_GROUND_MAT, cn, st);
+                launch_ground_mat(g, bc, d_gm + (size_t)(f0 + c0) * S, cn, st);
+            }
+            {   /* phase C for the candidates: labels, codes of the un-grounded ones */
+                ProfScope ps(c, K_GROUND_RESOLVE, cn, st);
+                launch_ground_resolve(g, bc, cn, identity, st);
+            }
+            if (d_multi || d_single) {
+                ProfScope ps(c, K_BEV_RASTER, cn, st);
+                launch_bev_raster(g, bc, d_multi != nullptr, d_single != nullptr, cn, st);
+            }
         }
         HIPCK(c, hipEventRecord(ln.back_done, st));
         c->last_sub_frames = nb;
@@ -679,6 +696,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
          * (+3 ... +7 % frames/s, same-box A/B); BEV_STREAM=0 forces the general path for every frame. */
         const char *sm = getenv("BEV_STREAM");
         c->allow_stream = !(sm && atoi(sm) == 0);
+        if (const char *bk = getenv("BEV_BACK_CHUNK")) c->back_chunk = std::max(1, atoi(bk));
         const char *sg = getenv("BEV_STAGED");
         c->staged = (!sg || atoi(sg) != 0) && c->n_lanes >= 2;
     }
