@@ -43,7 +43,9 @@ def main() -> int:
     ap.add_argument("--workload", default="hdl64_sweep", choices=["hdl64_sweep", "os1_firing", "oxford_concat"],
                     help="hdl64_sweep = BASELINE configs[1]/[3] (default, the graded metric); os1_firing = configs[2] "
                          "(MulRan-style unordered OS1_64); oxford_concat = configs[4] (HDL_32E, ~2M points per frame)")
-    ap.add_argument("--sub-batch", type=int, default=int(os.environ.get("BEV_SUB_BATCH", "256")))
+    ap.add_argument("--sub-batch", type=int, default=int(os.environ.get("BEV_SUB_BATCH", "500")),
+                    help="frames per sub-batch of the two-stage pipeline (500: two sub-batches per 1000-frame step; measured "
+                         "300-309 k frames/s against 288-297 k at 256 on the same box)")
     ap.add_argument("--cpu-sample", type=int, default=400, help="frames timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")

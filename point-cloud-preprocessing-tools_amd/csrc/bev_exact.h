@@ -140,6 +140,31 @@ BEVX_HD int ground_cell_rc(float x, float y, int *row, int *col)
     return r * kGridCols + c;
 }
 
+/* Phase B's count, BatchMultiBevGen.cpp:135-136, :205-206: cnt starts at 0.01f and takes "cnt = cnt + 1" once per ground
+ * point of the cell, in float.  n of those steps at once: inside a binade [2^e, 2^(e+1)), e <= 23, cnt sits on the
+ * binade's grid and so does cnt + j, so the j-th step is exact as long as the sum stays below 2^(e+1) — all of them
+ * together are ONE exact addition; only the step that crosses into the next binade rounds (the grid doubles), and the
+ * step from 0.01 to 1.01.  n < 2^24.  (tests/hostcheck: hc_count_advance_check against the step-by-step loop.) */
+BEVX_HD float count_advance(float c, uint32_t n)
+{
+    while (n != 0u) {
+        if (c >= 1.0f) {
+            union { float f; uint32_t u; } top;
+            top.f = c;
+            top.u = (top.u & 0x7f800000u) + 0x00800000u;      /* 2^(e+1) */
+            const float d = top.f - c;                         /* exact */
+            const uint32_t stay = (uint32_t)ceilf(d) - 1u;     /* steps that stay below 2^(e+1): cnt + j < top  <=>  j < d */
+            const uint32_t t = n < stay ? n : stay;
+            c = c + (float)t;                                  /* exact: on the binade's grid */
+            n -= t;
+            if (n == 0u) break;
+        }
+        c = c + 1.0f;                                          /* the step that rounds */
+        --n;
+    }
+    return c;
+}
+
 /* Phase C test for one slot, BatchMultiBevGen.cpp:227-241: any in-range
  * 4-neighbour cell (own cell excluded) with (double)(float)(z - avg) > 0.30. */
 template <class AvgPtr>

@@ -832,8 +832,11 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
         if constexpr (!kInPlace) {
             if (lane < 2 || lane >= 62)
                 edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(__uint_as_float(cur_lo.x), __uint_as_float(cur_lo.y), __uint_as_float(cur_lo.z), __uint_as_float(cur_hi.x));
-            const unsigned long long m2 = __ballot(outcol && wr_gflag(p2.fl) == 1);
-            if (lane == 0) wave_cnt[par][wv] = (uint32_t)__popcll(m2);
+            const bool c2 = outcol && wr_gflag(p2.fl) == 1;
+            const uint32_t q2 = p2.key & 3u;
+            const uint32_t packed = (uint32_t)__popcll(__ballot(c2 && q2 == 0u)) | ((uint32_t)__popcll(__ballot(c2 && q2 == 1u)) << 8) |
+                                    ((uint32_t)__popcll(__ballot(c2 && q2 == 2u)) << 16) | ((uint32_t)__popcll(__ballot(c2 && q2 == 3u)) << 24);
+            if (lane == 0) wave_cnt[par][wv] = packed;
         }
         lds_barrier();
         PHA(2);
@@ -864,14 +867,26 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
             const int q = r - 2;
             const int rr = q - (lo_row - 1);        /* only rows lo-1 .. N-1 can hold candidates */
             if (rr >= 0) {
-                const unsigned long long mc = __ballot(cand2);
+                /* Candidates of row r-2 by cell quarter (cell mod 4, the low bits of the key): a segment keeps its candidates
+                 * as four consecutive runs, one per quarter, each in column order — phase B is four workgroups per frame that
+                 * each read one run (cells are independent, only the order inside a cell matters).  A wave's four counts (at
+                 * most 64 each; a segment's at most 236 each) travel in one word. */
+                const uint32_t q2 = p2.key & 3u;
                 static_assert(kWaves == 4, "the four counts are read as one 16-byte word");
                 const u32x4 wc = *reinterpret_cast<const u32x4 *>(&wave_cnt[par][0]);
-                const uint32_t total = wc.x + wc.y + wc.z + wc.w;
+                const uint32_t total = wc.x + wc.y + wc.z + wc.w; /* four byte-wide sums */
                 const uint32_t before = (wv > 0 ? wc.x : 0u) + (wv > 1 ? wc.y : 0u) + (wv > 2 ? wc.z : 0u);
                 const uint32_t seg = (uint32_t)(rr * strips + strip);
+                /* the lanes of this wave with a candidate of the same quarter */
+                const unsigned long long m0 = __ballot(cand2 && q2 == 0u), m1 = __ballot(cand2 && q2 == 1u),
+                                         m2 = __ballot(cand2 && q2 == 2u), m3 = __ballot(cand2 && q2 == 3u);
                 if (cand2) {
-                    const uint32_t rank = before + (uint32_t)__popcll(mc & ((1ull << lane) - 1ull));
+                    const unsigned long long same = q2 == 0u ? m0 : (q2 == 1u ? m1 : (q2 == 2u ? m2 : m3));
+                    const uint32_t sh = 8u * q2;
+                    /* where the quarter's run starts (byte q of total * 0x01010100 = the quarters below it), the earlier
+                     * waves' candidates of the quarter, the earlier lanes' */
+                    const uint32_t rank = (((total * 0x01010100u) >> sh) & 0xffu) + ((before >> sh) & 0xffu) +
+                                          (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
                     fcand[seg * (uint32_t)kSeg + rank] = u32x2{p2.key, p2.lo.z}; /* key | height */
                 }
                 if (tid == 2) fncand[seg] = total;
@@ -1006,8 +1021,10 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
         /* ---- in place: published for the next step: row r's edge lanes, the candidates of row r-1 per wave ---- */
         if constexpr (kInPlace) {
             if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
-            const unsigned long long m1 = __ballot(cand1);
-            if (lane == 0) wave_cnt[par ^ 1][wv] = (uint32_t)__popcll(m1);
+            const uint32_t q1 = p1.key & 3u;
+            const uint32_t packed = (uint32_t)__popcll(__ballot(cand1 && q1 == 0u)) | ((uint32_t)__popcll(__ballot(cand1 && q1 == 1u)) << 8) |
+                                    ((uint32_t)__popcll(__ballot(cand1 && q1 == 2u)) << 16) | ((uint32_t)__popcll(__ballot(cand1 && q1 == 3u)) << 24);
+            if (lane == 0) wave_cnt[par ^ 1][wv] = packed;
         }
     };
     /* two extra iterations drain the pipeline */
@@ -1065,55 +1082,66 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_only(BatchPtrs b, Geo
  * (row, strip) order, compacted in column order), so a STABLE sort by cell puts every cell's heights in the order the
  * reference adds them; then one lane per cell adds its run sequentially.
  *
- * One SMALL workgroup per frame (4 waves, the size of a column-walk workgroup, so that it is dispatched into whatever
- * slot a workgroup of the other sub-batch's streaming kernels leaves — an 8-wave / 139 KB workgroup waited for the
- * whole column walk to drain) works through the frame part by part; a part = kPartSegs consecutive segments, so parts
- * in order = slot order.  Per part, everything happens in LDS and registers:
- *   hist    every wave counts its kSegsPerWave segments' candidates per cell (LDS atomics, two 16-bit counters per
- *           word); keys and heights stay in registers
- *   scan    per-cell totals over the waves, exclusive scan over the cells -> the part's runs
- *   place   stable placement into the part's height buffer: lanes of a 64-slice that share a cell rank themselves with
+ * Round 3: FOUR workgroups per frame, by cell mod 4 (cells are independent and a cell lies in one quarter, so the order
+ * inside a cell is untouched).  The walk keeps every segment's candidates as four consecutive runs, one per quarter, each
+ * in column order; workgroup q reads run q of every segment.  A quarter's run of a segment is 35 candidates on average
+ * — one 64-slice — so the unit of work is the SLICE: the quarter's slices are numbered in slot order (a prefix sum over
+ * the segments' slice counts, once per workgroup), a part is 64 consecutive slices — 16 per wave, in registers — and a
+ * quarter walks 8 parts where the one-workgroup form of rounds 1-2 walked 37 (16 segments each): the kernel is a chain
+ * of per-part latencies (histogram, scan, placement, sums, five barriers), not of bytes.  39 KB of LDS instead of 99: four
+ * workgroups per CU, and room beside the column walk of the other stream.  (Round 2's four-workgroup form kept the
+ * 16-segment parts: 37 parts per quarter, 17 % shorter alone and slower in the pipeline; removed, then rebuilt this way.)
+ * Per part, everything happens in LDS and registers:
+ *   hist    every wave counts its 16 slices' candidates per cell (LDS atomics, two 16-bit counters per word); keys and
+ *           heights stay in registers
+ *   scan    per-cell totals over the waves, exclusive scan over the touched cells -> the part's runs
+ *   place   stable placement into the part's height buffer: lanes of a slice that share a cell rank themselves with
  *           ballots (six key bits, a verification, the other six only when it fails): constant work however many
  *           distinct cells a slice has
- *   sum     thread t continues the running (sum, cnt) of cells t, t + 256, ... through their runs of this part
+ *   sum     one thread per touched cell continues the cell's running (sum, cnt) through its run of this part
  * while the next part's keys and heights are already in flight, so the only memory round trip that is ever exposed is
- * the first one.  No intermediate of phase B touches HBM (round 1: the sorted heights bounced through global memory). */
+ * the first one.  No intermediate of phase B touches HBM. */
 constexpr int kCells = kGridCells;
-static_assert(kPartSegs * kSeg <= 4096, "a part's run start (12 bits) and length (13 bits) share a word with room to spare");
-/* one workgroup per frame, all 3750 cells: 99 KB of LDS.  (Round 2 also had a form with four workgroups per frame, cells
- * by cell mod 4, 37 KB each: bit-identical, 17 % shorter alone, but its 1000 high-priority workgroups per sub-batch pushed
- * the front stage aside — 230 k instead of 260 k frames/s — and the walk paid four ballots per row for it; removed in
- * round 3, DESIGN.md.) */
+constexpr int kSumQ = 4;                               /* workgroups per frame: cells by cell mod 4 */
+constexpr int kSlots = 16;                             /* slices a wave keeps in registers per part */
+constexpr int kPartSlices = kSumWaves * kSlots;        /* 64 slices = at most 4096 candidates per part */
 struct SumDims {
-    static constexpr int cells = kCells;
+    static constexpr int cells = (kCells + kSumQ - 1) / kSumQ;
     static constexpr int hist_stride = ((cells + 1) / 2 + 3) / 4 * 4; /* words per wave's histogram: two 16-bit counters per word */
     static constexpr int touch_words = (cells + 31) / 32;
-    static constexpr size_t lds_bytes = sizeof(uint32_t) * ((size_t)kSumWaves * hist_stride + cells + (size_t)kPartSegs * kSeg +
-                                                            2 * (size_t)cells + touch_words + (cells + 1) / 2 + 16);
+    /* hist, start, zbuf, sumv, cntv, tbits, tlist (u16), misc, then per segment: spre (u16, T + 2), cnt8 / rs8 (u8, T each) */
+    static constexpr size_t fixed_words = (size_t)kSumWaves * hist_stride + cells + (size_t)kPartSlices * 64 + 2 * (size_t)cells + touch_words +
+                                          (cells + 1) / 2 + 16;
+    static constexpr size_t seg_words(int T) { return (size_t)(T + 2 + 1) / 2 + 2 * ((size_t)(T + 3) / 4); }
+    static constexpr size_t lds_bytes(int T) { return sizeof(uint32_t) * (fixed_words + seg_words(T)); } /* HDL_64E (459 segments): 39.1 KB */
 };
-size_t cell_sums_lds_bytes() { return SumDims::lds_bytes; }
+static_assert(kPartSlices * 64 <= 4096, "a part's run start (12 bits) and length (13 bits) share a word with room to spare");
+size_t cell_sums_lds_bytes() { return SumDims::lds_bytes(kMaxSegs); }
 
-__global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry g, int nf)
+__global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geometry g, int nf)
 {
     using D = SumDims;
     constexpr int kCellsQ = D::cells, kHistStride = D::hist_stride, kTouchWords = D::touch_words;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *hist = lds;                                 /* [kSumWaves][kHistStride]: 16-bit counts, cells 2i | 2i+1 << 16 */
     uint32_t *start = hist + kSumWaves * kHistStride;     /* [kCellsQ]: the part's runs, start | length << 16 */
-    float *zbuf = reinterpret_cast<float *>(start + kCellsQ); /* [kPartSegs * kSeg]: the part's heights by cell */
-    float *sumv = zbuf + kPartSegs * kSeg;                /* [kCellsQ] running sums */
+    float *zbuf = reinterpret_cast<float *>(start + kCellsQ); /* [kPartSlices * 64]: the part's heights by cell */
+    float *sumv = zbuf + kPartSlices * 64;                /* [kCellsQ] running sums */
     float *cntv = sumv + kCellsQ;                          /* [kCellsQ] running counts */
     uint32_t *tbits = reinterpret_cast<uint32_t *>(cntv + kCellsQ); /* [kTouchWords]: cells this part has touched */
     uint16_t *tlist = reinterpret_cast<uint16_t *>(tbits + kTouchWords); /* [kCellsQ]: ... listed, in any order */
     uint32_t *misc = reinterpret_cast<uint32_t *>(tlist) + (kCellsQ + 1) / 2; /* [0..1] list lengths (by part parity), [4..7] wave sums, [8] carry */
+    const int T = g.segs;
+    uint16_t *spre = reinterpret_cast<uint16_t *>(misc + 16); /* [T + 1]: slices before segment t */
+    uint8_t *cnt8 = reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(spre) + (T + 2 + 1) / 2); /* [T]: this quarter's candidates of segment t */
+    uint8_t *rs8 = cnt8 + 4 * ((T + 3) / 4);               /* [T]: where its run starts inside the segment */
     uint16_t *hist16 = reinterpret_cast<uint16_t *>(hist); /* the same counters, cell c of wave w at [w * 2 * kHistStride + c] */
 
-    const int f = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int T = g.segs, P = g.parts;
+    int f, quarter;
+    if (!map_block_xcd(blockIdx.x, nf, kSumQ, f, quarter)) return; /* the quarters of a frame on one XCD: they read the same lines */
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint2 *ccand = b.cand + (size_t)f * T * kSeg; /* key | height */
     const uint32_t *fn = b.ncand + (size_t)f * T;
-    constexpr int kSl = kSeg / 64;
     PH_DECL;
     PH();
 
@@ -1124,41 +1152,86 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
         sumv[c] = 0.0f;   /* :133-134 */
         cntv[c] = 0.01f;  /* :135-136 */
     }
-
-    /* software pipeline: counts two parts ahead, keys + heights one part ahead */
-    auto load_counts = [&](int p) -> uint32_t { /* lane j < kSegsPerWave: count of this wave's segment j of part p */
-        const int t = p * kPartSegs + wv * kSegsPerWave + lane;
-        return (p < P && lane < kSegsPerWave && t < T) ? fn[t] : 0u;
-    };
-    uint32_t key_n[kSegsPerWave][kSl]; /* next part (raw keys; lanes past the segment's count hold garbage) */
-    float z_n[kSegsPerWave][kSl];
-    int n_n[kSegsPerWave];
-    auto request = [&](int p, uint32_t counts) {
-        const int t0 = p * kPartSegs + wv * kSegsPerWave;
+    /* this quarter's run of every segment (count, start inside the segment) and the number of slices before it.  The walk
+     * wrote a segment's four counts as four bytes; T <= kMaxSegs = 4 * 256: every thread takes four consecutive segments */
+    {
+        uint32_t ns[4], mine = 0u;
 #pragma unroll
-        for (int j = 0; j < kSegsPerWave; ++j) {
-            n_n[j] = __shfl((int)counts, j);
+        for (int k = 0; k < 4; ++k) {
+            const int t = 4 * tid + k;
+            const uint32_t w = t < T ? fn[t] : 0u;
+            const uint32_t sh = 8u * (uint32_t)quarter;
+            const uint32_t cq = (w >> sh) & 0xffu;
+            if (t < T) {
+                cnt8[t] = (uint8_t)cq;
+                rs8[t] = (uint8_t)(((w * 0x01010100u) >> sh) & 0xffu); /* the quarters below it (no byte exceeds the segment's 236) */
+            }
+            ns[k] = (cq + 63u) >> 6;
+            mine += ns[k];
+        }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) misc[4 + wv] = incl;
+        lds_barrier();
+        uint32_t base = incl - mine;
+        for (int w = 0; w < wv; ++w) base += misc[4 + w];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = 4 * tid + k;
+            if (t <= T) spre[t] = (uint16_t)base;
+            base += ns[k];
+        }
+        if (tid == kSumThreads - 1 && 4 * kSumThreads <= T) spre[T] = (uint16_t)base; /* (T == 1024 exactly) */
+        lds_barrier();
+        if (tid == 0) misc[4] = misc[5] = misc[6] = misc[7] = 0u;
+    }
+    const int G = (int)spre[T];                               /* slices of this quarter */
+    const int P = (G + kPartSlices - 1) / kPartSlices;
+
+    /* software pipeline: keys + heights one part ahead.  A wave's 16 slices of part p are slices p * 64 + 16 * wave + j: the
+     * segment of the first one by binary search over the slice prefix, the others by stepping on */
+    uint32_t key_n[kSlots]; /* next part (raw keys; lanes past the slice's count hold garbage) */
+    float z_n[kSlots];
+    int n_n[kSlots];        /* candidates in the slice (0: no such slice) */
+    auto request = [&](int p) {
+        /* lane j < 16 finds slice g0 + j by itself (binary search over the slice prefix: the sixteen searches run side by
+         * side), the wave then reads segment, slice, count and run start of slot j from lane j */
+        const int g0 = p * kPartSlices + wv * kSlots;
+        const int gl = g0 + (lane & (kSlots - 1));
+        int lo = 0;
+        if (gl < G) {
+            int hi = T - 1; /* largest t with spre[t] <= gl: it has a slice of its own, because spre[t + 1] > gl */
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if ((int)spre[mid] <= gl) lo = mid; else hi = mid - 1;
+            }
+        }
+        const int kl = gl - (int)spre[lo];
+        const int cl = (int)cnt8[lo], rl = (int)rs8[lo];
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
             /* whole 64-slices, loaded or skipped by a WAVE-UNIFORM test, and nothing but the loads inside the test: a
              * per-lane predicated load makes the compiler branch around it and wait for the data inside the branch —
-             * one round trip after the other (this loop took 4 us per part that way).  Lanes past the count read stale
-             * entries of the segment (allocated memory) and are masked where the values are used. */
-            const int n = __builtin_amdgcn_readfirstlane(n_n[j]);
-            const size_t at = (size_t)(t0 + j) * kSeg + lane;
-#pragma unroll
-            for (int k = 0; k < kSl; ++k) {
-                key_n[j][k] = 0u;
-                z_n[j][k] = 0.f;
-                if (64 * k < n) {
-                    const uint2 kz = ccand[at + 64 * k];
-                    key_n[j][k] = kz.x;
-                    z_n[j][k] = __uint_as_float(kz.y);
-                }
+             * one round trip after the other.  Lanes past the count read stale entries of the segment (allocated
+             * memory) and are masked where the values are used. */
+            const bool on = g0 + j < G; /* wave-uniform */
+            const int t = __builtin_amdgcn_readlane(lo, j), k = __builtin_amdgcn_readlane(kl, j);
+            const int cq = __builtin_amdgcn_readlane(cl, j), rs = __builtin_amdgcn_readlane(rl, j);
+            n_n[j] = on ? (cq - 64 * k < 64 ? cq - 64 * k : 64) : 0;
+            key_n[j] = 0u;
+            z_n[j] = 0.f;
+            if (on) {
+                const uint2 kz = ccand[(size_t)t * kSeg + rs + 64 * k + lane];
+                key_n[j] = kz.x;
+                z_n[j] = __uint_as_float(kz.y);
             }
         }
     };
-    uint32_t cnt_next = load_counts(0);
-    request(0, cnt_next);
-    cnt_next = load_counts(1);
+    request(0);
     lds_barrier(); /* LDS state initialised */
 
     uint32_t *myhist = hist + wv * kHistStride;
@@ -1167,67 +1240,68 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
         PHA(7);
         const int par = p & 1;
         /* part p's data into the "current" registers, part p + 1 requested */
-        uint32_t cell[kSegsPerWave][kSl];
-        float zz[kSegsPerWave][kSl];
-        int nn[kSegsPerWave];
+        uint32_t cell[kSlots];
+        float zz[kSlots];
+        int nn[kSlots];
 #pragma unroll
-        for (int j = 0; j < kSegsPerWave; ++j) {
+        for (int j = 0; j < kSlots; ++j) {
             nn[j] = n_n[j];
-#pragma unroll
-            for (int k = 0; k < kSl; ++k) {
-                cell[j][k] = lane + 64 * k < nn[j] ? (key_n[j][k] & kKeyCellMask) : 0xfffu; /* 0xfff: no candidate */
-                zz[j][k] = z_n[j][k];
-            }
+            cell[j] = lane < nn[j] ? ((key_n[j] & kKeyCellMask) >> 2) : 0xfffu; /* 0xfff: no candidate */
+            zz[j] = z_n[j];
         }
-        request(p + 1, cnt_next);
-        cnt_next = load_counts(p + 2);
+        request(p + 1);
         PHA(5);
 
-        /* hist.  Lanes of a 64-slice that hold the same cell find each other with one ballot per key bit (see below; 12
-         * bits cover 3750 cells; 0xfff is not a cell): constant work however many distinct cells the slice has.  Every lane keeps
-         * its rank inside its group, the group's size and whether it leads the group in the spare bits of its cell
-         * register (cell | rank << 12 | size << 18 | leader << 25), so the placement below needs no second look.
-         * Only leaders touch the histogram (64 LDS atomics on one address would serialise).  The first leader to touch
-         * a cell in this part lists it: everything after this phase works on the listed cells only. */
+        /* hist.  Lanes of a 64-slice that hold the same cell find each other with one ballot per key bit (10 bits cover
+         * the quarter's 938 cells; 0xfff is not a cell): constant work however many distinct cells the slice has, and
+         * nothing but vector / scalar ALU (rounds 1-2 took six ballots, fetched the group leader's cell through the LDS
+         * pipe to verify and took the other bits only on a mismatch: a round trip per slice on the critical path).  Every
+         * lane keeps its rank inside its group, the group's size and whether it leads the group in the spare bits of its
+         * cell register (cell | rank << 12 | size << 18 | leader << 25), so the placement below needs no second look.
+         * Only leaders touch the histogram (64 LDS atomics on one address would serialise) and mark their cell touched —
+         * without waiting for an answer: the list of touched cells is made from the marks after the barrier. */
 #pragma unroll
-        for (int j = 0; j < kSegsPerWave; ++j) {
+        for (int j = 0; j < kSlots; ++j) {
+            if (nn[j] == 0) break; /* wave-uniform */
+            const uint32_t c = cell[j];
+            const bool valid = c != 0xfffu;
+            unsigned long long peers = __ballot(valid);
 #pragma unroll
-            for (int k = 0; k < kSl; ++k) {
-                if (64 * k >= nn[j]) break; /* wave-uniform */
-                const uint32_t c = cell[j][k];
-                const bool valid = c != 0xfffu;
-                /* the cells of 64 consecutive slots are neighbours on the grid (numbers that differ by 1, 49, 50, 51):
-                 * their low six bits tell them apart; the group's first lane shows its whole cell, and only a slice
-                 * where somebody disagrees (far-apart cells with equal low bits) takes all twelve ballots */
-                unsigned long long peers = __ballot(valid);
-#pragma unroll
-                for (int bit = 0; bit < 6; ++bit) {
-                    const bool one = (c >> bit) & 1u;
-                    const unsigned long long bal = __ballot(one);
-                    peers &= one ? bal : ~bal;
-                }
-                const int first = valid ? __ffsll((long long)peers) - 1 : lane;
-                const uint32_t cf = (uint32_t)__builtin_amdgcn_ds_bpermute(first << 2, (int)c);
-                if (__ballot(valid && cf != c) != 0ull) { /* wave-uniform, rare */
-#pragma unroll
-                    for (int bit = 6; bit < 12; ++bit) {
-                        const bool one = (c >> bit) & 1u;
-                        const unsigned long long bal = __ballot(one);
-                        peers &= one ? bal : ~bal;
-                    }
-                }
-                const unsigned long long lower = peers & ((1ull << lane) - 1ull);
-                const uint32_t size = (uint32_t)__popcll(peers), rank = (uint32_t)__popcll(lower);
-                const bool leader = valid && lower == 0ull;
-                if (leader) {
-                    atomicAdd(&myhist[c >> 1], size << (16 * (c & 1u)));
-                    const uint32_t bit = 1u << (c & 31u);
-                    if (!(atomicOr(&tbits[c >> 5], bit) & bit)) tlist[atomicAdd(&misc[par], 1u)] = (uint16_t)c;
-                }
-                if (valid) cell[j][k] = c | (rank << 12) | (size << 18) | (leader ? 1u << 25 : 0u);
+            for (int bit = 0; bit < 10; ++bit) {
+                const bool one = (c >> bit) & 1u;
+                const unsigned long long bal = __ballot(one);
+                peers &= one ? bal : ~bal;
             }
+            const unsigned long long lower = peers & ((1ull << lane) - 1ull);
+            const uint32_t size = (uint32_t)__popcll(peers), rank = (uint32_t)__popcll(lower);
+            const bool leader = valid && lower == 0ull;
+            if (leader) {
+                atomicAdd(&myhist[c >> 1], size << (16 * (c & 1u)));
+                atomicOr(&tbits[c >> 5], 1u << (c & 31u));
+            }
+            if (valid) cell[j] = c | (rank << 12) | (size << 18) | (leader ? 1u << 25 : 0u);
         }
         PHA(6);
+        lds_barrier();
+        /* the touched cells, listed: the first wave takes one 32-cell word of marks per lane */
+        if (wv == 0) {
+            uint32_t word = lane < kTouchWords ? tbits[lane] : 0u;
+            const uint32_t mine = (uint32_t)__popc(word);
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const uint32_t v = __shfl_up(incl, d);
+                if (lane >= d) incl += v;
+            }
+            static_assert(kTouchWords <= 32, "one word of marks per lane of half a wave");
+            if (lane == kTouchWords - 1) misc[par] = incl;
+            uint32_t at = incl - mine;
+            while (word) { /* (at most 32 turns, for the few lanes whose cells are all touched) */
+                const uint32_t bit = (uint32_t)__ffs((int)word) - 1u;
+                word &= word - 1u;
+                tlist[at++] = (uint16_t)(32u * (uint32_t)lane + bit);
+            }
+        }
         lds_barrier();
         PHA(0);
 
@@ -1265,22 +1339,18 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
         if (tid == 0) misc[8] = 0u;
         PHA(2);
 
-        /* stable placement: slices in slot order (segment by segment, 64 candidates at a time); position = the cell's
-         * run start + this wave's cursor inside the run + the lane's rank in its group; the group's leader then
-         * advances the cursor (the reads are issued before that update: same wave, program order; two cells of one
-         * word may both advance: atomic) */
+        /* stable placement: slices in slot order; position = the cell's run start + this wave's cursor inside the run +
+         * the lane's rank in its group; the group's leader then advances the cursor (the reads are issued before that
+         * update: same wave, program order; two cells of one word may both advance: atomic) */
 #pragma unroll
-        for (int j = 0; j < kSegsPerWave; ++j) {
-#pragma unroll
-            for (int k = 0; k < kSl; ++k) {
-                if (64 * k >= nn[j]) break; /* wave-uniform */
-                const uint32_t v = cell[j][k];
-                const uint32_t c = v & 0xfffu;
-                if (c != 0xfffu) {
-                    const uint32_t off = (myhist[c >> 1] >> (16 * (c & 1u))) & 0xffffu;
-                    zbuf[(start[c] & 0xffffu) + off + ((v >> 12) & 63u)] = zz[j][k];
-                    if (v & (1u << 25)) atomicAdd(&myhist[c >> 1], ((v >> 18) & 127u) << (16 * (c & 1u)));
-                }
+        for (int j = 0; j < kSlots; ++j) {
+            if (nn[j] == 0) break; /* wave-uniform */
+            const uint32_t v = cell[j];
+            const uint32_t c = v & 0xfffu;
+            if (c != 0xfffu) {
+                const uint32_t off = (myhist[c >> 1] >> (16 * (c & 1u))) & 0xffffu;
+                zbuf[(start[c] & 0xffffu) + off + ((v >> 12) & 63u)] = zz[j];
+                if (v & (1u << 25)) atomicAdd(&myhist[c >> 1], ((v >> 18) & 127u) << (16 * (c & 1u)));
             }
         }
         lds_barrier();
@@ -1295,7 +1365,10 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
             for (int w = 0; w < kSumWaves; ++w) hist16[w * 2 * kHistStride + c] = 0;
             int q = (int)(se & 0xffffu);
             const int e = q + (int)(se >> 16);
-            float sj = sumv[c], cj = cntv[c];
+            float sj = sumv[c];
+            /* the count of the run in one go (bev_exact.h: the reference's "cnt = cnt + 1" steps are exact inside a
+             * binade): the loop below is the sum's chain alone */
+            cntv[c] = count_advance(cntv[c], se >> 16); /* :205-206 */
             /* the adds of one cell are a serial chain (that IS the reference's order); what can be hidden is the LDS
              * latency: the next 8 heights are requested before the current 8 are added */
             if (q + 8 <= e) {
@@ -1308,27 +1381,17 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
 #pragma unroll
                     for (int u = 0; u < 8; ++u) nx[u] = zbuf[q + 8 + u];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        sj += v[u];       /* :198-199 */
-                        cj = cj + 1.0f;   /* :205-206 */
-                    }
+                    for (int u = 0; u < 8; ++u) sj += v[u]; /* :198-199 */
 #pragma unroll
                     for (int u = 0; u < 8; ++u) v[u] = nx[u];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    sj += v[u];
-                    cj = cj + 1.0f;
-                }
+                for (int u = 0; u < 8; ++u) sj += v[u];
                 q += 8;
             }
 #pragma unroll 1
-            for (; q < e; ++q) {
-                sj += zbuf[q];
-                cj = cj + 1.0f;
-            }
+            for (; q < e; ++q) sj += zbuf[q];
             sumv[c] = sj;
-            cntv[c] = cj;
         }
         lds_barrier(); /* the next part overwrites start and zbuf; hist and tbits are clean */
         PHA(4);
@@ -1336,7 +1399,8 @@ __global__ __launch_bounds__(kSumThreads) void k_cell_sums(BatchPtrs b, Geometry
     PHA_PRINT("cell_sums barrier0 - scan place sum request histloop looptop", tid == 0 && blockIdx.x == 100);
     PH();
     float *avg = b.avg + (size_t)f * kCells;
-    for (int c = tid; c < kCellsQ; c += kSumThreads) avg[c] = sumv[c] / cntv[c]; /* :210 */
+    for (int c = tid; c < kCellsQ; c += kSumThreads)
+        if (c * kSumQ + quarter < kCells) avg[c * kSumQ + quarter] = sumv[c] / cntv[c]; /* :210 */
     PH_PRINT("cell_sums all-parts", tid == 0 && blockIdx.x == 100);
 }
 
@@ -1394,7 +1458,10 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = g.segs;
     const int t0 = (int)((long long)T * part / kResolveParts), t1 = (int)((long long)T * (part + 1) / kResolveParts);
-    for (int i = tid; i < t1 - t0; i += kResolveThreads) cnt[i] = (uint16_t)b.ncand[(size_t)f * T + t0 + i];
+    for (int i = tid; i < t1 - t0; i += kResolveThreads) {
+        const uint32_t w = b.ncand[(size_t)f * T + t0 + i]; /* four byte-wide counts: the segment's runs by cell quarter, back to back */
+        cnt[i] = (uint16_t)((w & 0xffu) + ((w >> 8) & 0xffu) + ((w >> 16) & 0xffu) + (w >> 24));
+    }
     for (int c = tid; c < kCells; c += kResolveThreads) avg[c] = b.avg[(size_t)f * kCells + c];
     if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
     else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
@@ -1837,7 +1904,7 @@ __global__ __launch_bounds__(256) void k_angle_debug(const float *dx, const floa
 hipError_t configure_kernels(const Geometry &g)
 {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cell_sums),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SumDims::lds_bytes);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SumDims::lds_bytes(kMaxSegs));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)raster_lds_bytes(g));
@@ -1889,7 +1956,7 @@ void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream
 void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_cell_sums, dim3(nf), dim3(kSumThreads), SumDims::lds_bytes, st, b, g, nf);
+    hipLaunchKernelGGL(k_cell_sums, dim3(xcd_grid(nf, kSumQ)), dim3(kSumThreads), SumDims::lds_bytes(g.segs), st, b, g, nf);
 }
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st)
 {

@@ -174,6 +174,32 @@ uint64_t hc_angle_nodiv_check(uint64_t n)
     return bad;
 }
 
+/* count_advance against the reference's step-by-step count: from 0.01f, every n up to n_max in one go, and chains of
+ * random run lengths (the state after one call is the start of the next); returns mismatches */
+uint64_t hc_count_advance_check(uint32_t n_max)
+{
+    uint64_t bad = 0;
+    float seq = 0.01f;
+    for (uint32_t n = 1; n <= n_max; ++n) {
+        seq = seq + 1.0f;
+        if (float_bits(count_advance(0.01f, n)) != float_bits(seq)) ++bad;
+    }
+    uint64_t z = 88172645463325252ULL;
+    for (int chain = 0; chain < 200; ++chain) {
+        float a = 0.01f, b = 0.01f;
+        uint32_t total = 0;
+        while (total < n_max) {
+            z ^= z << 13; z ^= z >> 7; z ^= z << 17;
+            const uint32_t run = 1u + (uint32_t)(z % ((chain & 1) ? 700u : 9u));
+            a = count_advance(a, run);
+            for (uint32_t k = 0; k < run; ++k) b = b + 1.0f;
+            total += run;
+            if (float_bits(a) != float_bits(b)) { ++bad; break; }
+        }
+    }
+    return bad;
+}
+
 int hc_ground_cell(float x, float y) { return ground_cell(x, y); }
 
 /* exact_reciprocal (bev_exact.h): for every power of two v it accepts, x / v == x * (1 / v) bit for bit over `samples`

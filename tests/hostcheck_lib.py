@@ -23,6 +23,8 @@ def lib():
         l.hc_ground_cell.argtypes = [C.c_float, C.c_float]
         l.hc_bev_code.argtypes = [C.POINTER(BevParams), C.c_float, C.c_float, C.c_float, C.c_int]
         l.hc_bev_code.restype = C.c_uint32
+        l.hc_count_advance_check.argtypes = [C.c_uint32]
+        l.hc_count_advance_check.restype = C.c_uint64
         l.hc_angle_nodiv_check.argtypes = [C.c_uint64]
         l.hc_angle_nodiv_check.restype = C.c_uint64
         l.hc_exact_reciprocal_check.argtypes = [C.c_uint64]

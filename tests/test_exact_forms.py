@@ -27,3 +27,10 @@ def test_angle_predicate_without_the_division():
     midpoint between the threshold and its successor) against the division form, BatchMultiBevGen.cpp:173-179: random
     bit patterns, the walk's magnitudes, pairs straddling the cut by up to four ulps over sixty binades, special values."""
     assert hc.lib().hc_angle_nodiv_check(40_000_000) == 0
+
+
+def test_count_of_a_cell_in_one_step():
+    """bev_exact.h count_advance: n of the reference's `cnt = cnt + 1` float steps (BatchMultiBevGen.cpp:205-206, from
+    0.01f, :135-136) at once — one exact addition per binade plus the rounding steps — against the step-by-step loop,
+    for every n up to 2^21 (more than the slots of the largest range image) and for chains of random run lengths."""
+    assert hc.lib().hc_count_advance_check(1 << 21) == 0
