@@ -220,9 +220,11 @@ def main() -> int:
     # whose read of it cannot be avoided — the column walk when P ~ S (it gathers every point it writes), the order scan
     # when P >> S (oxford_concat: 2 M points into 33,792 slots; the walk then only gathers the S winners)
     if args.workload == "oxford_concat":
-        own_bytes = {"k_order_scan": 32.0 * mean_pts, "k_walk": 32.0 * S, "k_bev_raster": float(L * M * M + M * M)}
-    else:
-        own_bytes = {"k_walk": 32.0 * mean_pts + 32.0 * S, "k_bev_raster": float(L * M * M + M * M)}
+        own_bytes = {"k_order_scan": 32.0 * mean_pts, "k_walk": 32.0 * S, "k_walk_general": 32.0 * S,
+                     "k_bev_raster": float(L * M * M + M * M)}
+    else:  # k_walk: frames read in place; k_walk_general: frames that go through the winner table (only one of the two moves a frame)
+        own_bytes = {"k_walk": 32.0 * mean_pts + 32.0 * S, "k_walk_general": 32.0 * mean_pts + 32.0 * S,
+                     "k_bev_raster": float(L * M * M + M * M)}
     roofline = None
     kernels = []
     kernels_pipelined = [{"name": s["name"], "launches": s["launches"], "avg_launch_ms": s["total_ms"] / s["launches"],
@@ -254,7 +256,7 @@ def main() -> int:
                     continue
                 pmc = json.loads(pmc_file.read_text())
                 for kname, kv in pmc["kernels"].items():
-                    if kname.split("<")[0] == dom["name"] and kv.get("hbm_bytes_per_frame", 0) > 1e5:  # (the in-place instantiation, not the empty redo launch)
+                    if kname.split("<")[0] == dom["name"].replace("_general", "") and kv.get("hbm_bytes_per_frame", 0) > 1e5:  # (the instantiation that moved the frames, not the empty launch)
                         traffic = kv["hbm_bytes_per_frame"] * per_launch_frames
                         traffic_src = f"profiles/{name}: {pmc.get('source', 'rocprofv3 --pmc')}"
                 traffic_total = pmc.get("hbm_bytes_per_frame_all_kernels")

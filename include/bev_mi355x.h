@@ -239,7 +239,8 @@ int bev_debug_get_cell_avg(bev_ctx_t *ctx, int first_frame, int n_frames, float 
 /* Test hook: how the frames of the LAST sub-batch reached their slots (getOrderedCloud, BatchMultiBevGen.cpp:94-117).
  * out[4 * i .. 4 * i + 3] = { T, mode, consumed, failed } of frame first_frame + i: mode 0 = order scan over all points,
  * 1 = the first T points were read in place (sorted prefix, verified: consumed == T, failed == 0), 2 = read in place,
- * verification failed, done again the general way.  Results never depend on the mode. */
+ * verification failed, done again the general way.  Results never depend on the mode (reading in place is the default for
+ * frames that qualify; BEV_STREAM=0 in the environment of bev_create turns it off). */
 int bev_debug_get_frame_info(bev_ctx_t *ctx, int first_frame, int n_frames, uint32_t *out);
 /* Evaluates the phase-A angle predicate (BatchMultiBevGen.cpp:169-179) on the
  * device for n (dx,dy,dz) triples given as HOST arrays; out[i] = 1 if GROUND. */

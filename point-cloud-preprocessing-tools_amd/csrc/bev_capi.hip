@@ -45,6 +45,7 @@ struct Lane {
     hipEvent_t done = nullptr;
     hipEvent_t front_done = nullptr, back_done = nullptr; /* staged mode: workspace hand-over between the two stages */
     FrameInfo *info = nullptr;  /* per frame: how its points reach their slots (k_probe / k_verdict) */
+    uint32_t *hint = nullptr;   /* mapped host word: frames of the set's last sub-batch that were NOT read in place (k_verdict) */
     uint32_t *est = nullptr;    /* stream frames: estimated input position of every (row, strip)'s first slot */
     uint32_t *tail_list = nullptr, *tail_cnt = nullptr; /* ... and their tail points per (row, strip) (stream mode only) */
     uint32_t *winner = nullptr;
@@ -478,20 +479,21 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                 ProfScope ps(c, K_PROBE, nb, st);
                 launch_probe(g, b, nb, c->allow_stream, st);
             }
-            {
+            if (c->allow_stream) { /* frames k_probe found sorted up to a tail: read in place, verified */
+                ProfScope ps(c, K_GATHER_GROUND, nb, st);
+                launch_gather_ground(g, b, nb, 2, kFrameStream, st);
+                launch_verdict(b, nb, ln.hint, st);
+            }
+            {   /* every other frame — general, or read in place and failed (normally none of a sorted sub-batch).  Thin
+                 * launch while this workspace set's earlier sub-batches were read in place entirely (a hint that k_verdict
+                 * leaves in mapped host memory; read without waiting: it only chooses the launch shape) */
+                const bool thin = c->allow_stream && ln.hint && *reinterpret_cast<volatile uint32_t *>(ln.hint) == 0u;
                 ProfScope ps(c, K_ORDER_SCAN, nb, st);
-                launch_order_scan(g, b, nb, max_pts, 0, st);
+                launch_order_scan(g, b, nb, max_pts, thin, st);
             }
             {
-                ProfScope ps(c, K_GATHER_GROUND, nb, st);
+                ProfScope ps(c, K_WALK_GENERAL, nb, st);
                 launch_gather_ground(g, b, nb, 0, kFrameGeneral, st);
-                if (c->allow_stream) {
-                    launch_gather_ground(g, b, nb, 2, kFrameStream, st);
-                    /* stream frames that failed their verification: once more, the general way (normally none) */
-                    launch_verdict(b, nb, st);
-                    launch_order_scan(g, b, nb, max_pts, 1, st);
-                    launch_gather_ground(g, b, nb, 0, kFrameRedo, st);
-                }
             }
         }
         /* One-time stagger: a lane's FIRST sub-batch starts only after the previous lane has issued its
@@ -717,6 +719,8 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ln.front_done, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ln.back_done, hipEventDisableTiming));
+        CK(hipHostMalloc((void **)&ln.hint, sizeof(uint32_t), hipHostMallocMapped));
+        *ln.hint = 0u;
         CK(hipMalloc((void **)&ln.info, nb * sizeof(FrameInfo)));
         CK(hipMemset(ln.info, 0, nb * sizeof(FrameInfo)));
         CK(hipMalloc((void **)&ln.est, nb * (size_t)c->geo.N * c->geo.strips * sizeof(uint32_t)));
@@ -759,6 +763,7 @@ void bev_destroy(bev_ctx_t *c)
         void *ws[] = {ln.info, ln.est, ln.tail_list, ln.tail_cnt, ln.winner, ln.cand, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
         for (void *p : ws)
             if (p) (void)hipFree(p);
+        if (ln.hint) (void)hipHostFree(ln.hint);
         if (ln.done) (void)hipEventDestroy(ln.done);
         if (ln.front_done) (void)hipEventDestroy(ln.front_done);
         if (ln.back_done) (void)hipEventDestroy(ln.back_done);
@@ -918,7 +923,7 @@ int bev_order_cloud(bev_ctx_t *c, const bev_point_t *pts, uint32_t n_pts, bev_po
     HIPCK(c, hipMemsetAsync(c->winner, 0, S * sizeof(uint32_t), c->stream));
     {
         ProfScope ps(c, K_ORDER_SCAN, 1);
-        launch_order_scan(g, b, 1, n_pts, 0, c->stream); /* b.info == nullptr: the whole cloud */
+        launch_order_scan(g, b, 1, n_pts, false, c->stream); /* b.info == nullptr: the whole cloud */
     }
     {
         ProfScope ps(c, K_GATHER_ONLY, 1);

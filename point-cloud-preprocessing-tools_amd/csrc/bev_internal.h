@@ -127,6 +127,7 @@ enum KernelId {
     K_PROJECT,
     K_TRANSFORM,
     K_PROBE,
+    K_WALK_GENERAL, /* the walk through the winner table (K_GATHER_GROUND: the walk that reads in place, or the identity walk) */
     K_COUNT
 };
 const char *kernel_name(int id);
@@ -134,13 +135,13 @@ const char *kernel_name(int id);
 int raster_bands_for(int mat_size);
 
 /* launchers (bev_kernels.hip) — all asynchronous on `st` */
-/* pass 0: general frames only (frames read in place have no winner entries: their tail is listed by k_probe); pass 1: redo frames, whole */
-void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, int pass, hipStream_t st);
-/* the column walk.  source 0: through the winner table, frames of mode `mode`; 1: identity, b.pts already is the ordered
- * cloud (bev_mark_ground); 2: stream frames */
+/* the frames that are not read in place: general ones and (after k_verdict) those whose verification failed */
+void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, bool thin, hipStream_t st);
+/* the column walk.  source 0: through the winner table (frames of every mode but kFrameStream); 1: identity, b.pts
+ * already is the ordered cloud (bev_mark_ground); 2: in place (frames of mode kFrameStream: pass mode = kFrameStream) */
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int source, uint32_t mode, hipStream_t st);
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st);
-void launch_verdict(const BatchPtrs &b, int nf, hipStream_t st);
+void launch_verdict(const BatchPtrs &b, int nf, uint32_t *host_hint, hipStream_t st);
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
 void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, bool identity, hipStream_t st);

@@ -63,7 +63,7 @@ namespace bevk {
 static const char *const kNames[K_COUNT] = {
     "k_order_scan", "k_walk", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project", "k_transform",
-    "k_probe",
+    "k_probe", "k_walk_general",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
 
@@ -275,12 +275,26 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
 }
 
 /* after the stream walk: a frame whose consumed points do not add up to its prefix, or with a failed check, is redone */
-__global__ __launch_bounds__(256) void k_verdict(FrameInfo *info, int nf)
+/* ... and the host is told, without being waited for, how many frames of the sub-batch are NOT read in place (a word in
+ * mapped host memory): the next sub-batches' order scan is launched thin or wide by it — a hint about speed, the thin
+ * and the wide launch compute the same */
+__global__ __launch_bounds__(1024) void k_verdict(FrameInfo *info, int nf, uint32_t *host_hint)
 {
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= nf) return;
-    FrameInfo fi = info[f];
-    if (fi.mode == kFrameStream && (fi.failed != 0u || fi.consumed != fi.T)) info[f].mode = kFrameRedo;
+    __shared__ uint32_t others;
+    if (threadIdx.x == 0) others = 0u;
+    __syncthreads();
+    uint32_t mine = 0u;
+    for (int f = threadIdx.x; f < nf; f += 1024) {
+        FrameInfo fi = info[f];
+        if (fi.mode == kFrameStream && (fi.failed != 0u || fi.consumed != fi.T)) {
+            info[f].mode = kFrameRedo;
+            fi.mode = kFrameRedo;
+        }
+        mine += fi.mode != kFrameStream ? 1u : 0u;
+    }
+    if (mine) atomicAdd(&others, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && host_hint) __hip_atomic_store(host_hint, others, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -292,27 +306,30 @@ constexpr int kScanIdxBits = 10; /* 256 * kScanPerThread = 1024 points per block
 constexpr int kScanRowBins = 128; /* rows the LDS regrouping below can bin (more rows: plain path) */
 __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restrict__ pts,
                                                     const FrameDesc *__restrict__ frames,
-                                                    const FrameInfo *__restrict__ info, int pass,
+                                                    const FrameInfo *__restrict__ info,
                                                     uint32_t *__restrict__ winner, int N, int H, int S,
                                                     uint32_t tag_bits)
 {
+    /* One launch, after the in-place walk and its verdict: the frames that are NOT read in place — general ones and
+     * those whose verification failed.  (A frame read in place has no winner entries; its tail is listed by k_probe.)
+     * gridDim.x workgroups per frame stride over its 1024-point blocks (launch_order_scan: one per block, or 8 per frame
+     * for the launch that is expected to find nothing to do). */
     const int f = blockIdx.y;
+    if (info && info[f].mode == kFrameStream) return;
     const FrameDesc fd = frames[f];
-    const uint32_t block0 = blockIdx.x * (256u * kScanPerThread);
-    const uint32_t base = block0 + threadIdx.x;
-    if (block0 >= fd.n_pts) return;
-    /* pass 0: general frames only (a frame read in place has its tail listed by k_probe); pass 1: redo frames, whole */
-    if (info) {
-        const FrameInfo fi = info[f];
-        if (pass == 0) {
-            if (fi.mode == kFrameStream) return; /* read in place by the stream walk; k_probe has listed its tail */
-        } else if (fi.mode != kFrameRedo) {
-            return;
-        }
-    } else if (pass != 0) {
-        return;
-    }
     const bev_point_t *fp = pts + fd.in_offset;
+    uint32_t *fw = winner + (size_t)f * S;
+    __shared__ uint32_t any_spread2[2]; /* (by block parity: a thread may still read one block's flag while the next block's is cleared) */
+    __shared__ uint32_t row_fill[kScanRowBins];
+    /* (slot << kScanIdxBits | index within the block) regrouped by row; 4 B per point, not 8: LDS is what decides how many of these
+     * blocks fit on a CU beside the back end's workgroups of another sub-batch */
+    __shared__ uint32_t pairs[256 * kScanPerThread];
+    static_assert(256 * kScanPerThread == (1 << kScanIdxBits), "bits of block-local index");
+  uint32_t turn = 0u;
+  for (uint32_t blk = blockIdx.x; blk * (256u * kScanPerThread) < fd.n_pts; blk += gridDim.x, ++turn) { /* (uniform trip count) */
+    uint32_t &any_spread = any_spread2[turn & 1u];
+    const uint32_t block0 = blk * (256u * kScanPerThread);
+    const uint32_t base = block0 + threadIdx.x;
     uint32_t slot[kScanPerThread];
     bool spread = false; /* does any wave-instruction's worth of 64 points straddle far-apart slots? */
     uint32_t rcw[kScanPerThread];
@@ -328,7 +345,6 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
         slot[k] = (i < fd.n_pts && row < (uint32_t)N && col < (uint32_t)H) ? row * (uint32_t)H + col
                                                                                          : 0xffffffffu; /* :106-111 ("< 0" is dead: u16) */
     }
-    uint32_t *fw = winner + (size_t)f * S;
 #pragma unroll
     for (int k = 0; k < kScanPerThread; ++k) {
         /* slots of a sorted cloud rise by ~1 per lane; a wave whose first and last valid lanes are more
@@ -341,12 +357,6 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
             spread = spread || d > 4u * (uint32_t)H;
         }
     }
-    __shared__ uint32_t any_spread;
-    __shared__ uint32_t row_fill[kScanRowBins];
-    /* (slot << kScanIdxBits | index within the block) regrouped by row; 4 B per point, not 8: LDS is what decides how many of these
-     * blocks fit on a CU beside a k_cell_sums / k_bev_raster workgroup of another sub-batch */
-    __shared__ uint32_t pairs[256 * kScanPerThread];
-    static_assert(256 * kScanPerThread == (1 << kScanIdxBits), "bits of block-local index");
     if (threadIdx.x == 0) any_spread = 0u;
     __syncthreads();
     if (spread && (threadIdx.x & 63) == 0) any_spread = 1u;
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
 #pragma unroll
         for (int k = 0; k < kScanPerThread; ++k)
             if (slot[k] != 0xffffffffu) atomicMax(&fw[slot[k]], tag_bits | (base + 256u * k + 1u));
-        return;
+        continue; /* (workgroup-uniform) */
     }
     /* Scattering input: regroup the block's (slot, index) pairs by row in LDS (atomicMax is order-free,
      * so an unstable counting sort is enough); a wave then sends its atomics to one row and nearby
@@ -392,8 +402,9 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
     for (int k = 0; k < kScanPerThread; ++k) {
         const uint32_t j = threadIdx.x + 256u * k;
         const uint32_t pr = pairs[j];
-        if (pr != 0xffffffffu) atomicMax(&fw[pr >> kScanIdxBits], tag_bits | (blockIdx.x * (256u * kScanPerThread) + (pr & ((1u << kScanIdxBits) - 1u)) + 1u));
+        if (pr != 0xffffffffu) atomicMax(&fw[pr >> kScanIdxBits], tag_bits | (block0 + (pr & ((1u << kScanIdxBits) - 1u)) + 1u));
     }
+  }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -540,7 +551,7 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
     static_assert(kWinPos == 256 && kStripVirt + 16 <= kWinPos && kTailCap == 64 && kWrapPos == 16, "DMA pieces of the in-place source");
     int f, strip;
     if (!map_block_xcd(blockIdx.x, nf, g.strips, f, strip)) return;
-    if (!kIdentity && b.info && b.info[f].mode != want_mode) return; /* another launch of the walk has the frame */
+    if (!kIdentity && b.info && (b.info[f].mode == kFrameStream) != (want_mode == kFrameStream)) return; /* the other launch of the walk has the frame */
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = g.N, H = g.H, lo_row = g.N - g.G, strips = g.strips;
     const size_t frame_off = (size_t)f * g.S;
@@ -1912,12 +1923,15 @@ hipError_t configure_kernels(const Geometry &g)
     return hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster_dense),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)raster_lds_bytes(g));
 }
-void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, int pass, hipStream_t st)
+void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, bool thin, hipStream_t st)
 {
     if (max_pts == 0 || nf == 0) return;
     const unsigned per_block = 256u * kScanPerThread;
-    dim3 grid((max_pts + per_block - 1u) / per_block, (unsigned)nf);
-    hipLaunchKernelGGL(k_order_scan, grid, dim3(256), 0, st, b.pts, b.frames, b.info, pass, b.winner, g.N, g.H, g.S,
+    const unsigned blocks = (max_pts + per_block - 1u) / per_block;
+    /* wide: one workgroup per 1024-point block (every load of a frame in flight at once: 20 % faster when frames do go
+     * this way); thin: 8 per frame striding over the blocks, for the launch that is expected to find nothing to do */
+    dim3 grid(thin && blocks > 8u ? 8u : blocks, (unsigned)nf);
+    hipLaunchKernelGGL(k_order_scan, grid, dim3(256), 0, st, b.pts, b.frames, b.info, b.winner, g.N, g.H, g.S,
                        b.win_tag << b.win_shift);
 }
 template <int kSrc>
@@ -1943,10 +1957,10 @@ void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stre
     if (nf == 0) return;
     hipLaunchKernelGGL(k_probe, dim3(nf), dim3(kProbeThreads), 0, st, b, g, allow_stream ? 1 : 0);
 }
-void launch_verdict(const BatchPtrs &b, int nf, hipStream_t st)
+void launch_verdict(const BatchPtrs &b, int nf, uint32_t *host_hint, hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_verdict, dim3((nf + 255) / 256), dim3(256), 0, st, b.info, nf);
+    hipLaunchKernelGGL(k_verdict, dim3(1), dim3(1024), 0, st, b.info, nf, host_hint);
 }
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {

@@ -31,7 +31,7 @@ def _both(sp, pts):
     return a, gma, b, gmb
 
 
-def test_baseline_frames_no_label_depends_on_the_overload_reading():
+def test_baseline_frames_overload_readings_differ_in_at_most_ten_slots():
     p = bev_amd.params_for_sensor("HDL_64E")
     sp = orc.sensor_from_params(p)
 
