@@ -1120,11 +1120,11 @@ struct SumDims {
     static constexpr int cells = (kCells + kSumQ - 1) / kSumQ;
     static constexpr int hist_stride = ((cells + 1) / 2 + 3) / 4 * 4; /* words per wave's histogram: two 16-bit counters per word */
     static constexpr int touch_words = (cells + 31) / 32;
-    /* hist, start, zbuf, sumv, cntv, tbits, tlist (u16), misc, then per segment: spre (u16, T + 2), cnt8 / rs8 (u8, T each) */
+    /* hist, start, zbuf, sumv, cntv, tbits, tlist (u16), misc, then per segment: cpre (u32, T + 1), rs8 (u8, T) */
     static constexpr size_t fixed_words = (size_t)kSumWaves * hist_stride + cells + (size_t)kPartSlices * 64 + 2 * (size_t)cells + touch_words +
                                           (cells + 1) / 2 + 16;
-    static constexpr size_t seg_words(int T) { return (size_t)(T + 2 + 1) / 2 + 2 * ((size_t)(T + 3) / 4); }
-    static constexpr size_t lds_bytes(int T) { return sizeof(uint32_t) * (fixed_words + seg_words(T)); } /* HDL_64E (459 segments): 39.1 KB */
+    static constexpr size_t seg_words(int T) { return (size_t)(T + 1) + (size_t)(T + 3) / 4; }
+    static constexpr size_t lds_bytes(int T) { return sizeof(uint32_t) * (fixed_words + seg_words(T)); } /* HDL_64E (459 segments): 39.5 KB */
 };
 static_assert(kPartSlices * 64 <= 4096, "a part's run start (12 bits) and length (13 bits) share a word with room to spare");
 size_t cell_sums_lds_bytes() { return SumDims::lds_bytes(kMaxSegs); }
@@ -1143,9 +1143,8 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
     uint16_t *tlist = reinterpret_cast<uint16_t *>(tbits + kTouchWords); /* [kCellsQ]: ... listed, in any order */
     uint32_t *misc = reinterpret_cast<uint32_t *>(tlist) + (kCellsQ + 1) / 2; /* [0..1] list lengths (by part parity), [4..7] wave sums, [8] carry */
     const int T = g.segs;
-    uint16_t *spre = reinterpret_cast<uint16_t *>(misc + 16); /* [T + 1]: slices before segment t */
-    uint8_t *cnt8 = reinterpret_cast<uint8_t *>(reinterpret_cast<uint32_t *>(spre) + (T + 2 + 1) / 2); /* [T]: this quarter's candidates of segment t */
-    uint8_t *rs8 = cnt8 + 4 * ((T + 3) / 4);               /* [T]: where its run starts inside the segment */
+    uint32_t *cpre = misc + 16;                            /* [T + 1]: this quarter's candidates before segment t */
+    uint8_t *rs8 = reinterpret_cast<uint8_t *>(cpre + T + 1); /* [T]: where its run starts inside segment t */
     uint16_t *hist16 = reinterpret_cast<uint16_t *>(hist); /* the same counters, cell c of wave w at [w * 2 * kHistStride + c] */
 
     int f, quarter;
@@ -1163,22 +1162,19 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
         sumv[c] = 0.0f;   /* :133-134 */
         cntv[c] = 0.01f;  /* :135-136 */
     }
-    /* this quarter's run of every segment (count, start inside the segment) and the number of slices before it.  The walk
-     * wrote a segment's four counts as four bytes; T <= kMaxSegs = 4 * 256: every thread takes four consecutive segments */
+    /* this quarter's run of every segment (where it starts inside the segment) and the number of the quarter's candidates
+     * before it.  The walk wrote a segment's four counts as four bytes; T <= kMaxSegs = 4 * 256: every thread takes four
+     * consecutive segments */
     {
-        uint32_t ns[4], mine = 0u;
+        uint32_t cq[4], mine = 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int t = 4 * tid + k;
             const uint32_t w = t < T ? fn[t] : 0u;
             const uint32_t sh = 8u * (uint32_t)quarter;
-            const uint32_t cq = (w >> sh) & 0xffu;
-            if (t < T) {
-                cnt8[t] = (uint8_t)cq;
-                rs8[t] = (uint8_t)(((w * 0x01010100u) >> sh) & 0xffu); /* the quarters below it (no byte exceeds the segment's 236) */
-            }
-            ns[k] = (cq + 63u) >> 6;
-            mine += ns[k];
+            cq[k] = (w >> sh) & 0xffu;
+            if (t < T) rs8[t] = (uint8_t)(((w * 0x01010100u) >> sh) & 0xffu); /* the quarters below it (no byte exceeds the segment's 236) */
+            mine += cq[k];
         }
         uint32_t incl = mine;
 #pragma unroll
@@ -1193,50 +1189,54 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int t = 4 * tid + k;
-            if (t <= T) spre[t] = (uint16_t)base;
-            base += ns[k];
+            if (t <= T) cpre[t] = base;
+            base += cq[k];
         }
-        if (tid == kSumThreads - 1 && 4 * kSumThreads <= T) spre[T] = (uint16_t)base; /* (T == 1024 exactly) */
+        if (tid == kSumThreads - 1 && 4 * kSumThreads <= T) cpre[T] = base; /* (T == 1024 exactly) */
         lds_barrier();
         if (tid == 0) misc[4] = misc[5] = misc[6] = misc[7] = 0u;
     }
-    const int G = (int)spre[T];                               /* slices of this quarter */
+    /* The quarter's candidates, segment after segment, are ONE stream in slot order; a slice is 64 consecutive candidates
+     * of it — full, whatever the segments' run lengths (a run of a (segment, quarter) is 35 candidates on average: slices
+     * cut at segment ends were 55 % full, 1,930 of them per frame where 1,000 do) */
+    const int GC = (int)cpre[T];                              /* candidates of this quarter */
+    const int G = (GC + 63) >> 6;                             /* slices */
     const int P = (G + kPartSlices - 1) / kPartSlices;
 
-    /* software pipeline: keys + heights one part ahead.  A wave's 16 slices of part p are slices p * 64 + 16 * wave + j: the
-     * segment of the first one by binary search over the slice prefix, the others by stepping on */
+    /* software pipeline: keys + heights one part ahead.  A wave's 16 slices of part p are slices p * 64 + 16 * wave + j */
     uint32_t key_n[kSlots]; /* next part (raw keys; lanes past the slice's count hold garbage) */
     float z_n[kSlots];
     int n_n[kSlots];        /* candidates in the slice (0: no such slice) */
     auto request = [&](int p) {
-        /* lane j < 16 finds slice g0 + j by itself (binary search over the slice prefix: the sixteen searches run side by
-         * side), the wave then reads segment, slice, count and run start of slot j from lane j */
+        /* lane j <= 16 finds the segment of slice g0 + j's first candidate by itself (binary search over the candidate
+         * prefix: the searches run side by side); a slice then spans the segments from its own start to the next slice's */
         const int g0 = p * kPartSlices + wv * kSlots;
-        const int gl = g0 + (lane & (kSlots - 1));
+        const int gl = g0 + (lane < kSlots + 1 ? lane : kSlots);
         int lo = 0;
         if (gl < G) {
-            int hi = T - 1; /* largest t with spre[t] <= gl: it has a slice of its own, because spre[t + 1] > gl */
+            const uint32_t x = 64u * (uint32_t)gl;
+            int hi = T - 1; /* largest t with cpre[t] <= x: the segment that holds candidate x (cpre[t + 1] > x) */
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
-                if ((int)spre[mid] <= gl) lo = mid; else hi = mid - 1;
+                if (cpre[mid] <= x) lo = mid; else hi = mid - 1;
             }
+        } else {
+            lo = T - 1;
         }
-        const int kl = gl - (int)spre[lo];
-        const int cl = (int)cnt8[lo], rl = (int)rs8[lo];
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
-            /* whole 64-slices, loaded or skipped by a WAVE-UNIFORM test, and nothing but the loads inside the test: a
-             * per-lane predicated load makes the compiler branch around it and wait for the data inside the branch —
-             * one round trip after the other.  Lanes past the count read stale entries of the segment (allocated
-             * memory) and are masked where the values are used. */
             const bool on = g0 + j < G; /* wave-uniform */
-            const int t = __builtin_amdgcn_readlane(lo, j), k = __builtin_amdgcn_readlane(kl, j);
-            const int cq = __builtin_amdgcn_readlane(cl, j), rs = __builtin_amdgcn_readlane(rl, j);
-            n_n[j] = on ? (cq - 64 * k < 64 ? cq - 64 * k : 64) : 0;
+            n_n[j] = on ? (GC - 64 * (g0 + j) < 64 ? GC - 64 * (g0 + j) : 64) : 0;
             key_n[j] = 0u;
             z_n[j] = 0.f;
             if (on) {
-                const uint2 kz = ccand[(size_t)t * kSeg + rs + 64 * k + lane];
+                const int t0 = __builtin_amdgcn_readlane(lo, j), t1 = __builtin_amdgcn_readlane(lo, j + 1);
+                const uint32_t i = 64u * (uint32_t)(g0 + j) + (uint32_t)lane; /* this lane's candidate (past the end in the last slice) */
+                int t = t0;
+                for (int u = t0 + 1; u <= t1; ++u) t += cpre[u] <= i ? 1 : 0; /* (wave-uniform trip count, broadcast reads) */
+                /* lanes past the stream's end read the last run's stale tail (allocated memory) and are masked where
+                 * the values are used */
+                const uint2 kz = ccand[(size_t)t * kSeg + rs8[t] + (i - cpre[t])];
                 key_n[j] = kz.x;
                 z_n[j] = __uint_as_float(kz.y);
             }
