@@ -1460,7 +1460,12 @@ constexpr int kResolveBatch = 4;
 template <bool kPow2>
 __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b, Geometry g)
 {
-    __shared__ float avg[kCells];                        /* the frame's 75 x 50 averages: 4 look-ups per candidate */
+    /* Per cell, the LOWEST of its in-range 4-neighbours' averages: "any neighbour n with fl(z - avg[n]) >= 0.3f" is
+     * "fl(z - min_n avg[n]) >= 0.3f" — fl(z - a) does not increase with a, and the minimum passes over NaN averages exactly
+     * as the comparisons do (a difference with a NaN is never >= 0.3f).  One look-up and one subtraction per candidate
+     * instead of four of each with their range tests (bev_exact.h above_neighbour_ground, BatchMultiBevGen.cpp:227-241). */
+    __shared__ float minavg[kCells];
+    __shared__ float avg[kCells];                        /* the frame's 75 x 50 averages */
     __shared__ int edge_x[kGridRows], edge_y[kGridCols]; /* BEV bin of every ground-grid row's / column's lower edge */
     __shared__ uint32_t band_cursor[kMaxBands];
     __shared__ uint8_t band_tab[512];                    /* x bin -> raster band */
@@ -1478,6 +1483,16 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
     else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
     if (tid < kMaxBands) band_cursor[tid] = 0u;
     for (int x = tid; x < g.rp.mat_size; x += kResolveThreads) band_tab[x] = (uint8_t)raster_band_of(x, g.rp);
+    lds_barrier();
+    for (int c = tid; c < kCells; c += kResolveThreads) {
+        const int sr = c / kGridCols, sc = c % kGridCols;
+        float m = __uint_as_float(0x7fc00000u); /* NaN: no neighbour yet (fminf returns the other operand) */
+        if (sr - 1 >= 0) m = fminf(m, avg[c - kGridCols]);
+        if (sc + 1 < kGridCols) m = fminf(m, avg[c + 1]);
+        if (sc - 1 >= 0) m = fminf(m, avg[c - 1]);
+        if (sr + 1 < kGridRows) m = fminf(m, avg[c + kGridCols]);
+        minavg[c] = m;
+    }
     lds_barrier();
 
     constexpr int kSl = kSeg / 64;
@@ -1533,7 +1548,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
                 const uint32_t kk = key[j][k];
                 const bool have = lane + 64 * k < n;
                 const int cell = (int)(kk & kKeyCellMask);
-                const bool hit = have && above_neighbour_ground(z[j][k], cell, avg);
+                const bool hit = have && (z[j][k] - minavg[cell]) >= 0.3f;
                 const bool pred = (kk & kKeyPredBit) != 0u;
                 const bool wrong = have && hit != pred;
                 if (!__ballot(hit || wrong)) continue; /* wave-uniform */
