@@ -541,6 +541,16 @@ constexpr uint32_t kIdxTail = 1u << 30;
 #define BEV_WALK_OCC
 #define BEV_WALK_WAVES 4
 #endif
+/* A wave's candidates per cell quarter, four byte-wide counts in one word: three ballots (candidate, bit 0 and bit 1 of
+ * the quarter) and scalar arithmetic on the masks. */
+__device__ __forceinline__ uint32_t quarter_counts(bool c, uint32_t q)
+{
+    const unsigned long long bc = __builtin_amdgcn_ballot_w64(c), b0 = __builtin_amdgcn_ballot_w64(c && (q & 1u)),
+                             b1 = __builtin_amdgcn_ballot_w64(c && (q & 2u));
+    const uint32_t n3 = (uint32_t)__popcll(b0 & b1), n1 = (uint32_t)__popcll(b0) - n3, n2 = (uint32_t)__popcll(b1) - n3;
+    return ((uint32_t)__popcll(bc) - n1 - n2 - n3) | (n1 << 8) | (n2 << 16) | (n3 << 24);
+}
+
 template <int kSrc, bool kPow2, bool kGm>
 __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
@@ -845,8 +855,7 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
                 edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(__uint_as_float(cur_lo.x), __uint_as_float(cur_lo.y), __uint_as_float(cur_lo.z), __uint_as_float(cur_hi.x));
             const bool c2 = outcol && wr_gflag(p2.fl) == 1;
             const uint32_t q2 = p2.key & 3u;
-            const uint32_t packed = (uint32_t)__popcll(__ballot(c2 && q2 == 0u)) | ((uint32_t)__popcll(__ballot(c2 && q2 == 1u)) << 8) |
-                                    ((uint32_t)__popcll(__ballot(c2 && q2 == 2u)) << 16) | ((uint32_t)__popcll(__ballot(c2 && q2 == 3u)) << 24);
+            const uint32_t packed = quarter_counts(c2, q2);
             if (lane == 0) wave_cnt[par][wv] = packed;
         }
         lds_barrier();
@@ -889,10 +898,10 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
                 const uint32_t before = (wv > 0 ? wc.x : 0u) + (wv > 1 ? wc.y : 0u) + (wv > 2 ? wc.z : 0u);
                 const uint32_t seg = (uint32_t)(rr * strips + strip);
                 /* the lanes of this wave with a candidate of the same quarter */
-                const unsigned long long m0 = __ballot(cand2 && q2 == 0u), m1 = __ballot(cand2 && q2 == 1u),
-                                         m2 = __ballot(cand2 && q2 == 2u), m3 = __ballot(cand2 && q2 == 3u);
+                const unsigned long long bc = __builtin_amdgcn_ballot_w64(cand2), b0 = __builtin_amdgcn_ballot_w64(cand2 && (q2 & 1u)),
+                                         b1 = __builtin_amdgcn_ballot_w64(cand2 && (q2 & 2u));
                 if (cand2) {
-                    const unsigned long long same = q2 == 0u ? m0 : (q2 == 1u ? m1 : (q2 == 2u ? m2 : m3));
+                    const unsigned long long same = bc & ((q2 & 1u) ? b0 : ~b0) & ((q2 & 2u) ? b1 : ~b1);
                     const uint32_t sh = 8u * q2;
                     /* where the quarter's run starts (byte q of total * 0x01010100 = the quarters below it), the earlier
                      * waves' candidates of the quarter, the earlier lanes' */
@@ -1033,8 +1042,7 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
         if constexpr (kInPlace) {
             if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
             const uint32_t q1 = p1.key & 3u;
-            const uint32_t packed = (uint32_t)__popcll(__ballot(cand1 && q1 == 0u)) | ((uint32_t)__popcll(__ballot(cand1 && q1 == 1u)) << 8) |
-                                    ((uint32_t)__popcll(__ballot(cand1 && q1 == 2u)) << 16) | ((uint32_t)__popcll(__ballot(cand1 && q1 == 3u)) << 24);
+            const uint32_t packed = quarter_counts(cand1, q1);
             if (lane == 0) wave_cnt[par ^ 1][wv] = packed;
         }
     };
