@@ -287,6 +287,8 @@ void fill_geometry(const bev_params_t *p, Geometry *g)
         g->rp.z0 = z0;
         g->rp.z1 = z1;
         g->rp.bands = 2 * (z0 / coarse) + (z1 - z0) / fine;
+        g->rp.coarse_magic = bevx::small_div_magic(coarse);
+        g->rp.fine_magic = bevx::small_div_magic(fine);
         g->raster_bands = g->rp.bands;
     }
     g->emitters = g->strips + kResolveParts;

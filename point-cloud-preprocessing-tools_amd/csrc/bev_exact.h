@@ -208,7 +208,14 @@ struct RasterParams {
      * by 2^k and multiplying by 2^-k are the same correctly rounded operation, and the multiply is ten instructions
      * shorter on the device.  0 = not a power of two: divide. */
     float inv_interval, inv_height_res;
+    /* the band of an x bin without a division (small_div below): ceil(2^20 / coarse), ceil(2^20 / fine) */
+    uint32_t coarse_magic, fine_magic;
 };
+/* x / d for 0 <= x < 512, 1 <= d <= 512 as a multiplication by m = ceil(2^20 / d): with e = m * d - 2^20 < d,
+ * x * m / 2^20 = x / d + x * e / (d * 2^20), and the second term is below 1 / d (x * e < 2^18): the floor is x / d.
+ * All 512 * 512 pairs are checked by tests/test_exact_forms.py. */
+BEVX_HD uint32_t small_div_magic(int d) { return ((1u << 20) + (uint32_t)d - 1u) / (uint32_t)d; }
+BEVX_HD int small_div(int x, uint32_t magic) { return (int)(((uint32_t)x * magic) >> 20); }
 /* 1 / v if v is a power of two (then x / v == x * (1 / v) bit for bit, for every x), else 0 */
 BEVX_HD float exact_reciprocal(float v)
 {
@@ -226,6 +233,14 @@ BEVX_HD int raster_band_of(int x, const RasterParams &rp)
     if (x < rp.z0) return x / rp.coarse;
     if (x < rp.z1) return rp.z0 / rp.coarse + (x - rp.z0) / rp.fine;
     return rp.z0 / rp.coarse + (rp.z1 - rp.z0) / rp.fine + (x - rp.z1) / rp.coarse;
+}
+/* the same for 0 <= x < 512 with the divisions as multiplications (the kernels fill a table of M entries per workgroup) */
+BEVX_HD int raster_band_of_nodiv(int x, const RasterParams &rp)
+{
+    const int n0 = small_div(rp.z0, rp.coarse_magic), n1 = small_div(rp.z1 - rp.z0, rp.fine_magic);
+    if (x < rp.z0) return small_div(x, rp.coarse_magic);
+    if (x < rp.z1) return n0 + small_div(x - rp.z0, rp.fine_magic);
+    return n0 + n1 + small_div(x - rp.z1, rp.coarse_magic);
 }
 BEVX_HD int raster_band_x0(int band, const RasterParams &rp)
 {
@@ -267,6 +282,18 @@ BEVX_HD bool bin_in_range(float v, int M, int *bin)
     const float w = in ? v : 0.0f;
     const int t = (int)floorf(w) + 1;
     *bin = ((w < 0.0f) & (w >= -0x1p-55f)) ? 1 : t;
+    return in;
+}
+/* bin_in_range for a value that IS (p + MAX_RANGE) scaled by the interval (BatchMultiBevGen.cpp:279): the patch for
+ * [-2^-55, 0) is dead code there.  The rounded sum of two floats is zero or at least half an ulp of the larger operand
+ * in magnitude (p + R is tiny only for p within a binade of -R, and then it is a multiple of ulp(R) / 2): for the ranges
+ * and intervals validate_params admits (an image of 16 bins or more: R / interval >= 8) the scaled value is zero or beyond
+ * 2^-22 in magnitude.  Checked against bin_in_range for every coordinate and seven (range, interval) pairs
+ * (tests/test_exact_forms.py). */
+BEVX_HD bool bin_of_shifted(float v, int M, int *bin)
+{
+    const bool in = (v > -1.0f) & (v < (float)(M - 1)); /* (false for NaN) */
+    *bin = (int)floorf(in ? v : 0.0f) + 1;               /* (-1, 0) -> 0 */
     return in;
 }
 BEVX_HD int bev_bin(float p, float max_range_f, float interval)

@@ -509,9 +509,9 @@ template <bool kPow2>
 __device__ __forceinline__ uint32_t code_t(float px, float py, float pz, int label, const RasterParams &rp)
 {
     const float sx = px + rp.max_range_f, sy = py + rp.max_range_f;
-    int x, y; /* (bin_in_range: round_half_up_bin for callers that only want bins inside the image) */
-    const bool inx = bin_in_range(kPow2 ? sx * rp.inv_interval : sx / rp.interval, rp.mat_size, &x); /* :279, :343 */
-    const bool iny = bin_in_range(kPow2 ? sy * rp.inv_interval : sy / rp.interval, rp.mat_size, &y); /* :280, :344 */
+    int x, y; /* (bin_of_shifted: round_half_up_bin for a shifted coordinate, for callers that only want bins inside the image) */
+    const bool inx = bin_of_shifted(kPow2 ? sx * rp.inv_interval : sx / rp.interval, rp.mat_size, &x); /* :279, :343 */
+    const bool iny = bin_of_shifted(kPow2 ? sy * rp.inv_interval : sy / rp.interval, rp.mat_size, &y); /* :280, :344 */
     const bool in = (label != 0) & inx & iny; /* :285, :349 */
     const uint32_t code = code_from_bins_t<kPow2>(in ? x : 0, in ? y : 0, pz, rp);
     return in ? code : kSkip;
@@ -541,15 +541,38 @@ constexpr uint32_t kIdxTail = 1u << 30;
 #define BEV_WALK_OCC
 #define BEV_WALK_WAVES 4
 #endif
-/* A wave's candidates per cell quarter, four byte-wide counts in one word: three ballots (candidate, bit 0 and bit 1 of
- * the quarter) and scalar arithmetic on the masks. */
-__device__ __forceinline__ uint32_t quarter_counts(bool c, uint32_t q)
+#ifdef BEV_CS_CLOCK /* developer build: start, end, HW_ID, XCC_ID of every workgroup of the last in-place walk launch */
+constexpr int kWalkTlCap = 8192;
+__device__ long long g_walk_tl[kWalkTlCap][4];
+} // namespace bevk
+extern "C" int bev_clk_walk_timeline(long long *out, int cap)
 {
-    const unsigned long long bc = __builtin_amdgcn_ballot_w64(c), b0 = __builtin_amdgcn_ballot_w64(c && (q & 1u)),
-                             b1 = __builtin_amdgcn_ballot_w64(c && (q & 2u));
-    const uint32_t n3 = (uint32_t)__popcll(b0 & b1), n1 = (uint32_t)__popcll(b0) - n3, n2 = (uint32_t)__popcll(b1) - n3;
-    return ((uint32_t)__popcll(bc) - n1 - n2 - n3) | (n1 << 8) | (n2 << 16) | (n3 << 24);
+    const int n = cap < bevk::kWalkTlCap ? cap : bevk::kWalkTlCap;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bevk::g_walk_tl), (size_t)n * 4 * sizeof(long long)) == hipSuccess ? n : -1;
 }
+namespace bevk {
+#endif
+/* A wave's candidates per cell quarter.  Every candidate lane holds a one in the byte of its quarter; an inclusive scan
+ * over the wave's lanes (six DPP additions: four inside the rows of 16 lanes, two across rows) leaves in lane 63 the
+ * wave's four counts (at most 64 each) and in every lane, in the byte of its quarter, its rank among the wave's candidates
+ * of that quarter plus one.  No ballots, no 64-bit lane masks.  Returns the scan; *rank = this lane's rank. */
+__device__ __forceinline__ uint32_t quarter_scan(bool c, uint32_t q, uint32_t *rank)
+{
+    const uint32_t sh = q << 3;
+    const uint32_t one = c ? 1u << sh : 0u;
+    uint32_t x = one;
+    /* (a lane whose source lies outside its row / outside the row mask keeps the 0 given as the old value) */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    *rank = __builtin_amdgcn_ubfe(x - one, sh, 8u);
+    return x;
+}
+constexpr int kFlRankShift = 8; /* WalkRow::fl bits 8..13: the lane's rank among its wave's candidates of its quarter */
 
 template <int kSrc, bool kPow2, bool kGm>
 __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
@@ -560,6 +583,9 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
 #endif
     static_assert(kWinPos == 256 && kStripVirt + 16 <= kWinPos && kTailCap == 64 && kWrapPos == 16, "DMA pieces of the in-place source");
     int f, strip;
+#ifdef BEV_CS_CLOCK
+    const long long tl_t0 = wall_clock64();
+#endif
     if (!map_block_xcd(blockIdx.x, nf, g.strips, f, strip)) return;
     if (!kIdentity && b.info && (b.info[f].mode == kFrameStream) != (want_mode == kFrameStream)) return; /* the other launch of the walk has the frame */
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -590,16 +616,18 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
     __shared__ int est_l[2][kInPlace ? kStreamMaxRows : 1];
     __shared__ uint8_t tcnt_l[kInPlace ? kStreamMaxRows : 1];
     __shared__ float4 edge[3][kWaves][4];                  /* rows r, r-1, (r-2): lanes 0, 1, 62, 63 of every wave */
-    __shared__ __attribute__((aligned(16))) uint32_t wave_cnt[2][kWaves]; /* per-wave candidate counts of the row being written */
+    /* per-wave candidate counts of the row being written, at [.][kWaves + wave] behind kWaves words that stay zero: the
+     * three words before a wave's own are the counts of the waves before it, whichever wave it is (no selects) */
+    __shared__ __attribute__((aligned(16))) uint32_t wave_cnt[2][2 * kWaves];
     __shared__ uint32_t band_cursor[kMaxBands];            /* entries already in this strip's code list of each band */
     __shared__ uint8_t band_tab[512];                      /* x bin -> raster band */
     __shared__ uint32_t seen[1 << kSeenB];                 /* direct-mapped memo of codes this strip has already listed */
     __shared__ int edge_x[kGridRows], edge_y[kGridCols];   /* BEV bin of every ground-grid row's / column's lower edge */
     if (tid < kMaxBands) band_cursor[tid] = 0u;
-    if (tid < 2 * kWaves) wave_cnt[tid / kWaves][tid % kWaves] = 0u;
+    if (tid < 4 * kWaves) (&wave_cnt[0][0])[tid] = 0u;
     if (tid < 3 * kWaves * 4) (&edge[0][0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = tid; k < (1 << kSeenB); k += kStripThreads) seen[k] = kSkip;
-    for (int x = tid; x < g.rp.mat_size; x += kStripThreads) band_tab[x] = (uint8_t)raster_band_of(x, g.rp);
+    for (int x = tid; x < g.rp.mat_size; x += kStripThreads) band_tab[x] = (uint8_t)raster_band_of_nodiv(x, g.rp);
     if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
     else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
     if constexpr (kInPlace) {
@@ -676,8 +704,9 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
         if (lane < 2 * kWrapPos)
             glds16(pos_addr(est_l[1][clamp_row(q)] - kWrapLead + (lane >> 1)) + 16 * (lane & 1), ring_l + (uint32_t)slot * kSlotBytes + 8192u);
     };
-    auto issue_tail_list = [&](int q, int slot) { /* wave 3: the (row, strip)'s list, 64 words (stale past the count) */
-        glds4_nt(ftail + (size_t)clamp_row(q) * tail_stride + lane, tlist_l + (uint32_t)slot * 256u);
+    auto issue_tail_list = [&](int q, int slot) { /* wave 3: the (row, strip)'s list; lanes past its count fetch word 0 again (only the lines that hold entries move) */
+        const int qc = clamp_row(q);
+        glds4_nt(ftail + (size_t)qc * tail_stride + (lane < (int)tcnt_l[qc] ? lane : 0), tlist_l + (uint32_t)slot * 256u);
     };
     auto issue_tail_points = [&](int q, int slot, int tslot) { /* wave 3: the listed points of row q beside its window, 32 B each */
         const int n = q < N ? (int)tcnt_l[clamp_row(q)] : 0;
@@ -815,6 +844,12 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
     const uint32_t xp_unit = ((uint32_t)lane & ~1u) | (((uint32_t)lane & 1u) ^ (((uint32_t)lane >> 3) & 1u));
     const uint32_t xp_r0 = (uint32_t)wv * 1024u + xp_unit * 16u, xp_r1 = xp_r0 + 4096u; /* first, second KiB */
 
+    /* byte offset of this lane's 16-byte unit in the SECOND KiB of the wave's 64 columns of the ordered cloud's row r - 2
+     * (128 units; the first KiB lies 1024 bytes before).  Modulo 2^32 while the row is negative: never used then; from row 0
+     * on it is a true offset for every lane (the first strip's first wave starts two columns before the row: its first
+     * KiB's first four units do not exist — those lanes do not store — but its second KiB does). */
+    uint32_t ord_off = (uint32_t)((-2 * H + strip * kStripCols - 2 + 64 * wv) * 2 + 64 + lane) * 16u;
+    const uint32_t row_bytes = (uint32_t)H * 32u;
     auto row_step = [&](auto I, const int r) {
         constexpr int s0 = decltype(I)::value % 3;         /* ring slot of row r (and of row r + 3) */
         constexpr int s2 = (decltype(I)::value + 2) % 3;   /* ... of row r + 2: the slot row r - 1 has left */
@@ -855,8 +890,10 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
                 edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(__uint_as_float(cur_lo.x), __uint_as_float(cur_lo.y), __uint_as_float(cur_lo.z), __uint_as_float(cur_hi.x));
             const bool c2 = outcol && wr_gflag(p2.fl) == 1;
             const uint32_t q2 = p2.key & 3u;
-            const uint32_t packed = quarter_counts(c2, q2);
-            if (lane == 0) wave_cnt[par][wv] = packed;
+            uint32_t rank2;
+            const uint32_t scan = quarter_scan(c2, q2, &rank2);
+            if (lane == 63) wave_cnt[par][kWaves + wv] = scan;
+            p2.fl |= rank2 << kFlRankShift;
         }
         lds_barrier();
         PHA(2);
@@ -893,20 +930,18 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
                  * most 64 each; a segment's at most 236 each) travel in one word. */
                 const uint32_t q2 = p2.key & 3u;
                 static_assert(kWaves == 4, "the four counts are read as one 16-byte word");
-                const u32x4 wc = *reinterpret_cast<const u32x4 *>(&wave_cnt[par][0]);
+                const u32x4 wc = *reinterpret_cast<const u32x4 *>(&wave_cnt[par][kWaves]);
                 const uint32_t total = wc.x + wc.y + wc.z + wc.w; /* four byte-wide sums */
-                const uint32_t before = (wv > 0 ? wc.x : 0u) + (wv > 1 ? wc.y : 0u) + (wv > 2 ? wc.z : 0u);
+                const uint32_t *wb = &wave_cnt[par][wv + 1];
+                const uint32_t before = wb[0] + wb[1] + wb[2];
                 const uint32_t seg = (uint32_t)(rr * strips + strip);
-                /* the lanes of this wave with a candidate of the same quarter */
-                const unsigned long long bc = __builtin_amdgcn_ballot_w64(cand2), b0 = __builtin_amdgcn_ballot_w64(cand2 && (q2 & 1u)),
-                                         b1 = __builtin_amdgcn_ballot_w64(cand2 && (q2 & 2u));
                 if (cand2) {
-                    const unsigned long long same = bc & ((q2 & 1u) ? b0 : ~b0) & ((q2 & 2u) ? b1 : ~b1);
-                    const uint32_t sh = 8u * q2;
-                    /* where the quarter's run starts (byte q of total * 0x01010100 = the quarters below it), the earlier
-                     * waves' candidates of the quarter, the earlier lanes' */
-                    const uint32_t rank = (((total * 0x01010100u) >> sh) & 0xffu) + ((before >> sh) & 0xffu) +
-                                          (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                    /* where the quarter's run starts (byte q of total * 0x01010100: the quarters below it) + the earlier
+                     * waves' candidates of the quarter (no byte overflows: everything stays below the segment's total) +
+                     * the earlier lanes' (the rank the scan left in the record) */
+                    const uint32_t t8 = total << 8;
+                    const uint32_t starts = t8 + (t8 << 8) + (t8 << 16) + before;
+                    const uint32_t rank = __builtin_amdgcn_ubfe(starts, q2 << 3, 8u) + ((p2.fl >> kFlRankShift) & 63u);
                     fcand[seg * (uint32_t)kSeg + rank] = u32x2{p2.key, p2.lo.z}; /* key | height */
                 }
                 if (tid == 2) fncand[seg] = total;
@@ -945,16 +980,19 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
                 const u32x4 pa = *reinterpret_cast<const u32x4 *>(xb + xp_r0);
                 const u32x4 pb = *reinterpret_cast<const u32x4 *>(xb + xp_r1);
                 const unsigned long long owners = __ballot(outcol);
-                const uint32_t at = (uint32_t)(q * H + (strip * kStripCols - 2 + 64 * wv)) * 2u; /* (never dereferenced below 0) */
+                /* (this lane's unit of row q: a byte offset into the frame kept per lane and advanced by one row per step —
+                 * base register + 32-bit offset, no 64-bit address arithmetic) */
+                const gptr<char> orow = (gptr<char>)fordered + ord_off;
 #ifndef BEV_EXP_NOSTORE /* timing experiment: what the ordered cloud's stores cost (results are wrong without them) */
-                if ((owners >> (lane >> 1)) & 1ull) __builtin_nontemporal_store(pa, fordered + (at + (uint32_t)lane));
-                if ((owners >> (32 + (lane >> 1))) & 1ull) __builtin_nontemporal_store(pb, fordered + (at + 64u + (uint32_t)lane));
+                if ((owners >> (lane >> 1)) & 1ull) __builtin_nontemporal_store(pa, (gptr<u32x4>)(orow - 1024));
+                if ((owners >> (32 + (lane >> 1))) & 1ull) __builtin_nontemporal_store(pb, (gptr<u32x4>)orow);
 #else
-                if (pa.x == 0x12345678u && pb.x == 0x9abcdef0u && owners) __builtin_nontemporal_store(pa, fordered + (at + (uint32_t)lane)); /* keeps the values alive */
+                if (pa.x == 0x12345678u && pb.x == 0x9abcdef0u && owners) __builtin_nontemporal_store(pa, (gptr<u32x4>)(orow - 1024)); /* keeps the values alive */
 #endif
                 if (kGm && outcol) fgm[(uint32_t)(q * H + v)] = (int8_t)wr_gflag(p2.fl);
             }
         }
+        ord_off += row_bytes;
         /* ---- the loads of this step, behind its stores: row r + 2 (and the winner words / tail list of row r + 4) ---- */
         PHA(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave is done reading the pieces it refills */
@@ -1042,8 +1080,10 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
         if constexpr (kInPlace) {
             if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
             const uint32_t q1 = p1.key & 3u;
-            const uint32_t packed = quarter_counts(cand1, q1);
-            if (lane == 0) wave_cnt[par ^ 1][wv] = packed;
+            uint32_t rank1;
+            const uint32_t scan = quarter_scan(cand1, q1, &rank1);
+            if (lane == 63) wave_cnt[par ^ 1][kWaves + wv] = scan;
+            p1.fl |= rank1 << kFlRankShift;
         }
     };
     /* two extra iterations drain the pipeline */
@@ -1054,7 +1094,16 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
     }
     wait_vm<0>(); /* no LDS-DMA may outlive the workgroup's LDS */
     PHA_PRINT(kInPlace ? "walk_inplace vmwait index barrier acquire writeout issue status rest" : "walk_gather vmwait - barrier acquire writeout issue status rest",
-              lane == 0 && blockIdx.x == 1000);
+              lane == 0 && blockIdx.x == 100);
+#ifdef BEV_CS_CLOCK /* where and when the workgroup ran: HW_ID (wave, SIMD, CU, SH, SE), XCC_ID; start and end on the 100 MHz clock */
+    if (tid == 0 && kInPlace && blockIdx.x < kWalkTlCap) {
+        long long *rec = g_walk_tl[blockIdx.x];
+        rec[0] = tl_t0;
+        rec[1] = wall_clock64();
+        rec[2] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        rec[3] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
     lds_barrier();
     if (tid < bands) b.ncode[((size_t)f * g.emitters + strip) * bands + tid] = band_cursor[tid];
     if constexpr (kInPlace) {
@@ -1490,7 +1539,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
     if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
     else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
     if (tid < kMaxBands) band_cursor[tid] = 0u;
-    for (int x = tid; x < g.rp.mat_size; x += kResolveThreads) band_tab[x] = (uint8_t)raster_band_of(x, g.rp);
+    for (int x = tid; x < g.rp.mat_size; x += kResolveThreads) band_tab[x] = (uint8_t)raster_band_of_nodiv(x, g.rp);
     lds_barrier();
     for (int c = tid; c < kCells; c += kResolveThreads) {
         const int sr = c / kGridCols, sc = c % kGridCols;

@@ -8,7 +8,7 @@ for F in 32 64 96 128 256; do
 import json,sys
 d=json.loads(open("/tmp/wl.json").read()); F=int(sys.argv[1])
 for k in d["kernels"]:
-    if "strip_ground" in k["name"] or "cell_sums" in k["name"]:
+    if k["name"] in ("k_walk", "k_walk_general") or "cell_sums" in k["name"]:
         print(F, "frames:", k["name"], "launch", round(k["avg_launch_ms"]*1e3,1), "us ->", round(k["avg_launch_ms"]*1e3/F,2), "us/frame;", "launches", k["launches"])
 PY
 done

@@ -44,6 +44,8 @@ RasterParams raster_params(const bev_params_t *p)
     rp.z0 = 3 * rp.coarse;
     rp.z1 = rp.mat_size - rp.z0;
     rp.bands = 2 * (rp.z0 / rp.coarse) + (rp.z1 - rp.z0) / rp.fine;
+    rp.coarse_magic = small_div_magic(rp.coarse);
+    rp.fine_magic = small_div_magic(rp.fine);
     return rp;
 }
 } // namespace
@@ -202,6 +204,32 @@ uint64_t hc_count_advance_check(uint32_t n_max)
 
 int hc_ground_cell(float x, float y) { return ground_cell(x, y); }
 
+/* small_div against the division for every 0 <= x < 512, 1 <= d <= 512, and raster_band_of_nodiv against raster_band_of
+ * for every image size / band layout fill_geometry can produce (M a multiple of 16 up to 512; 4, 8 or 16 coarse bands):
+ * the number of mismatches */
+uint64_t hc_small_div_check(void)
+{
+    uint64_t bad = 0;
+    for (int d = 1; d <= 512; ++d) {
+        const uint32_t m = small_div_magic(d);
+        for (int x = 0; x < 512; ++x) bad += small_div(x, m) != x / d;
+    }
+    for (int M = 16; M <= 512; M += 16)
+        for (int u = 4; u <= 16; u *= 2) {
+            RasterParams rp{};
+            rp.mat_size = M;
+            rp.coarse = M / u;
+            if (rp.coarse < 1 || M % u) continue;
+            rp.fine = rp.coarse % 4 == 0 ? rp.coarse / 4 : rp.coarse;
+            rp.z0 = (3 * u / 8) * rp.coarse;
+            rp.z1 = M - rp.z0;
+            rp.coarse_magic = small_div_magic(rp.coarse);
+            rp.fine_magic = small_div_magic(rp.fine);
+            for (int x = 0; x < M; ++x) bad += raster_band_of_nodiv(x, rp) != raster_band_of(x, rp);
+        }
+    return bad;
+}
+
 /* exact_reciprocal (bev_exact.h): for every power of two v it accepts, x / v == x * (1 / v) bit for bit over `samples`
  * pseudo-random bit patterns of x per v plus the extremes; everything that is not a power of two is refused.
  * Returns the number of violations. */
@@ -264,11 +292,15 @@ uint32_t hc_bev_code(const bev_params_t *p, float x, float y, float z, int label
  *   2: round_half_up_bin(v) vs cvttsd2si(round((double)v + 0.5))  (compared after mapping out-of-[0,4096) to -1)
  *   3: height_times4(t)     vs cvttsd2si((double)t * 4.0)
  *   4: d >= 0.3f            vs (double)d > 0.30
- *   5: bin_in_range(v, M)   vs round_half_up_bin(v) in [0, M), M = 2, 112, 224, 448, 512, 4096 */
+ *   5: bin_in_range(v, M)   vs round_half_up_bin(v) in [0, M), M = 2, 112, 224, 448, 512, 4096
+ *   6: bin_of_shifted(p + R scaled by the interval, M) vs bin_in_range of the same value, for every coordinate p and a
+ *      set of (MAX_RANGE, interval) from the smallest image validate_params admits (M = 16) to the largest, powers of
+ *      two and not: the sum of two floats is never a tiny negative number */
 void hc_exhaustive_exact_forms(uint64_t *out)
 {
-    uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
-#pragma omp parallel for reduction(+ : m0, m1, m2, m3, m4, m5) schedule(static)
+    uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, m6 = 0;
+    static const float kShift[][2] = {{112.0f, 1.0f}, {8.0f, 1.0f}, {50.0f, 0.25f}, {80.0f, 0.5f}, {100.0f, 0.4f}, {2048.0f, 8.0f}, {3.0f, 0.375f}};
+#pragma omp parallel for reduction(+ : m0, m1, m2, m3, m4, m5, m6) schedule(static)
     for (int64_t u = 0; u <= 0xffffffffLL; ++u) {
         const float f = bits_to_float((uint32_t)u);
         {
@@ -297,8 +329,17 @@ void hc_exhaustive_exact_forms(uint64_t *out)
                 if (in != want || (in && b != full)) ++m5;
             }
         }
+        for (const auto &ri : kShift) {
+            const float inv = exact_reciprocal(ri[1]);
+            const float sh = f + ri[0];
+            const float v = inv != 0.0f ? sh * inv : sh / ri[1];
+            const int M = cvtt_f32((ri[0] * 2.0f) / ri[1]);
+            int a = -7, b = -9;
+            const bool ia = bin_in_range(v, M, &a), ib = bin_of_shifted(v, M, &b);
+            if (ia != ib || (ia && a != b)) ++m6;
+        }
     }
-    out[0] = m0; out[1] = m1; out[2] = m2; out[3] = m3; out[4] = m4; out[5] = m5;
+    out[0] = m0; out[1] = m1; out[2] = m2; out[3] = m3; out[4] = m4; out[5] = m5; out[6] = m6;
 }
 
 /* bev_libm.h against the host libm: out[0] = atanf mismatches over ALL 2^32 floats,

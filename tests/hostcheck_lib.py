@@ -25,6 +25,8 @@ def lib():
         l.hc_bev_code.restype = C.c_uint32
         l.hc_count_advance_check.argtypes = [C.c_uint32]
         l.hc_count_advance_check.restype = C.c_uint64
+        l.hc_small_div_check.argtypes = []
+        l.hc_small_div_check.restype = C.c_uint64
         l.hc_angle_nodiv_check.argtypes = [C.c_uint64]
         l.hc_angle_nodiv_check.restype = C.c_uint64
         l.hc_exact_reciprocal_check.argtypes = [C.c_uint64]
