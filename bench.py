@@ -46,6 +46,9 @@ def main() -> int:
     ap.add_argument("--sub-batch", type=int, default=int(os.environ.get("BEV_SUB_BATCH", "500")),
                     help="frames per sub-batch of the two-stage pipeline (500: two sub-batches per 1000-frame step; measured "
                          "300-309 k frames/s against 288-297 k at 256 on the same box)")
+    ap.add_argument("--n-dup", type=int, default=int(os.environ.get("BEV_BENCH_NDUP", "5000")),
+                    help="duplicates appended to every hdl64_sweep frame (BASELINE config 2: 5000; anything else is a "
+                         "developer experiment and is named in config.workload)")
     ap.add_argument("--cpu-sample", type=int, default=400, help="frames timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
@@ -123,7 +126,7 @@ def main() -> int:
     assert count == F
 
     # ---- synthetic frames, generated on the host cores, then made resident in HBM
-    n_dup = 5000
+    n_dup = args.n_dup
     n_sweeps = 60
     cap = {"hdl64_sweep": S + n_dup, "os1_firing": S, "oxford_concat": S * n_sweeps}[args.workload]
     t_gen = time.time()
@@ -365,7 +368,8 @@ def main() -> int:
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{F} synthetic {args.workload} {args.sensor} clouds per GPU (mean {mean_pts:.0f} input pts, "
-                                   f"{S} slots), single+multi BEV, device-resident",
+                                   f"{S} slots), single+multi BEV, device-resident" +
+                                   (f" [developer run: {n_dup} appended duplicates instead of 5000]" if args.workload == "hdl64_sweep" and n_dup != 5000 else ""),
                        "frames_per_gpu": F, "frames_per_step": F * world, "sub_batch": args.sub_batch, "sensor": args.sensor,
                        "algorithmic_bytes_per_frame": b_frame, "parallelism": f"frames x{world}"},
             "roofline": roofline,
