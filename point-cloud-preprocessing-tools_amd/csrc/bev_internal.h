@@ -27,8 +27,18 @@ constexpr int kSumWaves = 4;      /* waves of the per-frame cell-sum workgroup: 
 constexpr int kSumThreads = kSumWaves * 64;
 constexpr int kSegsPerWave = 4;                              /* segments a wave keeps in registers per part */
 constexpr int kPartSegs = kSumWaves * kSegsPerWave;          /* segments per part: 16 (4,096 candidates at most) */
-constexpr int kResolveThreads = 256;
-constexpr int kResolveParts = 4;  /* workgroups per frame in k_ground_resolve, each with its own code lists */
+#ifndef BEV_RESOLVE_THREADS
+#define BEV_RESOLVE_THREADS 256
+#endif
+constexpr int kResolveThreads = BEV_RESOLVE_THREADS;
+constexpr int kResolveParts = 4;  /* code lists per frame written by k_ground_resolve (a contiguous quarter of the segments each) */
+#ifndef BEV_RESOLVE_WGS
+#define BEV_RESOLVE_WGS 1
+#endif
+/* workgroups per frame in k_ground_resolve, kResolveParts / kResolveWgs consecutive parts each: a workgroup's tables
+ * (3,750 averages, their neighbour minima, edge bins, band table) cost as much as a part's candidates */
+constexpr int kResolveWgs = BEV_RESOLVE_WGS;
+static_assert(kResolveParts % kResolveWgs == 0, "whole parts per workgroup");
 #ifndef BEV_RASTER_THREADS
 #define BEV_RASTER_THREADS 512 /* (overridable for `make exp`: bev_kernels.hip is the only user) */
 #endif

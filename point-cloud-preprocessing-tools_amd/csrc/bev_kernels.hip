@@ -808,6 +808,9 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
 
     WalkRow pr[3] = {};
     PHA_DECL;
+#ifdef BEV_CS_CLOCK
+    if (lane == 0 && blockIdx.x == 100) printf("walk_prologue %lld (x10 ns)\n", pha_t - tl_t0);
+#endif
     float zref = __uint_as_float(0x7fc00000u); /* height of the column's last candidate taken for ground (NaN: none yet) */
 
     const size_t cand_base = (size_t)f * g.segs * kSeg;
@@ -1527,14 +1530,10 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
     __shared__ uint32_t band_cursor[kMaxBands];
     __shared__ uint8_t band_tab[512];                    /* x bin -> raster band */
     __shared__ uint16_t cnt[kMaxSegs / kResolveParts + 8];
-    const int f = blockIdx.x / kResolveParts, part = blockIdx.x - f * kResolveParts;
+    constexpr int kPartsPerWg = kResolveParts / kResolveWgs;
+    const int f = blockIdx.x / kResolveWgs, part0 = (blockIdx.x - f * kResolveWgs) * kPartsPerWg;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = g.segs;
-    const int t0 = (int)((long long)T * part / kResolveParts), t1 = (int)((long long)T * (part + 1) / kResolveParts);
-    for (int i = tid; i < t1 - t0; i += kResolveThreads) {
-        const uint32_t w = b.ncand[(size_t)f * T + t0 + i]; /* four byte-wide counts: the segment's runs by cell quarter, back to back */
-        cnt[i] = (uint16_t)((w & 0xffu) + ((w >> 8) & 0xffu) + ((w >> 16) & 0xffu) + (w >> 24));
-    }
     for (int c = tid; c < kCells; c += kResolveThreads) avg[c] = b.avg[(size_t)f * kCells + c];
     if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
     else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
@@ -1557,7 +1556,6 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
     const int bands = g.raster_bands, lo_row = g.N - g.G, H = g.H, strips = g.strips;
     const uint2 *fcand = b.cand + (size_t)f * T * kSeg; /* key | height */
     const uint32_t code_cap = g.code_cap;
-    const gptr<uint32_t> flist = (gptr<uint32_t>)(b.code_main + ((size_t)f * g.emitters + g.strips + part) * bands * (size_t)code_cap);
     const gptr<uint16_t> flabel = (gptr<uint16_t>)(b.ordered + (size_t)f * g.S); /* label @28 of point i: [16 * i + 14] */
     const bev_point_t *fordered = b.ordered + (size_t)f * g.S;
     RasterParams rp = g.rp; /* the fields the BEV code needs, in vector registers */
@@ -1574,6 +1572,16 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
         rp.inv_interval = 0.0f;
         rp.inv_height_res = 0.0f;
     }
+  for (int part = part0; part < part0 + kPartsPerWg; ++part) { /* one code list set per part */
+    const int t0 = (int)((long long)T * part / kResolveParts), t1 = (int)((long long)T * (part + 1) / kResolveParts);
+    const gptr<uint32_t> flist = (gptr<uint32_t>)(b.code_main + ((size_t)f * g.emitters + g.strips + part) * bands * (size_t)code_cap);
+    if (part != part0) lds_barrier(); /* the previous part's cursors have been written out, its counts read */
+    for (int i = tid; i < t1 - t0; i += kResolveThreads) {
+        const uint32_t w = b.ncand[(size_t)f * T + t0 + i]; /* four byte-wide counts: the segment's runs by cell quarter, back to back */
+        cnt[i] = (uint16_t)((w & 0xffu) + ((w >> 8) & 0xffu) + ((w >> 16) & 0xffu) + (w >> 24));
+    }
+    if (tid < kMaxBands) band_cursor[tid] = 0u;
+    lds_barrier();
     for (int s0 = t0 + wv; s0 < t1; s0 += kWaves * kResolveBatch) {
         uint32_t key[kResolveBatch][kSl];
         float z[kResolveBatch][kSl];
@@ -1634,6 +1642,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
     }
     lds_barrier();
     if (tid < bands) b.ncode[((size_t)f * g.emitters + g.strips + part) * bands + tid] = band_cursor[tid];
+  }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -2049,8 +2058,8 @@ void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, bool i
     (void)identity; /* (the escape branch reads the point from the ordered cloud either way) */
     if (nf == 0) return;
     const bool pow2 = g.rp.inv_interval != 0.0f && g.rp.inv_height_res != 0.0f;
-    if (pow2) hipLaunchKernelGGL(k_ground_resolve<true>, dim3(nf * kResolveParts), dim3(kResolveThreads), 0, st, b, g);
-    else hipLaunchKernelGGL(k_ground_resolve<false>, dim3(nf * kResolveParts), dim3(kResolveThreads), 0, st, b, g);
+    if (pow2) hipLaunchKernelGGL(k_ground_resolve<true>, dim3(nf * kResolveWgs), dim3(kResolveThreads), 0, st, b, g);
+    else hipLaunchKernelGGL(k_ground_resolve<false>, dim3(nf * kResolveWgs), dim3(kResolveThreads), 0, st, b, g);
 }
 void launch_bev_raster(const Geometry &g, const BatchPtrs &b, bool want_multi, bool want_single, int nf, hipStream_t st)
 {
