@@ -28,7 +28,7 @@ constexpr int kSumThreads = kSumWaves * 64;
 constexpr int kSegsPerWave = 4;                              /* segments a wave keeps in registers per part */
 constexpr int kPartSegs = kSumWaves * kSegsPerWave;          /* segments per part: 16 (4,096 candidates at most) */
 #ifndef BEV_RESOLVE_THREADS
-#define BEV_RESOLVE_THREADS 256
+#define BEV_RESOLVE_THREADS 512
 #endif
 constexpr int kResolveThreads = BEV_RESOLVE_THREADS;
 constexpr int kResolveParts = 4;  /* code lists per frame written by k_ground_resolve (a contiguous quarter of the segments each) */
