@@ -137,7 +137,10 @@ __device__ __forceinline__ uint32_t winner_index(uint32_t w, uint32_t tag, int s
  * strictly ascending bound a prefix [0, T) that is TAKEN for sorted; for every (row, strip) the position of its first
  * slot inside that prefix is estimated by interpolation between the two samples around it.  Nothing here is trusted:
  * the stream walk verifies every point it consumes and a frame that fails is redone the general way. */
-constexpr int kProbeThreads = 1024; /* one workgroup per frame: its latency is the kernel's */
+#ifndef BEV_PROBE_THREADS
+#define BEV_PROBE_THREADS 256
+#endif
+constexpr int kProbeThreads = BEV_PROBE_THREADS; /* one workgroup per frame */
 __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g, int allow_stream)
 {
     __shared__ uint32_t samp[kMaxSamples]; /* slot of sample k (position k * kProbeStride) */
@@ -148,28 +151,45 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
     const uint32_t n = fd.n_pts;
     const bev_point_t *fp = b.pts + fd.in_offset;
     const uint32_t ns = n ? (n - 1u) / kProbeStride + 1u : 0u;
+    PH_DECL;
+    PH();
     const bool can = allow_stream && n >= (uint32_t)kStreamMinPrefix && ns <= (uint32_t)kMaxSamples && g.N <= kStreamMaxRows &&
                      g.N * g.strips <= kTailBuckets && n < (1u << 24) && b.tail_list != nullptr;
     if (tid == 0) first_bad = can ? ns : 0u;
     __syncthreads();
     if (can) {
-        for (uint32_t k = tid; k < ns; k += (uint32_t)kProbeThreads) {
-            const size_t i = (size_t)k * kProbeStride;
-            const uint32_t rc = reinterpret_cast<const uint32_t *>(fp + i)[5]; /* row | col << 16 */
-            const uint32_t row = rc & 0xffffu, col = rc >> 16;
-            uint32_t sl = (row < (uint32_t)g.N && col < (uint32_t)g.H) ? row * (uint32_t)g.H + col : 0xffffffffu;
-            if (i + 1 < n) { /* the sample's successor too (mostly the same line): catches column-major orders at once */
-                const uint32_t rc1 = reinterpret_cast<const uint32_t *>(fp + i + 1)[5];
-                const uint32_t row1 = rc1 & 0xffffu, col1 = rc1 >> 16;
-                if (!(row1 < (uint32_t)g.N && col1 < (uint32_t)g.H) || row1 * (uint32_t)g.H + col1 <= sl) sl = 0xffffffffu;
+        /* every sample is a sector of its own somewhere in the frame: all of a thread's loads are requested before the
+         * first is used (one load per trip of the plain loop was half of the kernel's time: 8 round trips under load) */
+        constexpr int kSPer = 9; /* 256 x 9 samples = 145 k points per trip */
+        for (uint32_t k0 = 0; k0 < ns; k0 += (uint32_t)kProbeThreads * kSPer) {
+            uint32_t rc[kSPer], rc1[kSPer];
+#pragma unroll
+            for (int u = 0; u < kSPer; ++u) {
+                const uint32_t k = k0 + (uint32_t)kProbeThreads * u + tid;
+                const size_t i = (size_t)(k < ns ? k : ns - 1u) * kProbeStride;
+                rc[u] = load_once(reinterpret_cast<const uint32_t *>(fp + i) + 5);                       /* row | col << 16 */
+                rc1[u] = load_once(reinterpret_cast<const uint32_t *>(fp + (i + 1 < n ? i + 1 : i)) + 5); /* the sample's successor (mostly the same line): catches column-major orders at once */
             }
-            samp[k] = sl;
+#pragma unroll
+            for (int u = 0; u < kSPer; ++u) {
+                const uint32_t k = k0 + (uint32_t)kProbeThreads * u + tid;
+                if (k >= ns) continue;
+                const size_t i = (size_t)k * kProbeStride;
+                const uint32_t row = rc[u] & 0xffffu, col = rc[u] >> 16;
+                uint32_t sl = (row < (uint32_t)g.N && col < (uint32_t)g.H) ? row * (uint32_t)g.H + col : 0xffffffffu;
+                if (i + 1 < n) {
+                    const uint32_t row1 = rc1[u] & 0xffffu, col1 = rc1[u] >> 16;
+                    if (!(row1 < (uint32_t)g.N && col1 < (uint32_t)g.H) || row1 * (uint32_t)g.H + col1 <= sl) sl = 0xffffffffu;
+                }
+                samp[k] = sl;
+            }
         }
         __syncthreads();
         for (uint32_t k = tid; k < ns; k += (uint32_t)kProbeThreads) /* first sample that is out of range or not above its predecessor */
             if (samp[k] == 0xffffffffu || (k > 0u && samp[k] <= samp[k - 1u])) atomicMin(&first_bad, k);
         __syncthreads();
     }
+    PH(); /* samples */
     const uint32_t m = first_bad;                                      /* samples 0 .. m-1 ascend */
     const uint32_t T0 = m ? (m - 1u) * kProbeStride + 1u : 0u;         /* the last of them is position T0 - 1 */
     /* ... and the points after it, one by one, up to the first that does not ascend (at the latest the successor of the
@@ -189,6 +209,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
         }
     }
     __syncthreads();
+    PH(); /* prefix end */
     const uint32_t T = m ? first_bad : 0u;
     const bool stream = can && T >= (uint32_t)kStreamMinPrefix && n - T <= (uint32_t)kTailMax;
     if (!stream) { /* (`consumed` of a general frame says why, for bev_debug_get_frame_info: 1 not eligible, 2 prefix too
@@ -226,6 +247,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
         fest[i] = est < T ? est : T;
     }
 
+    PH(); /* estimates */
     /* The tail [T, n): too few points to be worth a pass of the order scan (scattered atomics run at a twentieth of the
      * rate of the scan's coalesced ones), and the stream walk has no winner table to look them up in.  They are listed
      * per (row, strip) — under every strip whose 256 virtual columns hold the slot: its own, a neighbour's halo, strip
@@ -242,7 +264,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
         if (pos < (uint32_t)kTailCap) flist[(size_t)bucket * kTailCap + pos] = (uint32_t)off | (i << 8);
         else overflow = 1u;
     };
-    constexpr int kPer = 8; /* loads in flight per thread: a 5000-point tail is one trip */
+    constexpr int kPer = 20; /* loads in flight per thread: a 5000-point tail is one trip */
     for (uint32_t i0 = T; i0 < n; i0 += (uint32_t)kProbeThreads * kPer) {
         uint32_t rc[kPer];
 #pragma unroll
@@ -267,11 +289,14 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
         }
     }
     __syncthreads();
+    PH(); /* tail lists */
     uint32_t *fcnt = b.tail_cnt + (size_t)f * g.N * g.strips;
     for (int i = tid; i < g.N * g.strips; i += kProbeThreads) fcnt[i] = tcnt[i] < (uint32_t)kTailCap ? tcnt[i] : (uint32_t)kTailCap;
     /* a list that does not hold its (row, strip)'s tail points: the frame goes the general way (the scan repeats the
      * scatter of the tail among all the others) */
     if (tid == 0) b.info[f] = overflow ? FrameInfo{0u, kFrameGeneral, 4u, 0u} : FrameInfo{T, kFrameStream, 0u, 0u};
+    PH();
+    PH_PRINT("probe samples prefix-end estimates tail-lists counts", tid == 0 && f == 100);
 }
 
 /* after the stream walk: a frame whose consumed points do not add up to its prefix, or with a failed check, is redone */
