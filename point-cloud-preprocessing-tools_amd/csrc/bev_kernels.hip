@@ -721,8 +721,11 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
     auto issue_window = [&](int q, int slot) { /* this wave's 64 positions of row q's window: low halves, high halves */
         const int e = est_l[0][clamp_row(q)] - kWinLead;
         const uint32_t at = ring_l + (uint32_t)slot * kSlotBytes + (uint32_t)wv * 1024u;
-        const char *src = (e >= 0 && e + kWinPos <= (int)T) ? fbytes + (size_t)(uint32_t)(e + tid) * 32u /* wave-uniform test */
-                                                            : pos_addr(e + tid);
+        /* (rows past the last one — the two steps that drain the pipeline and the two before them — still issue their
+         * loads, so that every step counts the same: all lanes fetch position 0, one line instead of the last row's window again) */
+        const char *src = q >= N ? fbytes
+                                 : ((e >= 0 && e + kWinPos <= (int)T) ? fbytes + (size_t)(uint32_t)(e + tid) * 32u /* wave-uniform test */
+                                                                      : pos_addr(e + tid));
         glds16x2(src, at, src + 16, at + 4096u);
     };
     auto issue_wrap = [&](int q, int slot) { /* last strip, wave 2: the positions around the row's start, 32 B each */
