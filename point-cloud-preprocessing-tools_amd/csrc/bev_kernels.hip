@@ -1195,8 +1195,8 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_only(BatchPtrs b, Geo
  *           heights stay in registers
  *   scan    per-cell totals over the waves, exclusive scan over the touched cells -> the part's runs
  *   place   stable placement into the part's height buffer: lanes of a slice that share a cell rank themselves with
- *           ballots (six key bits, a verification, the other six only when it fails): constant work however many
- *           distinct cells a slice has
+ *           ballots (one per bit of the quarter's cell number, ten: nothing but vector / scalar ALU): constant work
+ *           however many distinct cells a slice has
  *   sum     one thread per touched cell continues the cell's running (sum, cnt) through its run of this part
  * while the next part's keys and heights are already in flight, so the only memory round trip that is ever exposed is
  * the first one.  No intermediate of phase B touches HBM. */
@@ -1540,8 +1540,10 @@ __global__ __launch_bounds__(256) void k_cloud_codes(const bev_point_t *__restri
  * rebuilt from key and height, bev_exact.h — is appended to a code list of the raster band it falls into, exactly like
  * the walk's lists (an LDS cursor per band, no global atomics): k_bev_raster reads both kinds the same way.  The walk
  * wrote each candidate's label for its guess (key bit kKeyPredBit); only wrong guesses are patched.
- * kResolveParts workgroups per frame, each takes a contiguous quarter of the segments; a wave requests kResolveBatch
- * segments (x 4 slices of 64 candidates) at a time. */
+ * kResolveParts code lists per frame, a contiguous quarter of the segments each; kResolveWgs workgroups per frame (one:
+ * the frame's tables — 3,750 averages, their neighbour minima, edge bins, band table — cost as much as a part's
+ * candidates) walk kResolveParts / kResolveWgs parts each; a wave requests kResolveBatch segments (x 4 slices of 64
+ * candidates) at a time. */
 constexpr int kResolveBatch = 4;
 /* (round 3: the raster constants in vector registers and stores through address-space-1 pointers, as in the walk — a
  * quarter of this kernel's vector instructions were v_readlane restores of spilled 8-dword argument tuples) */
