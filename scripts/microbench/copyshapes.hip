@@ -109,6 +109,44 @@ __global__ __launch_bounds__(256) void k_walk(const v4u* __restrict__ in, v4u* _
         }
     }
 }
+// the same loop with whole-line LOADS as well: lane l of a wave fetches 16-B unit l (then 64 + l) of the wave's 2 KiB of
+// a row — what the walk would see if its windows arrived as they lie in memory instead of as two half-line planes
+template <int kD>
+__global__ __launch_bounds__(256) void k_walk_lines(const v4u* __restrict__ in, v4u* __restrict__ out, int nf, int strips, int N, int H)
+{
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int fl = j / strips, strip = j - fl * strips, f = fl * 8 + x;
+    if (f >= nf) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int c0 = strip * 252 - 2 + 64 * wv; /* first column of the wave */
+    if (c0 < 0) c0 = 0;
+    if (c0 + 64 > H) c0 = H - 64;
+    const size_t fbase = (size_t)f * N * H;
+    v4u lo[kD + 1], hi[kD + 1];
+#pragma unroll
+    for (int d = 0; d < kD; ++d) {
+        const v4u* p = in + 2 * (fbase + (size_t)d * H + c0);
+        lo[d] = p[lane];
+        hi[d] = p[64 + lane];
+    }
+    for (int r0 = 0; r0 < N; r0 += kD + 1) {
+#pragma unroll
+        for (int u = 0; u < kD + 1; ++u) {
+            const int r = r0 + u;
+            if (r >= N) break;
+            const int rn = r + kD < N ? r + kD : N - 1;
+            const v4u* p = in + 2 * (fbase + (size_t)rn * H + c0);
+            const int sn = (u + kD) % (kD + 1);
+            lo[sn] = p[lane];
+            hi[sn] = p[64 + lane];
+            v4u a = lo[u], c = hi[u];
+            c.w &= 0xffff0000u;
+            v4u* dst = out + 2 * (fbase + (size_t)r * H + c0);
+            __builtin_nontemporal_store(a, dst + lane);
+            __builtin_nontemporal_store(c, dst + 64 + lane);
+        }
+    }
+}
 int main()
 {
     const size_t bytes = (size_t)2 << 30; // 2 GiB per buffer: far beyond the 256 MiB Infinity Cache
@@ -166,6 +204,8 @@ int main()
         time("walk shape, 2 rows in flight, whole-line stores (LDS transpose)", moved, [&] { hipLaunchKernelGGL((k_walk<2, true, false>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
         time("walk shape, 2 rows in flight, whole-line stores, nt loads", moved, [&] { hipLaunchKernelGGL((k_walk<2, true, true>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
         time("walk shape, 4 rows in flight, whole-line stores", moved, [&] { hipLaunchKernelGGL((k_walk<4, true, false>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
+        time("walk shape, 2 rows in flight, whole-line loads AND stores", moved, [&] { hipLaunchKernelGGL((k_walk_lines<2>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
+        time("walk shape, 4 rows in flight, whole-line loads AND stores", moved, [&] { hipLaunchKernelGGL((k_walk_lines<4>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
         time("walk shape, 4 rows in flight, whole-line stores, nt loads", moved, [&] { hipLaunchKernelGGL((k_walk<4, true, true>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
     }
     return 0;
