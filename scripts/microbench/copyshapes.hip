@@ -206,6 +206,13 @@ int main()
         time("walk shape, 4 rows in flight, whole-line stores", moved, [&] { hipLaunchKernelGGL((k_walk<4, true, false>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
         time("walk shape, 2 rows in flight, whole-line loads AND stores", moved, [&] { hipLaunchKernelGGL((k_walk_lines<2>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
         time("walk shape, 4 rows in flight, whole-line loads AND stores", moved, [&] { hipLaunchKernelGGL((k_walk_lines<4>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
+        for (int per_cu : {1, 2, 3, 4, 6, 8}) { /* dynamic LDS limits how many of these workgroups share a CU */
+            char nm[96];
+            snprintf(nm, sizeof nm, "walk shape, whole-line loads and stores, 4 rows in flight, %d workgroups per CU", per_cu);
+            const size_t lds = (size_t)(160 * 1024) / per_cu - 1024;
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_walk_lines<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            time(nm, moved, [&] { hipLaunchKernelGGL((k_walk_lines<4>), dim3(g), dim3(256), lds, 0, a, b, nf, strips, N, H); });
+        }
         time("walk shape, 4 rows in flight, whole-line stores, nt loads", moved, [&] { hipLaunchKernelGGL((k_walk<4, true, true>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
     }
     return 0;
