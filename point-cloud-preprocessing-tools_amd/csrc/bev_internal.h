@@ -106,9 +106,9 @@ struct BatchPtrs {
     const bev_point_t *pts;      /* packed input points (or ordered cloud in identity mode) */
     const FrameDesc *frames;
     FrameInfo *info;             /* [nf] (nullptr: every frame general) */
-    uint32_t *est;               /* [nf][N][strips]: stream frames: estimated input position of slot (r, first column of strip - 2) */
+    uint32_t *est;               /* [nf][strips][N]: stream frames: estimated input position of slot (r, first column of strip - 2) */
     uint32_t *tail_list;         /* [nf][N][strips][kTailCap]: stream frames: column offset | input index << 8 of the tail points (nullptr: no stream mode) */
-    uint32_t *tail_cnt;          /* [nf][N][strips] */
+    uint32_t *tail_cnt;          /* [nf][strips][N] */
     uint32_t *winner;            /* [nf][S]  (win_tag << win_shift) | index+1 of the last input point per slot */
     uint32_t win_tag;            /* generation of this sub-batch in its workspace set (0: table was cleared) */
     int win_shift;               /* bits of index+1 */

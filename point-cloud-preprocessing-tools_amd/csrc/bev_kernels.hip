@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
                 est = p0 + (uint32_t)(((unsigned long long)(want - s0) * (T - 1u - p0)) / (slot_last - s0));
             }
         }
-        fest[i] = est < T ? est : T;
+        fest[st * g.N + r] = est < T ? est : T; /* [strip][row]: a strip's workgroup reads its 64 rows as two lines, not 64 sectors */
     }
 
     PH(); /* estimates */
@@ -291,7 +291,10 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
     __syncthreads();
     PH(); /* tail lists */
     uint32_t *fcnt = b.tail_cnt + (size_t)f * g.N * g.strips;
-    for (int i = tid; i < g.N * g.strips; i += kProbeThreads) fcnt[i] = tcnt[i] < (uint32_t)kTailCap ? tcnt[i] : (uint32_t)kTailCap;
+    for (int i = tid; i < g.N * g.strips; i += kProbeThreads) { /* [strip][row], as the estimates */
+        const int r = i / g.strips, st = i - r * g.strips;
+        fcnt[st * g.N + r] = tcnt[i] < (uint32_t)kTailCap ? tcnt[i] : (uint32_t)kTailCap;
+    }
     /* a list that does not hold its (row, strip)'s tail points: the frame goes the general way (the scan repeats the
      * scatter of the tail among all the others) */
     if (tid == 0) b.info[f] = overflow ? FrameInfo{0u, kFrameGeneral, 4u, 0u} : FrameInfo{T, kFrameStream, 0u, 0u};
@@ -662,9 +665,9 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
         const uint32_t *fe = b.est + (size_t)f * N * strips;
         const uint32_t *fc = b.tail_cnt + (size_t)f * N * strips;
         for (int r = tid; r < N; r += kStripThreads) {
-            est_l[0][r] = (int)fe[r * strips + strip];
-            est_l[1][r] = (int)fe[r * strips];
-            tcnt_l[r] = (uint8_t)fc[r * strips + strip];
+            est_l[0][r] = (int)fe[strip * N + r];
+            est_l[1][r] = (int)fe[r];
+            tcnt_l[r] = (uint8_t)fc[strip * N + r];
         }
     }
     lds_barrier();
