@@ -776,6 +776,15 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
             const int pflat = __builtin_amdgcn_update_dpp(0x7fffffff, sflat, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
             const bool chk = own & (q > 0);
             failed |= (chk & ((tid == 0) | ((lane != 0) & !(pflat < sflat)))) ? 1u : 0u;
+            /* ... and the window must BRACKET the (row, strip)'s span of slots, halo columns included: the own columns are
+             * proven found by the count, the two halo columns on either side are not — a halo point the window misses
+             * would read as an empty slot and change phase A's fallbacks (BatchMultiBevGen.cpp:146-154) with nobody
+             * noticing.  The prefix is strictly ascending (that is what the checks above prove), so it is enough that the
+             * first position's slot is not past the span's first slot (or the window starts at the input's start) and the
+             * last position's slot is the span's last or beyond (or the window reaches the prefix's end). */
+            const int ibase = rho * H + first_col;
+            failed |= (((tid == 0) & (q > 0) & (sflat > ibase)) |
+                       ((tid == kWinPos - 1) & (q < (int)T - 1) & (sflat < ibase + row_span - 1))) ? 1u : 0u;
             dneed = chk & (lane == 0) & (tid != 0);
             dflat = sflat;
             dq = q;
@@ -788,6 +797,10 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
             const uint32_t off = (uint32_t)(H - first_col) + col;
             const bool ok = (lane < kWrapPos) & ((unsigned)q < T) & (row == (uint32_t)rho) & (col < 2u) & (off < (uint32_t)kStripVirt);
             atomicMax(&irow[ok ? off : (uint32_t)kStripThreads], (uint32_t)(kWinPos + k) + 1u);
+            /* the same bracket for the 16 positions around the row's start: slots rho * H and rho * H + 1 lie inside */
+            const int wflat = slot_or_max(q, rcw);
+            failed |= (((lane == 0) & (q > 0) & (wflat > rho * H)) |
+                       ((lane == kWrapPos - 1) & (q < (int)T - 1) & (wflat < rho * H + 1))) ? 1u : 0u;
         }
         if (wv == 3) { /* later input index beats earlier, any tail point beats the prefix */
             const uint32_t e = te[tslot];

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _stream_on(monkeypatch):
-    """the in-place path is opt-in (BEV_STREAM=1, read by bev_create) until it is faster than the general one"""
+    """reading in place is the default (BEV_STREAM=0, read by bev_create, turns it off): pinned here so that a stray
+    environment cannot make these tests pass on the general path alone"""
     monkeypatch.setenv("BEV_STREAM", "1")
 
 
@@ -32,7 +33,7 @@ def _run(p, ctx, frames):
 @pytest.mark.parametrize("sensor", ["HDL_64E", "HDL_32E", "OS1_64"])
 def test_sorted_sweeps_are_read_in_place(sensor):
     p = bev_amd.params_for_sensor(sensor)
-    # (appended points per frame in proportion to the sensor: a (row, strip) lists at most 48 of them, bev_internal.h kTailCap)
+    # (appended points per frame in proportion to the sensor: a (row, strip) lists at most 64 of them, bev_internal.h kTailCap)
     dup = 5000 * p.slots // 133312
     frames = [synth.sweep(p, 70 + i, keep=k, n_dup=d) for i, (k, d) in enumerate([(0.98, dup), (1.0, 0), (0.6, 300), (0.9, 0)])]
     ctx = bev_amd.BevContext(p, device=0, max_batch=8, max_points=max(len(f) for f in frames))
@@ -79,7 +80,7 @@ def test_unsorted_frames_go_the_general_way():
 
 
 def test_inputs_that_only_look_sorted_are_caught_and_redone():
-    """The probe samples every 128th point; everything in between is verified by the walk.  Each frame below is a
+    """The probe samples every 63rd point; everything in between is verified by the walk.  Each frame below is a
     sorted sweep with one defect hidden from the samples."""
     p = bev_amd.params_for_sensor("HDL_64E")
     base = synth.sweep(p, 90, keep=0.97, n_dup=0)
@@ -115,6 +116,47 @@ def test_inputs_that_only_look_sorted_are_caught_and_redone():
         assert all(m == 2 for m in modes[:-1]), modes  # every defect is caught, the frame redone
     finally:
         ctx.close()
+
+
+def test_gaps_that_shift_a_window_off_its_halo_columns_are_caught_or_harmless():
+    """A (row, strip)'s window is placed by interpolation between the probe's samples; the walk counts and order-checks the
+    points of the strip's OWN columns only.  A run of dropped returns next to a row start or a strip boundary moves the
+    estimate by tens of positions while every own point may still lie inside the 256-position window — and the two halo
+    columns on either side (whose points feed phase A's (c + 2) % H and c - 2 fallbacks, BatchMultiBevGen.cpp:146-154)
+    may not.  The window has to bracket its whole span or the frame is redone; either way the result is the oracle's.
+    The points next to the gaps carry intensity -1, so that the fallbacks are really taken."""
+    p = bev_amd.params_for_sensor("HDL_64E")
+    H, strip = p.horizon_scan, 236
+    for fid, keep in [(300, 1.0), (301, 0.98), (302, 0.9)]:
+        frames = []
+        base = synth.sweep(p, fid, keep=keep, n_dup=0)
+        slot = base["row"].astype(np.int64) * H + base["col"]
+        for variant in range(4):
+            drop = np.zeros(len(base), bool)
+            minus1 = np.zeros(len(base), bool)
+            for r in range(15, 64, 3):
+                if variant == 0:    # 100 empty slots just after the row's start
+                    lo, hi = r * H + 2, r * H + 102
+                elif variant == 1:  # ... just before a strip boundary (strip 3 | strip 4)
+                    lo, hi = r * H + 4 * strip - 104, r * H + 4 * strip - 4
+                elif variant == 2:  # ... just before the row's end: the next row's strip 0 reads its flat-index halo there
+                    lo, hi = r * H + H - 110, r * H + H - 3
+                else:               # ... right after a strip boundary, 40 wide (estimate too high for the strip's left halo)
+                    lo, hi = r * H + 5 * strip + 1, r * H + 5 * strip + 41
+                drop |= (slot >= lo) & (slot < hi)
+                # upper neighbours (row r - 1) of the row's first and last columns and of the strip's edge columns: invalid
+                for c in (0, 1, H - 2, H - 1, 4 * strip - 2, 4 * strip - 1, 4 * strip, 4 * strip + 1, 5 * strip, 5 * strip + 1):
+                    minus1 |= (slot == (r - 1) * H + c) | (slot == r * H + c)
+            f = base.copy()
+            f["intensity"][minus1] = -1.0
+            frames.append(np.ascontiguousarray(f[~drop]))
+        ctx = bev_amd.BevContext(p, device=0, max_batch=16, max_points=max(len(f) for f in frames))  # one sub-batch
+        try:
+            info = _run(p, ctx, frames)   # every frame equal to the oracle
+            modes = [int(m) for m in info[:, 1]]
+            assert all(m in (1, 2) for m in modes), modes       # sorted sweeps: read in place or caught and redone
+        finally:
+            ctx.close()
 
 
 def test_stream_and_general_frames_mixed_in_one_sub_batch_and_the_knob():
