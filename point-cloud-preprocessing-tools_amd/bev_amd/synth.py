@@ -77,3 +77,16 @@ def adversarial(params: BevParams, n_points: int, seed: int, nonfinite: bool = F
     buf = np.empty(n_points, dtype=POINT_DTYPE)
     n = lib.bev_synth_adversarial(C.byref(params), seed, n_points, 1 if nonfinite else 0, buf.ctypes.data, n_points)
     return buf[:n]
+
+
+def structured(params: BevParams, frame_id: int, keep: float = 0.98, kitti_intensity: bool = False,
+               seed: int = SEED_BASE) -> np.ndarray:
+    """A structured cloud of exactly S records, what the KITTI selector writes (KittiPointCloudSelect.cpp:206-207,240):
+    record i is the point of slot i or — a dropped return — an all-zero record (row = col = 0).  The kept points are those
+    of `sweep` with the same frame id.  kitti_intensity: every real point carries intensity -1 (:238)."""
+    pts = sweep(params, frame_id, keep=keep, n_dup=0, seed=seed)
+    out = np.zeros(params.slots, dtype=POINT_DTYPE)
+    out[pts["row"].astype(np.int64) * params.horizon_scan + pts["col"]] = pts
+    if kitti_intensity:
+        out["intensity"][out["label"] == -2] = -1.0
+    return out

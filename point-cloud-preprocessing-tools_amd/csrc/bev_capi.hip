@@ -468,7 +468,11 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         } else {
             RoctxRange rr("bev:front (probe, order scan, column walk)");
             uint32_t max_pts = 0;
-            for (int f = 0; f < nb; ++f) max_pts = std::max(max_pts, c->h_desc[ds][f0 + f].n_pts);
+            int n_exact_s = 0; /* frames that can be structured clouds */
+            for (int f = 0; f < nb; ++f) {
+                max_pts = std::max(max_pts, c->h_desc[ds][f0 + f].n_pts);
+                n_exact_s += c->h_desc[ds][f0 + f].n_pts == (uint32_t)g.S ? 1 : 0;
+            }
             /* winner entries carry the set's generation: no memset between sub-batches (see winner_index) */
             const uint32_t max_gen = c->win_shift <= 28 ? (1u << (32 - c->win_shift)) - 1u : 0u;
             if (ln.win_gen + 1u > max_gen) {
@@ -481,14 +485,22 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                 ProfScope ps(c, K_PROBE, nb, st);
                 launch_probe(g, b, nb, c->allow_stream, st);
             }
-            if (c->allow_stream) { /* frames k_probe found sorted up to a tail: read in place, verified */
+            if (c->allow_stream && ln.tail_list) { /* frames k_probe found sorted up to a tail: read in place, verified */
                 ProfScope ps(c, K_GATHER_GROUND, nb, st);
                 launch_gather_ground(g, b, nb, 2, kFrameStream, st);
+            }
+            if (c->allow_stream && n_exact_s > 0) { /* structured clouds (only a frame of exactly S records can be one) */
+                ProfScope ps(c, K_WALK_STRUCTURED, nb, st);
+                launch_gather_ground(g, b, nb, 3, kFrameStructured, st);
+            }
+            if (c->allow_stream) {
+                ProfScope ps(c, K_VERDICT, nb, st);
                 launch_verdict(b, nb, ln.hint, st);
             }
             {   /* every other frame — general, or read in place and failed (normally none of a sorted sub-batch).  Thin
                  * launch while this workspace set's earlier sub-batches were read in place entirely (a hint that k_verdict
-                 * leaves in mapped host memory; read without waiting: it only chooses the launch shape) */
+                 * leaves in mapped host memory — UINT32_MAX until the set's first verdict: wide —, read without waiting:
+                 * it only chooses the launch shape) */
                 const bool thin = c->allow_stream && ln.hint && *reinterpret_cast<volatile uint32_t *>(ln.hint) == 0u;
                 ProfScope ps(c, K_ORDER_SCAN, nb, st);
                 launch_order_scan(g, b, nb, max_pts, thin, st);
@@ -722,7 +734,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipEventCreateWithFlags(&ln.front_done, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ln.back_done, hipEventDisableTiming));
         CK(hipHostMalloc((void **)&ln.hint, sizeof(uint32_t), hipHostMallocMapped));
-        *ln.hint = 0u;
+        *ln.hint = 0xffffffffu; /* nothing known yet: the set's first order scan is launched wide */
         CK(hipMalloc((void **)&ln.info, nb * sizeof(FrameInfo)));
         CK(hipMemset(ln.info, 0, nb * sizeof(FrameInfo)));
         CK(hipMalloc((void **)&ln.est, nb * (size_t)c->geo.N * c->geo.strips * sizeof(uint32_t)));

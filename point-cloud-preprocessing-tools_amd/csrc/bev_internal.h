@@ -59,15 +59,26 @@ struct FrameDesc {
  *   kFrameStream   the input's first T points are in strictly ascending slot order (a sweep written row by row, the
  *                  usual output of a selector): the walk reads them in place, row by row, and only the tail [T, n)
  *                  goes through the order scan; the walk VERIFIES the order of everything it consumes and counts it;
- *   kFrameRedo     a stream frame whose verification failed: done again the general way (results never depend on
- *                  what k_probe guessed). */
-enum : uint32_t { kFrameGeneral = 0, kFrameStream = 1, kFrameRedo = 2 };
+ *   kFrameRedo     a stream / structured frame whose verification failed: done again the general way (results never
+ *                  depend on what k_probe guessed);
+ *   kFrameStructured  the input IS a structured cloud of S records, what the KITTI selector writes
+ *                  (KittiPointCloudSelect.cpp:206-207,240): record i is the point of slot i or an all-zero record.  The
+ *                  scatter of getOrderedCloud is then the identity on every slot but slot 0, where every all-zero
+ *                  record lands (row = col = 0): slot 0 ends up all-zero iff a record after the first is all-zero.  The
+ *                  walk reads the records in place, once, coalesced, checks every one of them, and learns on the way
+ *                  whether an all-zero record exists — which k_probe had to guess from its samples (the guess decides
+ *                  slot 0 before the walk has seen the frame; a wrong guess is a failed frame). */
+enum : uint32_t { kFrameGeneral = 0, kFrameStream = 1, kFrameRedo = 2, kFrameStructured = 3 };
+__host__ __device__ inline bool frame_read_in_place(uint32_t mode) { return mode == kFrameStream || mode == kFrameStructured; }
 struct FrameInfo {
-    uint32_t T;        /* length of the prefix taken for sorted */
+    uint32_t T;        /* length of the prefix taken for sorted (structured: S) */
     uint32_t mode;
-    uint32_t consumed; /* prefix points the stream walk has found in their own (row, strip) window */
-    uint32_t failed;   /* != 0: a consumed point was not above its predecessor, or could not be checked */
+    uint32_t consumed; /* prefix points the stream walk has found in their own (row, strip) window (structured: records checked) */
+    uint32_t failed;   /* bit 0: a consumed point was not above its predecessor, or could not be checked (structured: a
+                        * record is neither its slot's point nor all-zero); structured frames also: bit 1: the walk saw an
+                        * all-zero record after the first, bit 2: k_probe guessed that there is one */
 };
+constexpr uint32_t kInfoFailed = 1u, kInfoZeroSeen = 2u, kInfoZeroGuess = 4u;
 constexpr int kProbeStride = 63;    /* k_probe looks at every 63rd point (odd: no resonance with firing orders of 2^k beams); the position of a
                                      * slot between two samples is interpolated: its error grows with the root of the stride */
 constexpr int kMaxSamples = 8192;   /* => stream mode for frames of up to 2^20 points; longer ones go the general way */
@@ -138,6 +149,8 @@ enum KernelId {
     K_TRANSFORM,
     K_PROBE,
     K_WALK_GENERAL, /* the walk through the winner table (K_GATHER_GROUND: the walk that reads in place, or the identity walk) */
+    K_WALK_STRUCTURED, /* the walk over structured clouds (kFrameStructured) */
+    K_VERDICT,
     K_COUNT
 };
 const char *kernel_name(int id);
@@ -147,8 +160,9 @@ int raster_bands_for(int mat_size);
 /* launchers (bev_kernels.hip) — all asynchronous on `st` */
 /* the frames that are not read in place: general ones and (after k_verdict) those whose verification failed */
 void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, bool thin, hipStream_t st);
-/* the column walk.  source 0: through the winner table (frames of every mode but kFrameStream); 1: identity, b.pts
- * already is the ordered cloud (bev_mark_ground); 2: in place (frames of mode kFrameStream: pass mode = kFrameStream) */
+/* the column walk.  source 0: through the winner table (frames of every mode but kFrameStream / kFrameStructured);
+ * 1: identity, b.pts already is the ordered cloud (bev_mark_ground); 2: in place (frames of mode kFrameStream: pass
+ * mode = kFrameStream); 3: structured clouds (frames of mode kFrameStructured: pass that mode) */
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int source, uint32_t mode, hipStream_t st);
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st);
 void launch_verdict(const BatchPtrs &b, int nf, uint32_t *host_hint, hipStream_t st);

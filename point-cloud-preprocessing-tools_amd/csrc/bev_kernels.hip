@@ -63,7 +63,7 @@ namespace bevk {
 static const char *const kNames[K_COUNT] = {
     "k_order_scan", "k_walk", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project", "k_transform",
-    "k_probe", "k_walk_general",
+    "k_probe", "k_walk_general", "k_walk_structured", "k_verdict",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
 
@@ -155,9 +155,16 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
     PH();
     const bool can = allow_stream && n >= (uint32_t)kStreamMinPrefix && ns <= (uint32_t)kMaxSamples && g.N <= kStreamMaxRows &&
                      g.N * g.strips <= kTailBuckets && n < (1u << 24) && b.tail_list != nullptr;
-    if (tid == 0) first_bad = can ? ns : 0u;
+    /* a structured cloud (kFrameStructured): exactly S records, every sampled one its own slot's point or empty */
+    const bool can_struct = allow_stream && n == (uint32_t)g.S;
+    __shared__ uint32_t struct_bad, struct_zero;
+    if (tid == 0) {
+        first_bad = can ? ns : 0u;
+        struct_bad = 0u;
+        struct_zero = 0u;
+    }
     __syncthreads();
-    if (can) {
+    if (can || can_struct) {
         /* every sample is a sector of its own somewhere in the frame: all of a thread's loads are requested before the
          * first is used (one load per trip of the plain loop was half of the kernel's time: 8 round trips under load) */
         constexpr int kSPer = 9; /* 256 x 9 samples = 145 k points per trip */
@@ -177,14 +184,30 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
                 const size_t i = (size_t)k * kProbeStride;
                 const uint32_t row = rc[u] & 0xffffu, col = rc[u] >> 16;
                 uint32_t sl = (row < (uint32_t)g.N && col < (uint32_t)g.H) ? row * (uint32_t)g.H + col : 0xffffffffu;
+                const uint32_t sl0 = sl;
                 if (i + 1 < n) {
                     const uint32_t row1 = rc1[u] & 0xffffu, col1 = rc1[u] >> 16;
-                    if (!(row1 < (uint32_t)g.N && col1 < (uint32_t)g.H) || row1 * (uint32_t)g.H + col1 <= sl) sl = 0xffffffffu;
+                    const uint32_t sl1 = (row1 < (uint32_t)g.N && col1 < (uint32_t)g.H) ? row1 * (uint32_t)g.H + col1 : 0xffffffffu;
+                    if (sl1 == 0xffffffffu || sl1 <= sl) sl = 0xffffffffu;
+                    if (can_struct) { /* the successor: position i + 1 >= 1 */
+                        if (sl1 != (uint32_t)(i + 1) && rc1[u] != 0u) struct_bad = 1u;
+                        if (rc1[u] == 0u) struct_zero = 1u;
+                    }
                 }
-                samp[k] = sl;
+                if (can_struct) {
+                    if (sl0 != (uint32_t)i && rc[u] != 0u) struct_bad = 1u;
+                    if (rc[u] == 0u && i >= 1) struct_zero = 1u;
+                }
+                if (can) samp[k] = sl;
             }
         }
         __syncthreads();
+        if (can_struct && !struct_bad) { /* (the walk checks every record; a wrong guess about the empty ones is a failed frame) */
+            if (tid == 0) b.info[f] = FrameInfo{n, kFrameStructured, 0u, struct_zero ? kInfoZeroGuess : 0u};
+            return;
+        }
+    }
+    if (can) {
         for (uint32_t k = tid; k < ns; k += (uint32_t)kProbeThreads) /* first sample that is out of range or not above its predecessor */
             if (samp[k] == 0xffffffffu || (k > 0u && samp[k] <= samp[k - 1u])) atomicMin(&first_bad, k);
         __syncthreads();
@@ -314,11 +337,16 @@ __global__ __launch_bounds__(1024) void k_verdict(FrameInfo *info, int nf, uint3
     uint32_t mine = 0u;
     for (int f = threadIdx.x; f < nf; f += 1024) {
         FrameInfo fi = info[f];
-        if (fi.mode == kFrameStream && (fi.failed != 0u || fi.consumed != fi.T)) {
+        const bool bad_stream = fi.mode == kFrameStream && (fi.failed != 0u || fi.consumed != fi.T);
+        /* structured: every record checked, none bad, and the guess about all-zero records (it decided slot 0) was right */
+        const bool bad_struct = fi.mode == kFrameStructured &&
+                                ((fi.failed & kInfoFailed) != 0u || fi.consumed != fi.T ||
+                                 ((fi.failed & kInfoZeroSeen) != 0u) != ((fi.failed & kInfoZeroGuess) != 0u));
+        if (bad_stream || bad_struct) {
             info[f].mode = kFrameRedo;
             fi.mode = kFrameRedo;
         }
-        mine += fi.mode != kFrameStream ? 1u : 0u;
+        mine += frame_read_in_place(fi.mode) ? 0u : 1u;
     }
     if (mine) atomicAdd(&others, mine);
     __syncthreads();
@@ -343,7 +371,7 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
      * gridDim.x workgroups per frame stride over its 1024-point blocks (launch_order_scan: one per block, or 8 per frame
      * for the launch that is expected to find nothing to do). */
     const int f = blockIdx.y;
-    if (info && info[f].mode == kFrameStream) return;
+    if (info && frame_read_in_place(info[f].mode)) return;
     const FrameDesc fd = frames[f];
     const bev_point_t *fp = pts + fd.in_offset;
     uint32_t *fw = winner + (size_t)f * S;
@@ -552,7 +580,7 @@ struct WalkRow {
 __device__ __forceinline__ int wr_status(uint32_t fl) { return (int)(fl & 3u) - 1; }
 __device__ __forceinline__ int wr_gflag(uint32_t fl) { return (int)((fl >> 2) & 3u) - 1; }
 
-enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcInPlace = 2 };
+enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcInPlace = 2, kSrcStructured = 3 };
 constexpr int kWinPos = kStripThreads; /* in-place source: window positions of a (row, strip), one per thread: est - kWinLead ... */
 constexpr int kWinLead = 12;
 constexpr int kWrapPos = 16;       /* ... the last strip's wrap-around halo: positions around the row's start */
@@ -605,7 +633,9 @@ constexpr int kFlRankShift = 8; /* WalkRow::fl bits 8..13: the lane's rank among
 template <int kSrc, bool kPow2, bool kGm>
 __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
-    constexpr bool kIdentity = kSrc == kSrcIdentity, kInPlace = kSrc == kSrcInPlace;
+    /* kStructured: the identity source over the caller's INPUT (record i = slot i's point or an all-zero record), every
+     * record checked; kIdentity below covers both (no winner table, position = slot) */
+    constexpr bool kStructured = kSrc == kSrcStructured, kIdentity = kSrc == kSrcIdentity || kStructured, kInPlace = kSrc == kSrcInPlace;
 #ifdef BEV_EXP_WALK3
     asm volatile("" ::: "v135"); /* 136 registers: three waves per SIMD */
 #endif
@@ -615,7 +645,10 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
     const long long tl_t0 = wall_clock64();
 #endif
     if (!map_block_xcd(blockIdx.x, nf, g.strips, f, strip)) return;
-    if (!kIdentity && b.info && (b.info[f].mode == kFrameStream) != (want_mode == kFrameStream)) return; /* the other launch of the walk has the frame */
+    if (kSrc != kSrcIdentity && b.info) { /* the launch for its mode has the frame; the general launch has every frame that is not read in place */
+        const uint32_t fmode = b.info[f].mode;
+        if (frame_read_in_place(want_mode) ? fmode != want_mode : frame_read_in_place(fmode)) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = g.N, H = g.H, lo_row = g.N - g.G, strips = g.strips;
     const size_t frame_off = (size_t)f * g.S;
@@ -675,7 +708,7 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
      * threads that would are not output columns; the in-place source needs every wave for its windows) */
     if (!kInPlace && __ballot(provider) == 0ull) return;
 
-    const bev_point_t *fpts = kIdentity ? (b.pts + frame_off) : (b.pts + b.frames[f].in_offset);
+    const bev_point_t *fpts = kSrc == kSrcIdentity ? (b.pts + frame_off) : (b.pts + b.frames[f].in_offset);
     const uint32_t *fwin = b.winner + frame_off;
     const uint32_t win_tag = b.win_tag;
     const int win_shift = b.win_shift;
@@ -717,6 +750,11 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
     const uint32_t tlist_l = __builtin_amdgcn_readfirstlane(lds_addr(&tlist[0][0]));
     uint32_t te[3] = {0u, 0u, 0u}; /* wave 3: this lane's tail entry of rows q at [q % 3] (column offset | input index << 8) */
     uint32_t consumed = 0u, failed = 0u;
+    /* structured: the (row | col << 16) word the record of this thread's slot in row r must carry is (r - st_rowadj) | st_col
+     * (the flat rule puts virtual columns < 0 into the previous row's tail); whether k_probe expects an all-zero record
+     * after the first — slot 0 is all-zero then, whatever record 0 holds (BatchMultiBevGen.cpp:112-115, last writer) */
+    const uint32_t st_rowadj = v < 0 ? 1u : 0u, st_col = (uint32_t)(v < 0 ? H + v : vcol) << 16;
+    const bool st_zero_guess = kStructured && (b.info[f].failed & kInfoZeroGuess) != 0u;
     const char *fbytes = reinterpret_cast<const char *>(fpts);
     auto pos_addr = [&](int q) -> const char * { /* the point at input position q, or position 0 outside the prefix */
         return fbytes + (size_t)((unsigned)q < T ? q : 0) * 32u;
@@ -925,6 +963,22 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
             if (!((full >> s0) & 1u)) { /* untouched slot: value-initialised, BatchMultiBevGen.cpp:98 */
                 cur_lo = u32x4{0u, 0u, 0u, 0u};
                 cur_hi = u32x4{0u, 0u, 0u, 0u};
+            }
+            if constexpr (kStructured) {
+                /* the record at flat position r * H + vcol: its slot's point (then the scatter leaves it where it is) or
+                 * all-zero (then it lands in slot 0 and its own slot stays value-initialised: all-zero as well); anything
+                 * else fails the frame.  Every record is seen by the owner of its column (counted) and by halo threads. */
+                const bool rec = (full >> s0) & 1u;
+                const uint32_t any = cur_lo.x | cur_lo.y | cur_lo.z | cur_lo.w | cur_hi.x | cur_hi.y | cur_hi.z | cur_hi.w;
+                const bool real = cur_hi.y == (((uint32_t)r - st_rowadj) | st_col);
+                const bool first = (r == 0) & (vcol == 0); /* flat position 0 */
+                failed |= (rec & !real & (any != 0u)) ? kInfoFailed : 0u;
+                failed |= (rec & (any == 0u) & !first) ? kInfoZeroSeen : 0u;
+                consumed += (rec & outcol) ? 1u : 0u;
+                if (first & st_zero_guess) {
+                    cur_lo = u32x4{0u, 0u, 0u, 0u};
+                    cur_hi = u32x4{0u, 0u, 0u, 0u};
+                }
             }
         }
         /* What the waves exchange per step: row r's edge lanes (read by the NEXT step's status) and the per-wave counts of
@@ -1153,7 +1207,7 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
 #endif
     lds_barrier();
     if (tid < bands) b.ncode[((size_t)f * g.emitters + strip) * bands + tid] = band_cursor[tid];
-    if constexpr (kInPlace) {
+    if constexpr (kInPlace || kStructured) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             consumed += __shfl_xor(consumed, d);
@@ -1161,7 +1215,7 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
         }
         if (lane == 0) {
             atomicAdd(&b.info[f].consumed, consumed);
-            if (failed) atomicOr(&b.info[f].failed, 1u);
+            if (failed) atomicOr(&b.info[f].failed, failed);
         }
     }
 }
@@ -2077,6 +2131,7 @@ void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int sou
     const int grid = xcd_grid(nf, g.strips);
     if (source == kSrcIdentity) launch_walk<kSrcIdentity>(g, b, nf, mode, grid, st);
     else if (source == kSrcInPlace) launch_walk<kSrcInPlace>(g, b, nf, mode, grid, st);
+    else if (source == kSrcStructured) launch_walk<kSrcStructured>(g, b, nf, mode, grid, st);
     else launch_walk<kSrcGather>(g, b, nf, mode, grid, st);
 }
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st)

@@ -1,5 +1,6 @@
 """Soak: many different BASELINE-config frames through the pipelined device-resident path, EVERY frame compared with the
-oracle.  usage (GPU box): python scripts/soak.py [rounds] [frames_per_round] [hdl64_sweep | os1_firing | hdl32_sweep | hdl64_adversarial]"""
+oracle.  usage (GPU box): python scripts/soak.py [rounds] [frames_per_round] [hdl64_sweep | os1_firing | hdl32_sweep | hdl64_adversarial | hdl64_structured] [sub_batch]
+(sub_batch defaults to 500, bench.py's launch size)"""
 import sys, os, time
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -12,7 +13,9 @@ from bev_amd import synth
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 workload = sys.argv[3] if len(sys.argv) > 3 else "hdl64_sweep"
-p = bev_amd.params_for_sensor({"hdl64_sweep": "HDL_64E", "os1_firing": "OS1_64", "hdl32_sweep": "HDL_32E", "hdl64_adversarial": "HDL_64E"}[workload])
+sub_batch = int(sys.argv[4]) if len(sys.argv) > 4 else 500
+p = bev_amd.params_for_sensor({"hdl64_sweep": "HDL_64E", "os1_firing": "OS1_64", "hdl32_sweep": "HDL_32E", "hdl64_adversarial": "HDL_64E",
+                               "hdl64_structured": "HDL_64E"}[workload])
 sp = orc.sensor_from_params(p)
 
 
@@ -20,6 +23,8 @@ def make_frame(rnd, f):
     fid = 100000 + rnd * n + f
     if workload == "os1_firing":
         return synth.firing_order(p, fid)
+    if workload == "hdl64_structured":
+        return synth.structured(p, fid, keep=0.98 - 0.3 * (rnd % 3), kitti_intensity=bool(rnd % 2))
     if workload == "hdl64_adversarial":
         return synth.adversarial(p, 60000 + 1000 * (f % 70), fid, nonfinite=bool(f % 2))
     return synth.sweep(p, fid, keep=0.98 - 0.02 * (rnd % 3), n_dup=5000 + 500 * (rnd % 4))
@@ -27,7 +32,8 @@ def make_frame(rnd, f):
 
 S, M, L = p.slots, p.mat_size, p.n_layers
 dev = torch.device("cuda:0")
-ctx = bev_amd.BevContext(p, device=0, max_batch=256, max_points=max(S + 8000, 140000))
+ctx = bev_amd.BevContext(p, device=0, max_batch=sub_batch, max_points=max(S + 8000, 140000))
+print(f"soak: {workload}, {rounds} x {n} frames, sub-batch {sub_batch}", flush=True)
 bad_total = 0
 for rnd in range(rounds):
     t0 = time.time()

@@ -59,6 +59,10 @@ def test_sub_batching_and_lanes_do_not_change_results():
     assert _digest(ref) == _digest(_run(p, frames, sub_batch=7, lanes=1))     # 43 ragged sub-batches, one lane
     assert _digest(ref) == _digest(_run(p, frames, sub_batch=300, lanes=3))   # one sub-batch
     assert _digest(ref) == _digest(_run(p, frames, sub_batch=37, lanes=4, repeats=2))
+    # launches past bench.py's 500 frames (4,500 walk workgroups): the same 300 frames three times over
+    want3 = _digest([np.tile(a, 3) for a in ref])
+    assert want3 == _digest(_run(p, frames * 3, sub_batch=600, lanes=2, repeats=2))   # launches of 600 and 300 frames
+    assert want3 == _digest(_run(p, frames * 3, sub_batch=900, lanes=2))              # one launch of 900 (8,100 workgroups)
     S, M, L = p.slots, p.mat_size, p.n_layers
     sp = orc.sensor_from_params(p)
     for i in (0, 63, 64, 150, N_FRAMES - 1):  # sub-batch edges and the last frame
@@ -94,16 +98,20 @@ def test_winner_generation_wraps():
         ctx.close()
 
 
-def test_baseline_config_every_frame_matches_oracle():
-    """BASELINE configs[1] as bench.py runs it (1000 HDL_64E frames, sub-batches of 256, the two-stage pipeline, three
-    back-to-back asynchronous steps over the same buffers): EVERY frame of the last step against the oracle."""
+@pytest.mark.parametrize("layout,sub_batch", [("sweep", 500), ("sweep", 256), ("structured", 500)])
+def test_baseline_config_every_frame_matches_oracle(layout, sub_batch):
+    """BASELINE configs[1] as bench.py runs it (1000 HDL_64E frames, sub-batches of 500 — bench.py's default launch
+    size — and of 256, the two-stage pipeline, three back-to-back asynchronous steps over the same buffers): EVERY frame
+    of the last step against the oracle.  "structured": the same sweeps in the layout the KITTI selector writes
+    (bench.py --workload hdl64_structured)."""
     from concurrent.futures import ThreadPoolExecutor
 
     p = bev_amd.params_for_sensor("HDL_64E")
     n = 1000
+    make = (lambda f: synth.sweep(p, f, keep=0.98, n_dup=5000)) if layout == "sweep" else (lambda f: synth.structured(p, f, keep=0.98))
     with ThreadPoolExecutor(16) as ex:
-        frames = list(ex.map(lambda f: synth.sweep(p, f, keep=0.98, n_dup=5000), range(n)))
-    ords, multis, singles = _run(p, frames, sub_batch=256, lanes=2, repeats=3)
+        frames = list(ex.map(make, range(n)))
+    ords, multis, singles = _run(p, frames, sub_batch=sub_batch, lanes=2, repeats=3)
     S, M, L = p.slots, p.mat_size, p.n_layers
     sp = orc.sensor_from_params(p)
 
@@ -169,7 +177,7 @@ def test_os1_firing_order_config_every_frame_matches_oracle():
     n = 1000
     with ThreadPoolExecutor(16) as ex:
         frames = list(ex.map(lambda f: synth.firing_order(p, f), range(n)))
-    ords, multis, singles = _run(p, frames, sub_batch=256, lanes=2, repeats=2)
+    ords, multis, singles = _run(p, frames, sub_batch=500, lanes=2, repeats=2)   # bench.py's launch size
     S, M, L = p.slots, p.mat_size, p.n_layers
     sp = orc.sensor_from_params(p)
 
