@@ -234,7 +234,8 @@ def main() -> int:
                      "k_bev_raster": float(L * M * M + M * M)}
     else:  # k_walk: frames read in place; k_walk_general: frames that go through the winner table (only one of the two moves a frame)
         own_bytes = {"k_walk": 32.0 * mean_pts + 32.0 * S, "k_walk_general": 32.0 * mean_pts + 32.0 * S,
-                     "k_walk_structured": 32.0 * mean_pts + 32.0 * S, "k_bev_raster": float(L * M * M + M * M)}
+                     "k_walk_structured": 32.0 * mean_pts + 32.0 * S, "k_walk_colmajor": 32.0 * mean_pts + 32.0 * S,
+                     "k_bev_raster": float(L * M * M + M * M)}
     roofline = None
     kernels = []
     kernels_pipelined = [{"name": s["name"], "launches": s["launches"], "avg_launch_ms": s["total_ms"] / s["launches"],

@@ -493,6 +493,10 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                 ProfScope ps(c, K_WALK_STRUCTURED, nb, st);
                 launch_gather_ground(g, b, nb, 3, kFrameStructured, st);
             }
+            if (c->allow_stream && n_exact_s > 0) { /* ... or S returns in firing order */
+                ProfScope ps(c, K_WALK_COLMAJOR, nb, st);
+                launch_gather_ground(g, b, nb, 4, kFrameColMajor, st);
+            }
             if (c->allow_stream) {
                 ProfScope ps(c, K_VERDICT, nb, st);
                 launch_verdict(b, nb, ln.hint, st);

@@ -67,9 +67,14 @@ struct FrameDesc {
  *                  record lands (row = col = 0): slot 0 ends up all-zero iff a record after the first is all-zero.  The
  *                  walk reads the records in place, once, coalesced, checks every one of them, and learns on the way
  *                  whether an all-zero record exists — which k_probe had to guess from its samples (the guess decides
- *                  slot 0 before the walk has seen the frame; a wrong guess is a failed frame). */
-enum : uint32_t { kFrameGeneral = 0, kFrameStream = 1, kFrameRedo = 2, kFrameStructured = 3 };
-__host__ __device__ inline bool frame_read_in_place(uint32_t mode) { return mode == kFrameStream || mode == kFrameStructured; }
+ *                  slot 0 before the walk has seen the frame; a wrong guess is a failed frame);
+ *   kFrameColMajor the input is S returns in firing order, what the MulRan selector writes
+ *                  (MulranPointCloudSelect.cpp:112-130): position k holds beam k % N of firing k / N, its column is the
+ *                  firing's number plus 0 .. 8 (or out of range: dropped).  The walk fetches a strip's firings band by
+ *                  band (two rows of a firing are one 64-byte sector), settles the last writer of every slot in an LDS
+ *                  index row and checks every record it fetches. */
+enum : uint32_t { kFrameGeneral = 0, kFrameStream = 1, kFrameRedo = 2, kFrameStructured = 3, kFrameColMajor = 4 };
+__host__ __device__ inline bool frame_read_in_place(uint32_t mode) { return mode == kFrameStream || mode == kFrameStructured || mode == kFrameColMajor; }
 struct FrameInfo {
     uint32_t T;        /* length of the prefix taken for sorted (structured: S) */
     uint32_t mode;
@@ -86,6 +91,7 @@ constexpr int kStreamMinPrefix = 2048;
 constexpr int kTailCap = 64;         /* tail points (those after the sorted prefix) a (row, strip) can list; more: general way */
 constexpr int kTailMax = 16384;     /* ... a frame can have */
 constexpr int kTailBuckets = 2048;  /* (row, strip) pairs of a frame that k_probe can count in LDS */
+constexpr int kColMaxDisp = 8;       /* kFrameColMajor: a return's column is its firing's number + 0 .. kColMaxDisp (or >= H: dropped) */
 constexpr int kStreamMaxRows = 64;   /* sensors with more rows go the general way (the stream walk keeps per-row estimates in LDS) */
 
 /* Workspace streams between the kernels of one sub-batch (see bev_exact.h for the candidate key):
@@ -150,6 +156,7 @@ enum KernelId {
     K_PROBE,
     K_WALK_GENERAL, /* the walk through the winner table (K_GATHER_GROUND: the walk that reads in place, or the identity walk) */
     K_WALK_STRUCTURED, /* the walk over structured clouds (kFrameStructured) */
+    K_WALK_COLMAJOR,   /* the walk over clouds in firing order (kFrameColMajor) */
     K_VERDICT,
     K_COUNT
 };
@@ -162,7 +169,8 @@ int raster_bands_for(int mat_size);
 void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, bool thin, hipStream_t st);
 /* the column walk.  source 0: through the winner table (frames of every mode but kFrameStream / kFrameStructured);
  * 1: identity, b.pts already is the ordered cloud (bev_mark_ground); 2: in place (frames of mode kFrameStream: pass
- * mode = kFrameStream); 3: structured clouds (frames of mode kFrameStructured: pass that mode) */
+ * mode = kFrameStream); 3: structured clouds (frames of mode kFrameStructured: pass that mode); 4: clouds in firing
+ * order (kFrameColMajor) */
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int source, uint32_t mode, hipStream_t st);
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st);
 void launch_verdict(const BatchPtrs &b, int nf, uint32_t *host_hint, hipStream_t st);

@@ -63,7 +63,7 @@ namespace bevk {
 static const char *const kNames[K_COUNT] = {
     "k_order_scan", "k_walk", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project", "k_transform",
-    "k_probe", "k_walk_general", "k_walk_structured", "k_verdict",
+    "k_probe", "k_walk_general", "k_walk_structured", "k_walk_colmajor", "k_verdict",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
 
@@ -157,11 +157,14 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
                      g.N * g.strips <= kTailBuckets && n < (1u << 24) && b.tail_list != nullptr;
     /* a structured cloud (kFrameStructured): exactly S records, every sampled one its own slot's point or empty */
     const bool can_struct = allow_stream && n == (uint32_t)g.S;
-    __shared__ uint32_t struct_bad, struct_zero;
+    /* ... or S returns in firing order (kFrameColMajor): every sampled record is beam (position mod N) of firing
+     * (position / N), its column the firing's number + 0 .. 8 or out of range */
+    __shared__ uint32_t struct_bad, struct_zero, cm_bad;
     if (tid == 0) {
         first_bad = can ? ns : 0u;
         struct_bad = 0u;
         struct_zero = 0u;
+        cm_bad = 0u;
     }
     __syncthreads();
     if (can || can_struct) {
@@ -192,11 +195,15 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
                     if (can_struct) { /* the successor: position i + 1 >= 1 */
                         if (sl1 != (uint32_t)(i + 1) && rc1[u] != 0u) struct_bad = 1u;
                         if (rc1[u] == 0u) struct_zero = 1u;
+                        const uint32_t fire1 = (uint32_t)(i + 1) / (uint32_t)g.N, beam1 = (uint32_t)(i + 1) - fire1 * (uint32_t)g.N;
+                        if (row1 != beam1 || (col1 < (uint32_t)g.H && col1 - fire1 > (uint32_t)kColMaxDisp)) cm_bad = 1u;
                     }
                 }
                 if (can_struct) {
                     if (sl0 != (uint32_t)i && rc[u] != 0u) struct_bad = 1u;
                     if (rc[u] == 0u && i >= 1) struct_zero = 1u;
+                    const uint32_t fire = (uint32_t)i / (uint32_t)g.N, beam = (uint32_t)i - fire * (uint32_t)g.N;
+                    if (row != beam || (col < (uint32_t)g.H && col - fire > (uint32_t)kColMaxDisp)) cm_bad = 1u;
                 }
                 if (can) samp[k] = sl;
             }
@@ -204,6 +211,10 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
         __syncthreads();
         if (can_struct && !struct_bad) { /* (the walk checks every record; a wrong guess about the empty ones is a failed frame) */
             if (tid == 0) b.info[f] = FrameInfo{n, kFrameStructured, 0u, struct_zero ? kInfoZeroGuess : 0u};
+            return;
+        }
+        if (can_struct && !cm_bad && g.N >= 2) {
+            if (tid == 0) b.info[f] = FrameInfo{n, kFrameColMajor, 0u, 0u};
             return;
         }
     }
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(1024) void k_verdict(FrameInfo *info, int nf, uint3
     uint32_t mine = 0u;
     for (int f = threadIdx.x; f < nf; f += 1024) {
         FrameInfo fi = info[f];
-        const bool bad_stream = fi.mode == kFrameStream && (fi.failed != 0u || fi.consumed != fi.T);
+        const bool bad_stream = (fi.mode == kFrameStream || fi.mode == kFrameColMajor) && (fi.failed != 0u || fi.consumed != fi.T);
         /* structured: every record checked, none bad, and the guess about all-zero records (it decided slot 0) was right */
         const bool bad_struct = fi.mode == kFrameStructured &&
                                 ((fi.failed & kInfoFailed) != 0u || fi.consumed != fi.T ||
@@ -580,7 +591,19 @@ struct WalkRow {
 __device__ __forceinline__ int wr_status(uint32_t fl) { return (int)(fl & 3u) - 1; }
 __device__ __forceinline__ int wr_gflag(uint32_t fl) { return (int)((fl >> 2) & 3u) - 1; }
 
-enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcInPlace = 2, kSrcStructured = 3 };
+enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcInPlace = 2, kSrcStructured = 3, kSrcColMajor = 4 };
+/* Column-major source (kFrameColMajor): input position k holds the return of firing k / N, beam k % N — what the MulRan
+ * selector writes (MulranPointCloudSelect.cpp:112-130: row = k % 64, col from the azimuth).  A strip's 256 threads take one
+ * firing each, kColLead firings before the strip's first own column; the records of kBandRows consecutive rows of a
+ * firing are 64 contiguous bytes of the input, fetched as one band. */
+constexpr int kColLead = 10;     /* 2 halo columns + kColMaxDisp */
+constexpr int kBandRows = 2;
+constexpr int kSideFirings = 16; /* the first / last firings: the last strip's wrap-around halo, strip 0's flat-index halo */
+constexpr int kBandBytes = kStripThreads * 32 * kBandRows;
+constexpr int kSideBytes = kSideFirings * 32 * kBandRows; /* one side window */
+constexpr int kColBuf = kBandBytes + 2 * kSideBytes;     /* one band buffer: the band, the flat-rule window, the wrap-around window */
+static_assert(kSideFirings * 2 * kBandRows == 64, "a side window of a band is one LDS-DMA instruction");
+static_assert(kStripVirt + kColMaxDisp <= kStripThreads && kColLead == 2 + kColMaxDisp && kColMaxDisp + 2 <= kSideFirings, "firings a strip's columns can come from");
 constexpr int kWinPos = kStripThreads; /* in-place source: window positions of a (row, strip), one per thread: est - kWinLead ... */
 constexpr int kWinLead = 12;
 constexpr int kWrapPos = 16;       /* ... the last strip's wrap-around halo: positions around the row's start */
@@ -631,11 +654,13 @@ __device__ __forceinline__ uint32_t quarter_scan(bool c, uint32_t q, uint32_t *r
 constexpr int kFlRankShift = 8; /* WalkRow::fl bits 8..13: the lane's rank among its wave's candidates of its quarter */
 
 template <int kSrc, bool kPow2, bool kGm>
-__global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
+__global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_WAVES) BEV_WALK_OCC void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
     /* kStructured: the identity source over the caller's INPUT (record i = slot i's point or an all-zero record), every
      * record checked; kIdentity below covers both (no winner table, position = slot) */
     constexpr bool kStructured = kSrc == kSrcStructured, kIdentity = kSrc == kSrcIdentity || kStructured, kInPlace = kSrc == kSrcInPlace;
+    /* kIndexed: the sources whose points reach their columns through an index row (LDS atomicMax), after the step's barrier */
+    constexpr bool kColMajor = kSrc == kSrcColMajor, kIndexed = kInPlace || kColMajor;
 #ifdef BEV_EXP_WALK3
     asm volatile("" ::: "v135"); /* 136 registers: three waves per SIMD */
 #endif
@@ -666,12 +691,13 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
 
     constexpr int kWaves = kStripThreads / 64;
     constexpr int kSlotBytes = kInPlace ? kInPlaceSlot : 8192;
-    constexpr int kSeenB = kInPlace ? BEV_SEENB : kSeenBits;       /* (the in-place source needs the LDS for its windows) */
+    constexpr int kSeenB = kIndexed ? BEV_SEENB : kSeenBits;       /* (the in-place source needs the LDS for its windows) */
     /* the points of rows r, r+1, r+2.  Gather / identity: by thread, low halves in the first 4 KiB, high halves in the
      * second.  In place: by window position, 32 B each, then the wrap-around positions, then the tail points */
-    __shared__ __attribute__((aligned(16))) char ring[3 * kSlotBytes];
+    /* column-major: two band buffers, then 8 KiB for the write-out's transposition */
+    __shared__ __attribute__((aligned(16))) char ring[kColMajor ? 2 * kColBuf + 8192 : 3 * kSlotBytes];
     __shared__ uint32_t wring[kSrc == kSrcGather ? 3 : 1][kStripThreads]; /* raw winner words of rows r+2, r+3, r+4 */
-    __shared__ uint32_t idx[kInPlace ? 2 : 1][kInPlace ? kStripThreads + 1 : 1]; /* column offset -> position + 1 | tail key ([256]: nowhere) */
+    __shared__ uint32_t idx[kIndexed ? 2 : 1][kIndexed ? kStripThreads + 1 : 1]; /* column offset -> position + 1 | tail key ([256]: nowhere) */
     __shared__ u32x4 zero16[kInPlace ? 1 : 1];                               /* what an empty slot reads */
     __shared__ uint32_t tlist[kInPlace ? 3 : 1][kInPlace ? 64 : 1];       /* tail lists of rows r+2, r+3, r+4 */
     __shared__ int est_l[2][kInPlace ? kStreamMaxRows : 1];
@@ -691,10 +717,12 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
     for (int x = tid; x < g.rp.mat_size; x += kStripThreads) band_tab[x] = (uint8_t)raster_band_of_nodiv(x, g.rp);
     if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
     else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
-    if constexpr (kInPlace) {
+    if constexpr (kIndexed) {
         idx[0][tid] = 0u;
         idx[1][tid] = 0u;
         if (tid == 0) zero16[0] = u32x4{0u, 0u, 0u, 0u};
+    }
+    if constexpr (kInPlace) {
         const uint32_t *fe = b.est + (size_t)f * N * strips;
         const uint32_t *fc = b.tail_cnt + (size_t)f * N * strips;
         for (int r = tid; r < N; r += kStripThreads) {
@@ -706,7 +734,7 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
     lds_barrier();
     /* a wave none of whose threads has a column ends here (its counts stay zero, nobody reads its edge lanes: the
      * threads that would are not output columns; the in-place source needs every wave for its windows) */
-    if (!kInPlace && __ballot(provider) == 0ull) return;
+    if (!kIndexed && __ballot(provider) == 0ull) return;
 
     const bev_point_t *fpts = kSrc == kSrcIdentity ? (b.pts + frame_off) : (b.pts + b.frames[f].in_offset);
     const uint32_t *fwin = b.winner + frame_off;
@@ -740,7 +768,7 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
     uint32_t full = 0u; /* bit (row mod 3): the row's slot holds a point */
 
     /* ---- in place ---- */
-    const uint32_t T = kInPlace ? b.info[f].T : 0u;
+    const uint32_t T = kIndexed ? b.info[f].T : 0u;
     const bool last_strip = strip == strips - 1;
     const int first_col = strip * kStripCols - 2; /* virtual column of offset 0 */
     const int own_cols = (H - first_col - 2) < kStripCols ? (H - first_col - 2) : kStripCols; /* own columns of this strip */
@@ -850,8 +878,70 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
         failed |= (dneed && !(slot_or_max(dq - 1, rcp) < dflat)) ? 1u : 0u;
     };
 
+    /* ---- column-major ---- */
+    const int cm_firing = strip * kStripCols - kColLead + tid;     /* this thread's firing */
+    const bool cm_valid = (unsigned)cm_firing < (unsigned)H;
+    const bool cm_own = (unsigned)(cm_firing - strip * kStripCols) < (unsigned)own_cols; /* counted by this strip */
+    auto cm_buf = [&](int band) -> uint32_t { return (uint32_t)(band & 1) * (uint32_t)kColBuf; };
+    /* rows 2 * band, 2 * band + 1 of this thread's firing: four 16-byte pieces of one 64-byte sector -> piece j at
+     * buffer + j * 4 KiB + thread * 16; wave 1 of strip 0: the same rows LESS ONE of the last kSideFirings firings
+     * (slots (r - 1, H - 2), (r - 1, H - 1) are strip 0's virtual columns -2, -1 of row r); wave 2 of the last strip:
+     * the rows of the first kSideFirings firings (columns 0, 1 as H, H + 1); lane = firing * 4 + piece */
+    auto issue_band = [&](int band) {
+        const int r0 = band * kBandRows;
+        if (r0 >= N) return; /* (uniform) */
+        const uint32_t at = ring_l + cm_buf(band) + (uint32_t)wv * 1024u;
+        const char *src = fbytes + ((size_t)(cm_valid ? cm_firing : 0) * N + r0) * 32u;
+        /* (N odd or a last band of one row: the second row's pieces come from the next firing or past the frame's end —
+         * never used; past the END of the input they would be out of bounds: clamp) */
+        const bool two = r0 + 1 < N;
+        glds16x2(src, at, src + 16, at + 4096u);
+        glds16x2(src + (two ? 32 : 0), at + 8192u, src + (two ? 48 : 16), at + 12288u);
+        if ((strip == 0 && wv == 1) || (last_strip && wv == 2)) {
+            const bool flat = wv == 1;
+            const int i = lane >> 2, piece = lane & 3;
+            const int fr = flat ? H - kSideFirings + i : i;
+            int row = r0 + (piece >> 1) - (flat ? 1 : 0);
+            const bool ok = (unsigned)fr < (unsigned)H && (unsigned)row < (unsigned)N;
+            glds16(fbytes + ((size_t)(ok ? fr : 0) * N + (ok ? row : 0)) * 32u + 16 * (piece & 1),
+                   ring_l + cm_buf(band) + (uint32_t)kBandBytes + (flat ? 0u : (uint32_t)kSideBytes));
+        }
+    };
+    /* Row rho's records -> idx[rho & 1]; every record this thread holds is CHECKED: beam = position mod N, column =
+     * firing + 0 .. kColMaxDisp or out of range (dropped by the scatter, BatchMultiBevGen.cpp:109-111).  Later firings
+     * are later in the input: the larger key wins, as the reference's last writer does (:112-115). */
+    auto index_row_cm = [&](int rho) {
+        if (rho >= N) return;
+        uint32_t *irow = idx[rho & 1];
+        const char *buf = &ring[cm_buf(rho / kBandRows)];
+        {
+            const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + ((rho & 1) * 2 + 1) * 4096 + tid * 16 + 4);
+            const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
+            const bool good = (row == (uint32_t)rho) & ((col >= (uint32_t)H) | ((col - (uint32_t)cm_firing) <= (uint32_t)kColMaxDisp));
+            failed |= (cm_valid & !good) ? 1u : 0u;
+            consumed += (cm_valid & cm_own) ? 1u : 0u;
+            const uint32_t off = col - (uint32_t)first_col;
+            atomicMax(&irow[(cm_valid & (col < (uint32_t)H) & (off < (uint32_t)row_span)) ? off : (uint32_t)kStripThreads], (uint32_t)tid + 1u);
+        }
+        if ((strip == 0 && wv == 1) || (last_strip && wv == 2)) { /* wave-uniform */
+            const bool flat = wv == 1;
+            const int i = lane & (kSideFirings - 1);
+            const int fr = flat ? H - kSideFirings + i : i;
+            const int want_row = flat ? rho - 1 : rho;
+            const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + kBandBytes + (flat ? 0 : kSideBytes) + i * 64 + (rho & 1) * 32 + 20);
+            const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
+            /* flat: columns H - 2, H - 1 of row rho - 1 at offsets 0, 1; wrap: columns 0, 1 of row rho at H - first_col + 0, 1 */
+            const uint32_t off = flat ? col - (uint32_t)(H - 2) : (uint32_t)(H - first_col) + col;
+            const bool ok = (lane < kSideFirings) & ((unsigned)fr < (unsigned)H) & (want_row >= 0) & (row == (uint32_t)want_row) &
+                            (flat ? (col < (uint32_t)H) & (off < 2u) : (col < 2u));
+            atomicMax(&irow[ok ? off : (uint32_t)kStripThreads], (uint32_t)(kStripThreads + (flat ? 0 : kSideFirings) + i) + 1u);
+        }
+    };
+
     /* ---- prologue: the queue the row loop expects ---- */
-    if constexpr (kInPlace) {
+    if constexpr (kColMajor) {
+        issue_band(0);
+    } else if constexpr (kInPlace) {
         if (wv == 3) {
             issue_tail_list(0, 0);
             issue_tail_list(1, 1);
@@ -946,7 +1036,14 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
         PHA(7);
         /* Everything but the newest step's loads has arrived: the points (window) of row r, the winner words (tail list)
          * of row r + 2.  A wave waits for as many operations as it issues loads per step. */
-        if constexpr (kInPlace) {
+        if constexpr (kColMajor) {
+            /* a band's loads are the newest operations but the stores since: they have arrived when nothing is outstanding
+             * (the stores of the step before are a step old, as for the other sources) */
+            if ((r % kBandRows) == 0) wait_vm<0>();
+            PHA(0);
+            index_row_cm(r);
+            PHA(1);
+        } else if constexpr (kInPlace) {
             if (wv == 3) wait_vm<5>();                    /* 2 window pieces, 1 list, 2 tail pieces */
             else if (last_strip && wv == 2) wait_vm<3>(); /* 2 window pieces, the wrap-around positions */
             else wait_vm<2>();
@@ -986,7 +1083,7 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
          * barrier.  In place: the point of row r is known only after the barrier (it makes the index row visible), so
          * both are published at the END of the previous step instead (measured on the gather source, that order costs
          * 7 %: a wave reaches the barrier straight from its memory wait). */
-        if constexpr (!kInPlace) {
+        if constexpr (!kIndexed) {
             if (lane < 2 || lane >= 62)
                 edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(__uint_as_float(cur_lo.x), __uint_as_float(cur_lo.y), __uint_as_float(cur_lo.z), __uint_as_float(cur_hi.x));
             const bool c2 = outcol && wr_gflag(p2.fl) == 1;
@@ -998,7 +1095,19 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
         }
         lds_barrier();
         PHA(2);
-        if constexpr (kInPlace) {
+        if constexpr (kColMajor) {
+            /* the column's owner follows its index entry to a firing of the band, or of a side window */
+            const uint32_t e = idx[par][tid];
+            idx[par][tid] = 0u;
+            const char *buf = &ring[cm_buf(r / kBandRows)];
+            const uint32_t k = e - 1u; /* thread of the window, or kStripThreads + side firing */
+            const bool main = k < (uint32_t)kStripThreads;
+            const uint32_t lo_at = main ? (uint32_t)((r & 1) * 2) * 4096u + k * 16u
+                                        : (uint32_t)kBandBytes + (k - (uint32_t)kStripThreads) * 64u + (uint32_t)(r & 1) * 32u;
+            const bool have = (e != 0u) & (r < N);
+            cur_lo = *(have ? reinterpret_cast<const u32x4 *>(buf + lo_at) : &zero16[0]);
+            cur_hi = *(have ? reinterpret_cast<const u32x4 *>(buf + lo_at + (main ? 4096u : 16u)) : &zero16[0]);
+        } else if constexpr (kInPlace) {
             /* the column's owner follows its index entry: a window / wrap-around position, or a tail point; an entry
              * whose (row, col) is not the slot's own is an empty slot (value-initialised, BatchMultiBevGen.cpp:98) */
             if (lane == 0) deferred_check(&ring[s0 * kSlotBytes]);
@@ -1075,7 +1184,7 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
                 u32x4 hi = p2.hi;
                 const bool as_ground = cand2 && !((p2.fl >> 4) & 1u);
                 if (as_ground) hi.w &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
-                char *xb = &ring[(kInPlace ? s2 : s0) * kSlotBytes];
+                char *xb = &ring[kColMajor ? 2 * kColBuf : (kInPlace ? s2 : s0) * kSlotBytes];
                 *reinterpret_cast<u32x4 *>(xb + xp_wlo) = p2.lo;
                 *reinterpret_cast<u32x4 *>(xb + xp_whi) = hi;
                 const u32x4 pa = *reinterpret_cast<const u32x4 *>(xb + xp_r0);
@@ -1097,7 +1206,10 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
         /* ---- the loads of this step, behind its stores: row r + 2 (and the winner words / tail list of row r + 4) ---- */
         PHA(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave is done reading the pieces it refills */
-        if constexpr (kInPlace) {
+        if constexpr (kColMajor) {
+            /* every wave has passed this step's barrier: nobody reads the band before this one any more */
+            if ((r % kBandRows) == 0) issue_band(r / kBandRows + 1);
+        } else if constexpr (kInPlace) {
             issue_window(r + 2, s2);
             if (last_strip && wv == 2) issue_wrap(r + 2, s2);
             if (wv == 3) {
@@ -1178,7 +1290,7 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
         p0.code = code_t<kPow2>(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w & 0xffffu), rp);
 
         /* ---- in place: published for the next step: row r's edge lanes, the candidates of row r-1 per wave ---- */
-        if constexpr (kInPlace) {
+        if constexpr (kIndexed) {
             if (lane < 2 || lane >= 62) edge[r % 3][wv][lane < 2 ? lane : lane - 60] = make_float4(cur.x, cur.y, cur.z, cur.i);
             const uint32_t q1 = p1.key & 3u;
             uint32_t rank1;
@@ -1207,7 +1319,7 @@ __global__ __launch_bounds__(kStripThreads, BEV_WALK_WAVES) BEV_WALK_OCC void k_
 #endif
     lds_barrier();
     if (tid < bands) b.ncode[((size_t)f * g.emitters + strip) * bands + tid] = band_cursor[tid];
-    if constexpr (kInPlace || kStructured) {
+    if constexpr (kIndexed || kStructured) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             consumed += __shfl_xor(consumed, d);
@@ -2132,6 +2244,7 @@ void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int sou
     if (source == kSrcIdentity) launch_walk<kSrcIdentity>(g, b, nf, mode, grid, st);
     else if (source == kSrcInPlace) launch_walk<kSrcInPlace>(g, b, nf, mode, grid, st);
     else if (source == kSrcStructured) launch_walk<kSrcStructured>(g, b, nf, mode, grid, st);
+    else if (source == kSrcColMajor) launch_walk<kSrcColMajor>(g, b, nf, mode, grid, st);
     else launch_walk<kSrcGather>(g, b, nf, mode, grid, st);
 }
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st)

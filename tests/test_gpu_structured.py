@@ -12,7 +12,7 @@ import oracle_lib as orc
 from bev_amd import synth
 
 pytestmark = pytest.mark.gpu
-STRUCTURED, REDO, GENERAL, STREAM = 3, 2, 0, 1
+STRUCTURED, REDO, GENERAL, STREAM, COLMAJOR = 3, 2, 0, 1, 4
 
 
 def _run(p, frames, max_batch=16):
@@ -101,7 +101,7 @@ def test_structured_sorted_and_unordered_frames_in_one_sub_batch():
               synth.structured(p, 43, 1.0), np.empty(0, bev_amd.POINT_DTYPE), synth.sweep(p, 44, keep=1.0, n_dup=0)]
     modes, info = _run(p, frames)
     # (a full sorted sweep without appended points IS a structured cloud; firing order has S points too but is not one)
-    assert modes == [STRUCTURED, STREAM, GENERAL, STRUCTURED, GENERAL, STRUCTURED], info
+    assert modes == [STRUCTURED, STREAM, COLMAJOR, STRUCTURED, GENERAL, STRUCTURED], info
 
 
 def test_the_kitti_projection_feeds_the_structured_route():
