@@ -45,7 +45,7 @@ struct Lane {
     hipEvent_t done = nullptr;
     hipEvent_t front_done = nullptr, back_done = nullptr; /* staged mode: workspace hand-over between the two stages */
     FrameInfo *info = nullptr;  /* per frame: how its points reach their slots (k_probe / k_verdict) */
-    uint32_t *hint = nullptr;   /* mapped host word: frames of the set's last sub-batch that were NOT read in place (k_verdict) */
+    uint32_t *hint = nullptr;   /* mapped host words (k_verdict): [0] frames of the set's last sub-batch that were NOT read in place, [1] the modes k_probe gave its frames (bit = mode) */
     uint32_t *est = nullptr;    /* stream frames: estimated input position of every (row, strip)'s first slot */
     uint32_t *tail_list = nullptr, *tail_cnt = nullptr; /* ... and their tail points per (row, strip) (stream mode only) */
     uint32_t *winner = nullptr;
@@ -485,15 +485,21 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                 ProfScope ps(c, K_PROBE, nb, st);
                 launch_probe(g, b, nb, c->allow_stream, st);
             }
-            if (c->allow_stream && ln.tail_list) { /* frames k_probe found sorted up to a tail: read in place, verified */
+            /* The walks of the modes that read in place.  Which of them are launched follows the modes k_probe gave the
+             * frames of this workspace set's last finished sub-batch (a word k_verdict leaves in mapped host memory, read
+             * without waiting; everything while nothing is known): an empty launch costs 5-8 us of a 1 ms sub-batch.  A
+             * frame whose walk was not launched fails k_verdict's count and is redone the general way — the hint decides
+             * speed, not results — and the next sub-batch of the set sees its mode in the word. */
+            const uint32_t seen = c->allow_stream && ln.hint ? reinterpret_cast<volatile uint32_t *>(ln.hint)[1] : 0u;
+            if (c->allow_stream && ln.tail_list && (seen & (1u << kFrameStream))) { /* frames k_probe found sorted up to a tail: read in place, verified */
                 ProfScope ps(c, K_GATHER_GROUND, nb, st);
                 launch_gather_ground(g, b, nb, 2, kFrameStream, st);
             }
-            if (c->allow_stream && n_exact_s > 0) { /* structured clouds (only a frame of exactly S records can be one) */
+            if (c->allow_stream && n_exact_s > 0 && (seen & (1u << kFrameStructured))) { /* structured clouds (only a frame of exactly S records can be one) */
                 ProfScope ps(c, K_WALK_STRUCTURED, nb, st);
                 launch_gather_ground(g, b, nb, 3, kFrameStructured, st);
             }
-            if (c->allow_stream && n_exact_s > 0) { /* ... or S returns in firing order */
+            if (c->allow_stream && n_exact_s > 0 && (seen & (1u << kFrameColMajor))) { /* ... or S returns in firing order */
                 ProfScope ps(c, K_WALK_COLMAJOR, nb, st);
                 launch_gather_ground(g, b, nb, 4, kFrameColMajor, st);
             }
@@ -737,8 +743,9 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ln.front_done, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&ln.back_done, hipEventDisableTiming));
-        CK(hipHostMalloc((void **)&ln.hint, sizeof(uint32_t), hipHostMallocMapped));
-        *ln.hint = 0xffffffffu; /* nothing known yet: the set's first order scan is launched wide */
+        CK(hipHostMalloc((void **)&ln.hint, 2 * sizeof(uint32_t), hipHostMallocMapped));
+        ln.hint[0] = 0xffffffffu; /* nothing known yet: the set's first order scan is launched wide, */
+        ln.hint[1] = 0xffffffffu; /* ... every walk is launched */
         CK(hipMalloc((void **)&ln.info, nb * sizeof(FrameInfo)));
         CK(hipMemset(ln.info, 0, nb * sizeof(FrameInfo)));
         CK(hipMalloc((void **)&ln.est, nb * (size_t)c->geo.N * c->geo.strips * sizeof(uint32_t)));

@@ -340,14 +340,18 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
 /* ... and the host is told, without being waited for, how many frames of the sub-batch are NOT read in place (a word in
  * mapped host memory): the next sub-batches' order scan is launched thin or wide by it — a hint about speed, the thin
  * and the wide launch compute the same */
+/* host_hint[1]: which modes k_probe gave the sub-batch's frames (bit = mode).  The host launches the walk of a mode only
+ * while the workspace set's last sub-batches had frames of it — a frame whose walk was not launched fails the count
+ * below and is redone the general way, so a stale hint costs time, never results. */
 __global__ __launch_bounds__(1024) void k_verdict(FrameInfo *info, int nf, uint32_t *host_hint)
 {
-    __shared__ uint32_t others;
-    if (threadIdx.x == 0) others = 0u;
+    __shared__ uint32_t others, modes;
+    if (threadIdx.x == 0) others = modes = 0u;
     __syncthreads();
-    uint32_t mine = 0u;
+    uint32_t mine = 0u, mask = 0u;
     for (int f = threadIdx.x; f < nf; f += 1024) {
         FrameInfo fi = info[f];
+        mask |= 1u << (fi.mode & 31u);
         const bool bad_stream = (fi.mode == kFrameStream || fi.mode == kFrameColMajor) && (fi.failed != 0u || fi.consumed != fi.T);
         /* structured: every record checked, none bad, and the guess about all-zero records (it decided slot 0) was right */
         const bool bad_struct = fi.mode == kFrameStructured &&
@@ -360,8 +364,12 @@ __global__ __launch_bounds__(1024) void k_verdict(FrameInfo *info, int nf, uint3
         mine += frame_read_in_place(fi.mode) ? 0u : 1u;
     }
     if (mine) atomicAdd(&others, mine);
+    if (mask) atomicOr(&modes, mask);
     __syncthreads();
-    if (threadIdx.x == 0 && host_hint) __hip_atomic_store(host_hint, others, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0 && host_hint) {
+        __hip_atomic_store(host_hint, others, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_hint + 1, modes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 /* ------------------------------------------------------------------------- */

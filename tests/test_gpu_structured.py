@@ -137,3 +137,27 @@ def test_knob_off_and_sensors_the_in_place_source_cannot_take():
     p.n_scan, p.horizon_scan, p.ground_upper_scan = 96, 700, 60
     modes, _ = _run(p, [synth.structured(p, 51, 0.9), synth.sweep(p, 52, n_dup=100)])
     assert modes == [STRUCTURED, GENERAL]
+
+
+def test_a_walk_that_was_not_launched_costs_time_not_results():
+    """The host launches the walk of a mode only while the workspace set's last sub-batch had frames of that mode (a hint
+    k_verdict leaves in mapped host memory).  A structured cloud that arrives after sweeps finds its walk not launched:
+    its count fails, it is redone the general way (mode 2) — same outputs — and the next call sees the mode again."""
+    p = bev_amd.params_for_sensor("HDL_32E")
+    sp = orc.sensor_from_params(p)
+    calls = [[synth.sweep(p, 60 + i, n_dup=300) for i in range(3)], [synth.structured(p, 63 + i, 0.9) for i in range(3)],
+             [synth.structured(p, 66 + i, 0.9) for i in range(3)], [synth.firing_order(p, 70), synth.structured(p, 71, 0.9)],
+             [synth.firing_order(p, 72), synth.sweep(p, 73, n_dup=300)]]
+    want_modes = [[STREAM] * 3, [REDO] * 3, [STRUCTURED] * 3, [REDO, STRUCTURED], [COLMAJOR, REDO]]
+    ctx = bev_amd.BevContext(p, device=0, max_batch=16, max_points=max(len(f) for c in calls for f in c))
+    try:
+        for frames, want in zip(calls, want_modes):
+            ordered, multi, single, gm = ctx.process_batch(frames, want_ground_mat=True)
+            modes = [int(m) for m in ctx.frame_info(0, len(frames))[:, 1]]
+            for i, pts in enumerate(frames):
+                o_ord, o_gm, o_multi, o_single = orc.process_frame(sp, pts)
+                assert ordered[i].tobytes() == o_ord.tobytes() and np.array_equal(gm[i], o_gm), (want, i)
+                assert np.array_equal(multi[i], o_multi) and np.array_equal(single[i], o_single), (want, i)
+            assert modes == want, (modes, want)
+    finally:
+        ctx.close()
