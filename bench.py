@@ -260,18 +260,22 @@ def main() -> int:
         # PMC counters cannot be read from inside the process: they come from the committed rocprofv3 --pmc passes of
         # THIS command line (scripts/profile_round.sh; 1000 frames, sub-batch 256), per frame, scaled to this launch.
         traffic, traffic_src, traffic_total = None, None, None
-        if args.workload == "hdl64_sweep":
-            for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
-                pmc_file = REPO / "profiles" / name
-                if not pmc_file.exists():
-                    continue
-                pmc = json.loads(pmc_file.read_text())
-                for kname, kv in pmc["kernels"].items():
-                    if kname.split("<")[0] == dom["name"].replace("_general", "") and kv.get("hbm_bytes_per_frame", 0) > 1e5:  # (the instantiation that moved the frames, not the empty launch)
-                        traffic = kv["hbm_bytes_per_frame"] * per_launch_frames
-                        traffic_src = f"profiles/{name}: {pmc.get('source', 'rocprofv3 --pmc')}"
-                traffic_total = pmc.get("hbm_bytes_per_frame_all_kernels")
-                break
+        # which instantiation of the walk a profile id is (rocprofv3 names kernels by their template arguments)
+        pmc_prefix = {"k_walk": "k_walk<2,", "k_walk_general": "k_walk<0,", "k_walk_structured": "k_walk<3,",
+                      "k_walk_colmajor": "k_walk<4,"}.get(dom["name"], dom["name"])
+        tag = "" if args.workload == "hdl64_sweep" else args.workload + "_"
+        rounds = ("r04",) if args.workload != "hdl64_sweep" else ("r04", "r03", "r02")
+        for name in (f"{r}_{tag}pmc_traffic.json" for r in rounds):
+            pmc_file = REPO / "profiles" / name
+            if not pmc_file.exists():
+                continue
+            pmc = json.loads(pmc_file.read_text())
+            for kname, kv in pmc["kernels"].items():
+                if kname.startswith(pmc_prefix) and kv.get("hbm_bytes_per_frame", 0) > 1e5:  # (the instantiation that moved the frames, not an empty launch)
+                    traffic = kv["hbm_bytes_per_frame"] * per_launch_frames
+                    traffic_src = f"profiles/{name}: {pmc.get('source', 'rocprofv3 --pmc')}"
+            traffic_total = pmc.get("hbm_bytes_per_frame_all_kernels")
+            break
         # whole hot path against the wall clock of the timed region (this rank): B_frame * frames / time
         pipe_achieved = b_frame * (count * args.steps) / elapsed / 1e9
         frames_per_s = count * args.steps / elapsed

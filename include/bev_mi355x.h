@@ -242,6 +242,10 @@ int bev_debug_get_cell_avg(bev_ctx_t *ctx, int first_frame, int n_frames, float 
  * verification failed, done again the general way.  Results never depend on the mode (reading in place is the default for
  * frames that qualify; BEV_STREAM=0 in the environment of bev_create turns it off). */
 int bev_debug_get_frame_info(bev_ctx_t *ctx, int first_frame, int n_frames, uint32_t *out);
+/* Test hook: out[i] = how many raster-band code lists of frame first_frame + i of the LAST sub-batch did not hold their
+ * codes (those bands of the frame's images were computed from the ordered cloud instead; normally 0; BEV_CODE_CAP in the
+ * environment of bev_create shrinks the lists). */
+int bev_debug_get_code_overflow(bev_ctx_t *ctx, int first_frame, int n_frames, uint32_t *out);
 /* Evaluates the phase-A angle predicate (BatchMultiBevGen.cpp:169-179) on the
  * device for n (dx,dy,dz) triples given as HOST arrays; out[i] = 1 if GROUND. */
 int bev_debug_angle_predicate(bev_ctx_t *ctx, const float *dx, const float *dy,

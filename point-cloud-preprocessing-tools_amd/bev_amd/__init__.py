@@ -75,7 +75,7 @@ ABI_SYMBOLS = [
     "bev_order_cloud", "bev_mark_ground", "bev_multi_bev", "bev_single_bev",
     "bev_float_bev", "bev_float_bev_size", "bev_transform_cloud", "bev_yaw_translate_matrix", "bev_project_xyzi", "bev_project_out_points", "bev_host_alloc", "bev_host_free",
     "bev_set_lanes", "bev_profile_enable", "bev_profile_reset", "bev_profile_get",
-    "bev_debug_get_cell_avg", "bev_debug_get_frame_info", "bev_debug_angle_predicate", "bev_abi_version",
+    "bev_debug_get_cell_avg", "bev_debug_get_frame_info", "bev_debug_get_code_overflow", "bev_debug_angle_predicate", "bev_abi_version",
 ]
 
 
@@ -140,6 +140,8 @@ def load_lib() -> C.CDLL:
     lib.bev_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32]
     lib.bev_debug_get_cell_avg.argtypes = [vp, i32, i32, vp]
     lib.bev_debug_get_frame_info.argtypes = [vp, i32, i32, vp]
+    if hasattr(lib, "bev_debug_get_code_overflow"):  # (absent from older builds selected through BEV_AMD_LIB for A/B runs)
+        lib.bev_debug_get_code_overflow.argtypes = [vp, i32, i32, vp]
     lib.bev_debug_angle_predicate.argtypes = [vp, vp, vp, vp, vp, sz]
     lib.bev_abi_version.restype = i32
     _lib = lib
@@ -313,6 +315,12 @@ class BevContext:
         of the last sub-batch."""
         out = np.empty((n_frames, 4), dtype=np.uint32)
         self._check(self.lib.bev_debug_get_frame_info(self._h, first_frame, n_frames, _ptr(out)), "bev_debug_get_frame_info")
+        return out
+
+    def code_overflow(self, first_frame=0, n_frames=1):
+        """(n,) uint32: BEV codes of each frame of the last sub-batch that went through the overflow list"""
+        out = np.empty(n_frames, dtype=np.uint32)
+        self._check(self.lib.bev_debug_get_code_overflow(self._h, first_frame, n_frames, _ptr(out)), "bev_debug_get_code_overflow")
         return out
 
     def angle_predicate(self, dx, dy, dz):

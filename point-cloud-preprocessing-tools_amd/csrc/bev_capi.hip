@@ -145,6 +145,7 @@ struct bev_ctx {
     uint32_t *codes = nullptr;
     size_t codes_elems = 0;
     float *last_avg = nullptr;
+    uint32_t *last_ncode = nullptr;
     FrameInfo *last_info = nullptr;
 
     /* frame descriptors: ring of pinned host + device arrays */
@@ -292,7 +293,14 @@ void fill_geometry(const bev_params_t *p, Geometry *g)
         g->raster_bands = g->rp.bands;
     }
     g->emitters = g->strips + kResolveParts;
-    g->code_cap = std::max((uint32_t)g->N * (uint32_t)kStripCols, (uint32_t)((g->segs + kResolveParts - 1) / kResolveParts + 1) * (uint32_t)kSeg);
+    {   /* worst case: every slot of a strip / every candidate of a resolve part in one band; normally far fewer (kCodeListCap) */
+        const uint32_t worst = std::max((uint32_t)g->N * (uint32_t)kStripCols, (uint32_t)((g->segs + kResolveParts - 1) / kResolveParts + 1) * (uint32_t)kSeg);
+        uint32_t cap = (uint32_t)kCodeListCap;
+        if (const char *e = getenv("BEV_CODE_CAP")) cap = (uint32_t)std::max(1, atoi(e));
+        g->code_cap = std::min(worst, cap);
+        const uint32_t pieces = (g->code_cap + 63u) / 64u; /* 256-byte pieces */
+        g->code_stride = (pieces | 1u) * 64u;
+    }
     g->rp.max_range_f = (float)p->max_range;
     g->rp.interval = p->interval;
     g->rp.height_res = p->height_res;
@@ -547,7 +555,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             bc.cand = b.cand + (size_t)c0 * g.segs * kSeg;
             bc.ncand = b.ncand + (size_t)c0 * g.segs;
             bc.avg = b.avg + (size_t)c0 * bevx::kGridCells;
-            bc.code_main = b.code_main + (size_t)c0 * g.emitters * g.raster_bands * g.code_cap;
+            bc.code_main = b.code_main + (size_t)c0 * g.emitters * g.raster_bands * g.code_stride;
             bc.ncode = b.ncode + (size_t)c0 * g.emitters * g.raster_bands;
             bc.ordered = b.ordered + (size_t)c0 * S;
             bc.gm = b.gm ? b.gm + (size_t)c0 * S : nullptr;
@@ -573,6 +581,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         HIPCK(c, hipEventRecord(ln.back_done, st));
         c->last_sub_frames = nb;
         c->last_avg = ln.avg;
+        c->last_ncode = ln.ncode;
         c->last_info = identity ? nullptr : ln.info;
         HIPCK(c, hipGetLastError());
     }
@@ -758,7 +767,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         /* (+ one segment of slack: whole 64-slices are read past a short segment's count) */
         CK(hipMalloc((void **)&ln.cand, (nb * (size_t)c->geo.segs + 1) * kSeg * sizeof(uint2)));
         CK(hipMalloc((void **)&ln.ncand, nb * (size_t)c->geo.segs * sizeof(uint32_t)));
-        CK(hipMalloc((void **)&ln.code_main, nb * (size_t)c->geo.emitters * c->geo.raster_bands * c->geo.code_cap * sizeof(uint32_t)));
+        CK(hipMalloc((void **)&ln.code_main, nb * (size_t)c->geo.emitters * c->geo.raster_bands * c->geo.code_stride * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.ncode, nb * (size_t)c->geo.emitters * c->geo.raster_bands * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.avg, nb * (size_t)bevx::kGridCells * sizeof(float)));
     }
@@ -1229,6 +1238,22 @@ int bev_debug_get_frame_info(bev_ctx_t *c, int first_frame, int n_frames, uint32
     HIPCK(c, hipSetDevice(c->device));
     HIPCK(c, hipStreamSynchronize(c->stream));
     HIPCK(c, hipMemcpy(out, c->last_info + first_frame, (size_t)n_frames * sizeof(FrameInfo), hipMemcpyDeviceToHost));
+    return BEV_OK;
+}
+
+int bev_debug_get_code_overflow(bev_ctx_t *c, int first_frame, int n_frames, uint32_t *out)
+{
+    if (!c || !out || first_frame < 0 || n_frames < 0 || first_frame + n_frames > c->last_sub_frames || !c->last_ncode)
+        return BEV_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    const size_t per = (size_t)c->geo.emitters * c->geo.raster_bands;
+    std::vector<uint32_t> counts((size_t)n_frames * per);
+    HIPCK(c, hipMemcpy(counts.data(), c->last_ncode + (size_t)first_frame * per, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int f = 0; f < n_frames; ++f) {
+        out[f] = 0u;
+        for (size_t k = 0; k < per; ++k) out[f] += counts[(size_t)f * per + k] > c->geo.code_cap ? 1u : 0u;
+    }
     return BEV_OK;
 }
 

@@ -46,6 +46,13 @@ constexpr int kRasterThreads = BEV_RASTER_THREADS;
 constexpr int kRasterSplit = 8;   /* x-bands per frame in the raster kernel at the reference's 224 x 224 (see raster_bands_for) */
 constexpr int kMaxBands = 32;     /* coarse + fine raster bands (see RasterParams) */
 constexpr int kMaxStrips = 280;   /* ceil(65535 / kStripCols) rounded up */
+/* Entries of one (emitter, band) code list.  A benchmark frame's fullest list holds well under 2,000 codes of the 15,104
+ * slots a strip has (the walk drops repeats of a code before they are listed); sized for the worst case the lists were
+ * 21.6 MB per frame and workspace set, now 1.5 MB.  A writer whose list is full keeps counting and overwrites the list's
+ * last entry; k_bev_raster sees the count and computes that band of the frame from the ordered cloud instead (it reads
+ * all S slots: slow, correct, and only for clouds piled up in one band).  BEV_CODE_CAP (environment of bev_create)
+ * overrides the size: the tests run with tiny lists. */
+constexpr int kCodeListCap = 2048;
 
 /* per-frame launch metadata, copied H2D once per sub-batch */
 struct FrameDesc {
@@ -98,7 +105,7 @@ constexpr int kStreamMaxRows = 64;   /* sensors with more rows go the general wa
  *   cand uint2 (key | height)  [nf][segs][kSeg]   candidates, one segment per (row, strip), compacted in column order;
  *                                                  segments in row-major order => concatenation = slot order
  *   ncand u32                  [nf][segs]
- *   code_main u32              [nf][emitters][bands][code_cap]   BEV codes of the slots that are NOT candidates
+ *   code_main u32              [nf][emitters][bands][code_stride]   BEV codes of the slots that are NOT candidates
  *                                                  (final when the walk writes them), one list per raster band, appended
  *                                                  row by row by the strip's workgroup (no atomics)
  *   ncode u32                  [nf][emitters][bands]
@@ -114,7 +121,12 @@ struct Geometry {
     int parts;         /* ceil(segs / kPartSegs): parts k_cell_sums works through, in slot order */
     int raster_bands;  /* x-bands per frame in the raster kernel (= rp.bands: coarse ones outside, fine ones in the middle) */
     int emitters;      /* strips + kResolveParts: writers of code lists per frame (the walk's strips, the resolve's parts) */
-    uint32_t code_cap; /* capacity of one (emitter, band) code list: max(N * kStripCols, candidates of a resolve part) */
+    uint32_t code_cap; /* capacity of one (emitter, band) code list: kCodeListCap, or the worst case (every slot of a strip /
+                        * every candidate of a resolve part in one band) where that is smaller; a raster band with a list
+                        * that does not hold its codes is computed from the ordered cloud instead */
+    uint32_t code_stride; /* words from one (emitter, band) list to the next: code_cap padded to an ODD number of 256-byte pieces —
+                           * lists that start a power of two apart put every writer's appends on the same few memory channels
+                           * (measured: -3 % frames/s with 8-KiB strides) */
     bevx::RasterParams rp;
 };
 
@@ -132,8 +144,8 @@ struct BatchPtrs {
     bev_point_t *ordered;        /* [nf][S] */
     uint2 *cand;                 /* [nf][segs][kSeg]: candidate key (bev_exact.h) | height */
     uint32_t *ncand;             /* [nf][segs] */
-    uint32_t *code_main;         /* [nf][emitters][bands][code_cap] */
-    uint32_t *ncode;             /* [nf][emitters][bands] */
+    uint32_t *code_main;         /* [nf][emitters][bands][code_stride] */
+    uint32_t *ncode;             /* [nf][emitters][bands]: codes the writer had for the list (more than code_cap: the list is incomplete) */
     float *avg;                  /* [nf][3750] */
     int8_t *gm;                  /* [nf][S] or nullptr: phase-A ground_mat */
     uint8_t *multi;              /* [nf][L*M*M] */

@@ -996,8 +996,8 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
     const size_t cand_base = (size_t)f * g.segs * kSeg;
     const gptr<u32x2> fcand = (gptr<u32x2>)(b.cand + cand_base);
     const gptr<uint32_t> fncand = (gptr<uint32_t>)(b.ncand + (size_t)f * g.segs);
-    const uint32_t code_cap = g.code_cap;
-    const gptr<uint32_t> flist = (gptr<uint32_t>)(b.code_main + ((size_t)f * g.emitters + strip) * bands * (size_t)code_cap);
+    const uint32_t code_last = in_vgpr(g.code_cap - 1u), code_stride = in_vgpr(g.code_stride); /* (they only feed vector instructions) */
+    const gptr<uint32_t> flist = (gptr<uint32_t>)(b.code_main + ((size_t)f * g.emitters + strip) * bands * (size_t)g.code_stride);
     const gptr<u32x4> fordered = (gptr<u32x4>)(b.ordered + frame_off);
     const gptr<int8_t> fgm = (gptr<int8_t>)(kGm ? b.gm + frame_off : nullptr);
     RasterParams rp = g.rp; /* the fields the BEV code needs, in vector registers */
@@ -1185,7 +1185,8 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
                 /* (one cursor atomic per wave and band instead of one per code — a ballot loop — measured 2 % slower) */
                 if (has) {
                     const uint32_t pos = atomicAdd(&band_cursor[band], 1u);
-                    flist[(uint32_t)band * code_cap + pos] = p2.code;
+                    /* (a full list keeps counting and overwrites its last entry: k_bev_raster sees the count) */
+                    flist[(uint32_t)band * code_stride + (pos < code_last ? pos : code_last)] = p2.code;
                 }
             }
             {   /* the ordered cloud, as whole lines */
@@ -1794,7 +1795,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
     }
   for (int part = part0; part < part0 + kPartsPerWg; ++part) { /* one code list set per part */
     const int t0 = (int)((long long)T * part / kResolveParts), t1 = (int)((long long)T * (part + 1) / kResolveParts);
-    const gptr<uint32_t> flist = (gptr<uint32_t>)(b.code_main + ((size_t)f * g.emitters + g.strips + part) * bands * (size_t)code_cap);
+    const gptr<uint32_t> flist = (gptr<uint32_t>)(b.code_main + ((size_t)f * g.emitters + g.strips + part) * bands * (size_t)g.code_stride);
     if (part != part0) lds_barrier(); /* the previous part's cursors have been written out, its counts read */
     for (int i = tid; i < t1 - t0; i += kResolveThreads) {
         const uint32_t w = b.ncand[(size_t)f * T + t0 + i]; /* four byte-wide counts: the segment's runs by cell quarter, back to back */
@@ -1849,7 +1850,8 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
                     }
                     if (code != kSkip) {
                         const int band = band_tab[code_x(code)];
-                        flist[(uint32_t)band * code_cap + atomicAdd(&band_cursor[band], 1u)] = code;
+                        const uint32_t pos = atomicAdd(&band_cursor[band], 1u);
+                        flist[(uint32_t)band * g.code_stride + (pos < code_cap ? pos : code_cap - 1u)] = code;
                     }
                 }
                 if (wrong) { /* the walk's provisional label differs */
@@ -1937,6 +1939,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t list_end[kMaxStrips + kResolveParts + 1]; /* inclusive prefix of this band's code-list lengths */
+    __shared__ uint32_t over_l;                                    /* a writer had more codes for this band than its list holds */
     const int M = g.rp.mat_size, L = g.rp.n_layers, bands = g.raster_bands, E = g.emitters;
     /* the bands of a frame on ONE XCD (blocks b and b+8 share an L2), adjacent launch slots */
     const int xl = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -1955,18 +1958,23 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
     if (tid < E) my_cnt = b.ncode[((size_t)f * E + tid) * bands + band];
     for (int k = tid; k < 2 * cells; k += kRasterThreads) lds[k] = 0u;
     if (tid < E) list_end[tid + 1] = my_cnt;
-    if (tid == 0) list_end[0] = 0u;
+    if (tid == 0) {
+        list_end[0] = 0u;
+        over_l = 0u;
+    }
     lds_barrier();
+    if (my_cnt > g.code_cap) over_l = 1u;
     if (tid == 0) /* few lists (13 for HDL_64E): a serial prefix */
         for (int e = 0; e < E; ++e) list_end[e + 1] += list_end[e];
     lds_barrier();
+    const uint32_t over = over_l;
     PH();
 
     /* this band's lists as ONE index space, so that every load of the workgroup is requested at once */
-    {
+    if (!over) {
         constexpr int kU = 8;
         const uint32_t total = list_end[E];
-        const uint32_t *fmain = b.code_main + (size_t)f * E * bands * g.code_cap;
+        const uint32_t *fmain = b.code_main + (size_t)f * E * bands * g.code_stride;
         uint32_t ends[16]; /* ends[j] = first index of list j (j >= 1) */
 #pragma unroll
         for (int j = 0; j < 16; ++j) ends[j] = __builtin_amdgcn_readfirstlane(j <= E ? list_end[j] : 0u);
@@ -1995,12 +2003,20 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
                         e = lo;
                         e0 = list_end[e];
                     }
-                    c[k] = fmain[((size_t)e * bands + band) * g.code_cap + (i - e0)];
+                    c[k] = fmain[((size_t)e * bands + band) * g.code_stride + (i - e0)];
                 }
             }
 #pragma unroll
             for (int k = 0; k < kU; ++k)
                 if (c[k] != kSkip) splat_code(c[k], x0, M, mask, hmax);
+        }
+    } else { /* (workgroup-uniform) the band's cells from the ordered, labelled cloud itself: every slot's code, as
+              * bev_multi_bev / bev_single_bev compute it for an arbitrary cloud */
+        const bev_point_t *cloud = b.ordered + (size_t)f * g.S;
+        for (int i = tid; i < g.S; i += kRasterThreads) {
+            const float4 a = *reinterpret_cast<const float4 *>(cloud + i);
+            const uint32_t c = bev_code(a.x, a.y, a.z, (int)reinterpret_cast<const int16_t *>(cloud + i)[14], g.rp);
+            if (c != kSkip && (uint32_t)(code_x(c) - x0) < (uint32_t)band_rows) splat_code(c, x0, M, mask, hmax);
         }
     }
     lds_barrier();

@@ -27,7 +27,7 @@ for name, out in (("bench_under_rocprof.log", "_bench_under_rocprof.json"), ("be
     if os.path.exists(p):
         json.dump(last_json_line(p), open(prefix + out, "w"), indent=1)
 
-for wl in ("os1_firing", "oxford_concat"):
+for wl in ("os1_firing", "oxford_concat", "hdl64_structured"):
     st = glob.glob(os.path.join(src, "trace_" + wl, "**", "*kernel_stats.csv"), recursive=True)
     if st:
         shutil.copy(st[0], f"{prefix}_{wl}_kernel_stats.csv")
@@ -36,50 +36,61 @@ for wl in ("os1_firing", "oxford_concat"):
         if os.path.exists(p):
             json.dump(last_json_line(p), open(prefix + out, "w"), indent=1)
 
-agg = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.defaultdict(lambda: collections.defaultdict(int))
-for f in glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bevk::", "")
-        if not k.startswith("k_") and "fillBuffer" not in k:
-            continue
-        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        cnt[k][r["Counter_Name"]] += 1
-out = {"source": "rocprofv3 --pmc (one counter group per run) of `bench.py --steps 1 --warmup 1` (the 1000-frame workload, "
-                 f"sub-batch 500, BEV_LANES=1): counters summed over all dispatches of a kernel / {pmc_frames} frame passes",
-       "frame_passes": pmc_frames,
-       "corrections": "FETCH_SIZE is reported in KiB and counts 128-B requests as 64 B on gfx950 (MI355X_MICROARCH.md, "
-                      "HBM): hbm_read_bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE KiB is exact",
-       "kernels": {}}
-total = 0.0
-for k in sorted(agg):
-    m = {c: agg[k][c] / cnt[k][c] for c in agg[k]}   # per-dispatch means
-    tot = {c: agg[k][c] for c in agg[k]}               # sums over the run
-    e = {"dispatches": max(cnt[k].values())}
-    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
-        e["hbm_read_bytes_per_launch"] = 2 * m["FETCH_SIZE"] * 1024
-        e["hbm_write_bytes_per_launch"] = m["WRITE_SIZE"] * 1024
-        e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
-        e["hbm_bytes_per_frame"] = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / pmc_frames
-        e["hbm_read_bytes_per_frame"] = 2 * tot["FETCH_SIZE"] * 1024 / pmc_frames
-        e["hbm_write_bytes_per_frame"] = tot["WRITE_SIZE"] * 1024 / pmc_frames
-        e["FETCH_SIZE_KiB_raw"], e["WRITE_SIZE_KiB"] = m["FETCH_SIZE"], m["WRITE_SIZE"]
-        if "fillBuffer" in k:
-            e["note"] = "one-time clear of a winner table at context creation, not part of a step"
-        else:
-            total += e["hbm_bytes_per_frame"]
-    if "TCC_EA0_RDREQ_sum" in m:
-        e["TCC_EA0_RDREQ"], e["TCC_EA0_WRREQ"] = m["TCC_EA0_RDREQ_sum"], m.get("TCC_EA0_WRREQ_sum")
-    if "TCC_HIT_sum" in m and m["TCC_HIT_sum"] + m.get("TCC_MISS_sum", 0) > 0:
-        e["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
-    if "SQ_WAIT_ANY" in m and m.get("SQ_WAVE_CYCLES"):
-        e["SQ_WAIT_ANY_over_WAVE_CYCLES"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
-    for a, b in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_INSTS_VMEM_RD", "vmem_rd_insts"), ("SQ_INSTS_VMEM_WR", "vmem_wr_insts"),
-                 ("SQ_INSTS_LDS", "lds_insts")):
-        if a in m:
-            e[b] = m[a]
-    out["kernels"][k] = e
-out["hbm_bytes_per_frame_all_kernels"] = total
-if agg:
-    json.dump(out, open(prefix + "_pmc_traffic.json", "w"), indent=1)
-print("wrote", sorted(glob.glob(prefix + "_*")), "total HBM bytes per frame:", round(total))
+def pmc_summary(dir_glob, out_path, frames, what):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(lambda: collections.defaultdict(int))
+    for f in glob.glob(os.path.join(src, dir_glob, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("bevk::", "")
+            if not k.startswith("k_") and "fillBuffer" not in k:
+                continue
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            cnt[k][r["Counter_Name"]] += 1
+    if not agg:
+        return
+    out = {"source": f"rocprofv3 --pmc (one counter group per run) of `{what}` (BEV_LANES=1): counters summed over all "
+                     f"dispatches of a kernel / {frames} frame passes",
+           "frame_passes": frames,
+           "corrections": "FETCH_SIZE is reported in KiB and counts 128-B requests as 64 B on gfx950 (MI355X_MICROARCH.md, "
+                          "HBM): hbm_read_bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE KiB is exact",
+           "kernels": {}}
+    total = 0.0
+    for k in sorted(agg):
+        m = {c: agg[k][c] / cnt[k][c] for c in agg[k]}   # per-dispatch means
+        tot = {c: agg[k][c] for c in agg[k]}               # sums over the run
+        e = {"dispatches": max(cnt[k].values())}
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            e["hbm_read_bytes_per_launch"] = 2 * m["FETCH_SIZE"] * 1024
+            e["hbm_write_bytes_per_launch"] = m["WRITE_SIZE"] * 1024
+            e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+            e["hbm_bytes_per_frame"] = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / frames
+            e["hbm_read_bytes_per_frame"] = 2 * tot["FETCH_SIZE"] * 1024 / frames
+            e["hbm_write_bytes_per_frame"] = tot["WRITE_SIZE"] * 1024 / frames
+            e["FETCH_SIZE_KiB_raw"], e["WRITE_SIZE_KiB"] = m["FETCH_SIZE"], m["WRITE_SIZE"]
+            if "fillBuffer" in k:
+                e["note"] = "one-time clear of a winner table at context creation, not part of a step"
+            else:
+                total += e["hbm_bytes_per_frame"]
+        if "TCC_EA0_RDREQ_sum" in m:
+            e["TCC_EA0_RDREQ"], e["TCC_EA0_WRREQ"] = m["TCC_EA0_RDREQ_sum"], m.get("TCC_EA0_WRREQ_sum")
+        if "TCC_HIT_sum" in m and m["TCC_HIT_sum"] + m.get("TCC_MISS_sum", 0) > 0:
+            e["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+        if "SQ_WAIT_ANY" in m and m.get("SQ_WAVE_CYCLES"):
+            e["SQ_WAIT_ANY_over_WAVE_CYCLES"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
+        for a, b in (("SQ_INSTS_VALU", "valu_insts"), ("SQ_INSTS_VMEM_RD", "vmem_rd_insts"), ("SQ_INSTS_VMEM_WR", "vmem_wr_insts"),
+                     ("SQ_INSTS_LDS", "lds_insts")):
+            if a in m:
+                e[b] = m[a]
+        out["kernels"][k] = e
+    out["hbm_bytes_per_frame_all_kernels"] = total
+    json.dump(out, open(out_path, "w"), indent=1)
+    print("wrote", out_path, "total HBM bytes per frame:", round(total))
+
+
+# bench.py --steps 1 --warmup 1 passes over its frames three times (warm-up, timed step, fenced step)
+pmc_summary("pmc[0-9]*", prefix + "_pmc_traffic.json", pmc_frames, "bench.py --steps 1 --warmup 1 (the 1000-frame workload, sub-batch 500)")
+pmc_summary("pmcgen[0-9]*", prefix + "_pmc_traffic_general.json", pmc_frames,
+            "BEV_STREAM=0 bench.py --steps 1 --warmup 1 (the 1000-frame workload through the GENERAL path: order scan + gather walk)")
+for wl in ("os1_firing", "hdl64_structured"):
+    pmc_summary(f"pmc_{wl}[0-9]*", f"{prefix}_{wl}_pmc_traffic.json", pmc_frames, f"bench.py --steps 1 --warmup 1 --workload {wl}")
+print("files:", sorted(glob.glob(prefix + "_*")))

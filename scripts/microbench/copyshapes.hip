@@ -147,8 +147,55 @@ __global__ __launch_bounds__(256) void k_walk_lines(const v4u* __restrict__ in, 
         }
     }
 }
-int main()
+// the walk's loop in BURSTS of kB rows: all loads of the next kB rows requested at once, then the kB rows before them stored
+// at once (does DRAM like a strip's consecutive rows — 66 KB apart: neighbouring 256-B pieces of the same pages — better
+// when they arrive together than one row per step?)
+template <int kB>
+__global__ __launch_bounds__(256) void k_walk_burst(const v4u* __restrict__ in, v4u* __restrict__ out, int nf, int strips, int N, int H)
 {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int fl = j / strips, strip = j - fl * strips, f = fl * 8 + x;
+    if (f >= nf) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int c0 = strip * 252 - 2 + 64 * wv; /* first column of the wave */
+    if (c0 < 0) c0 = 0;
+    if (c0 + 64 > H) c0 = H - 64;
+    const size_t fbase = (size_t)f * N * H;
+    v4u lo[2][kB], hi[2][kB];
+#pragma unroll
+    for (int d = 0; d < kB; ++d) {
+        const v4u* p = in + 2 * (fbase + (size_t)d * H + c0);
+        lo[0][d] = p[lane];
+        hi[0][d] = p[64 + lane];
+    }
+    for (int r0 = 0; r0 < N; r0 += 2 * kB) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int rb = r0 + half * kB;
+            if (rb >= N) break;
+#pragma unroll
+            for (int d = 0; d < kB; ++d) { /* the next block's loads */
+                const int rn = rb + kB + d < N ? rb + kB + d : N - 1;
+                const v4u* p = in + 2 * (fbase + (size_t)rn * H + c0);
+                lo[half ^ 1][d] = p[lane];
+                hi[half ^ 1][d] = p[64 + lane];
+            }
+#pragma unroll
+            for (int d = 0; d < kB; ++d) { /* this block's stores */
+                const int r = rb + d;
+                if (r >= N) break;
+                v4u a = lo[half][d], c = hi[half][d];
+                c.w &= 0xffff0000u;
+                v4u* dst = out + 2 * (fbase + (size_t)r * H + c0);
+                __builtin_nontemporal_store(a, dst + lane);
+                __builtin_nontemporal_store(c, dst + 64 + lane);
+            }
+        }
+    }
+}
+int main(int argc, char** argv)
+{
+    const bool only_walk = argc > 1;
     const size_t bytes = (size_t)2 << 30; // 2 GiB per buffer: far beyond the 256 MiB Infinity Cache
     v4u *a, *b; unsigned* o;
     CK(hipMalloc(&a, bytes + (1 << 20))); CK(hipMalloc(&b, bytes + (1 << 20))); CK(hipMalloc(&o, 4));
@@ -166,6 +213,7 @@ int main()
         printf("%-64s %.2f TB/s\n", name, moved * 5.0 / (ms * 1e-3) / 1e12);
         fflush(stdout);
     };
+    if (!only_walk) {
     time("read only (nt, grid-stride 4096)", (double)bytes, [&] { hipLaunchKernelGGL(k_read, dim3(4096), dim3(256), 0, 0, a, o, n16); });
     time("write only (nt, grid-stride 4096)", (double)bytes, [&] { hipLaunchKernelGGL(k_write, dim3(4096), dim3(256), 0, 0, b, n16); });
     time("hipMemcpyAsync D2D", 2.0 * bytes, [&] { CK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0)); });
@@ -194,6 +242,7 @@ int main()
         snprintf(nm, sizeof nm, "grid-stride %d x 256 thr, 2 in flight, nt", grid);
         time(nm, 2.0 * bytes, [&] { hipLaunchKernelGGL((k_gridstride<2, true>), dim3(grid), dim3(256), 0, 0, a, b, n16); });
     }
+    }
     {   // the walk's geometry: HDL_64E, 9 strips, 64 rows; as many frames as fit the buffer
         const int N = 64, H = 2083, strips = 9;
         const int nf = (int)(bytes / ((size_t)N * H * 32));
@@ -206,6 +255,9 @@ int main()
         time("walk shape, 4 rows in flight, whole-line stores", moved, [&] { hipLaunchKernelGGL((k_walk<4, true, false>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
         time("walk shape, 2 rows in flight, whole-line loads AND stores", moved, [&] { hipLaunchKernelGGL((k_walk_lines<2>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
         time("walk shape, 4 rows in flight, whole-line loads AND stores", moved, [&] { hipLaunchKernelGGL((k_walk_lines<4>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
+        time("walk shape, whole lines, bursts of 2 rows (loads of 2 rows at once, then stores of 2)", moved, [&] { hipLaunchKernelGGL((k_walk_burst<2>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
+        time("walk shape, whole lines, bursts of 4 rows", moved, [&] { hipLaunchKernelGGL((k_walk_burst<4>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
+        time("walk shape, whole lines, bursts of 8 rows", moved, [&] { hipLaunchKernelGGL((k_walk_burst<8>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
         for (int per_cu : {1, 2, 3, 4, 6, 8}) { /* dynamic LDS limits how many of these workgroups share a CU */
             char nm[96];
             snprintf(nm, sizeof nm, "walk shape, whole-line loads and stores, 4 rows in flight, %d workgroups per CU", per_cu);

@@ -1,7 +1,8 @@
-# usage (on the GPU box): bash scripts/profile_round.sh <tag> [pmc] [others]   -> gpurun_out/<tag>/...
+# usage (on the GPU box): bash scripts/profile_round.sh <tag> [pmc] [pmcothers] [others]   -> gpurun_out/<tag>/...
 #   default : plain bench line (with CPU baseline) + rocprofv3 kernel trace/stats of the same command with one lane
 #   pmc     : + the PMC passes (one counter group per run) on the SAME 1000-frame workload
-#   others  : + bench line and kernel stats of BASELINE configs 3 (os1_firing) and 5 (oxford_concat)
+#   pmcothers: + FETCH_SIZE / WRITE_SIZE passes of the general path (BEV_STREAM=0) and of os1_firing / hdl64_structured
+#   others  : + bench line and kernel stats of BASELINE configs 3 (os1_firing) and 5 (oxford_concat) and of hdl64_structured
 # The libraries are built ONCE up front; every profiled command is `rocprofv3 ... -- python3 bench.py --no-build`, so
 # nothing is spawned from a process the profiler has already attached to the GPU.
 export TMPDIR=/tmp
@@ -25,8 +26,19 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
   BEV_LANES=1 timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -- python3 $ARGS > $OUT/pmc$i.log 2>&1 || exit 1
 done
 fi
+if [ "$w" = pmcothers ]; then
+# 3b. HBM traffic (FETCH_SIZE, WRITE_SIZE: two passes each) of the general path on the headline workload and of the other layouts
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  BEV_STREAM=0 BEV_LANES=1 timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcgen$i -- python3 bench.py --no-build --steps 1 --warmup 1 --no-cpu --no-profile > $OUT/pmcgen$i.log 2>&1 || exit 1
+  for wl in os1_firing hdl64_structured; do
+    BEV_LANES=1 timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_${wl}$i -- python3 bench.py --no-build --steps 1 --warmup 1 --no-cpu --no-profile --workload $wl > $OUT/pmc_${wl}$i.log 2>&1 || exit 1
+  done
+done
+fi
 if [ "$w" = others ]; then
-for wl in os1_firing oxford_concat; do
+for wl in os1_firing oxford_concat hdl64_structured; do
   F=1000; if [ $wl = oxford_concat ]; then F=100; fi
   timeout 900 python3 bench.py --no-build --steps 5 --warmup 2 --workload $wl --frames $F --cpu-sample 50 > $OUT/bench_$wl.log 2>$OUT/bench_$wl.err || exit 1
   BEV_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -- python3 bench.py --no-build --steps 3 --warmup 1 --no-cpu --workload $wl --frames $F > $OUT/bench_under_rocprof_$wl.log 2>&1 || exit 1
