@@ -188,6 +188,7 @@ def main() -> int:
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     elapsed = shard.max_over_ranks(elapsed, world, device=dev, force_collective=use_dist)
     # the same steps once more, each one fenced by itself: the median step next to the mean of the timed region
     # (SURVEY.md 8(d) asks for the median; a fence per step costs the pipeline its overlap across steps)
@@ -200,6 +201,11 @@ def main() -> int:
     per_step.sort()
     median_step = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     total_frames = shard.sum_over_ranks(float(count * args.steps), world, device=dev, force_collective=use_dist)
+    # what every rank measured by itself (its shard of the table, its own wall time of the timed region, its device): the
+    # line shows that the collectives ran over `ranks_seen` ranks without anyone reading logs
+    ranks_seen = dist.get_world_size() if use_dist else 1
+    per_rank = shard.gather_per_rank([rank, local_rank, first, count, local_elapsed, count * args.steps / local_elapsed],
+                                     world, device=dev, force_collective=use_dist)
 
     # ---- profile passes (after the timed region, which carries no events): (1) the same steps again, still pipelined,
     # every launch bracketed by HIP events on its own stream: what each kernel costs UNDER OVERLAP, i.e. in the
@@ -258,7 +264,7 @@ def main() -> int:
         # HBM bytes of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs, gfx950 FETCH correction applied; see profiles/): per frame, scaled to this launch size
         # PMC counters cannot be read from inside the process: they come from the committed rocprofv3 --pmc passes of
-        # THIS command line (scripts/profile_round.sh; 1000 frames, sub-batch 256), per frame, scaled to this launch.
+        # THIS command line (scripts/profile_round.sh; 1000 frames, sub-batch 500), per frame, scaled to this launch.
         traffic, traffic_src, traffic_total = None, None, None
         # which instantiation of the walk a profile id is (rocprofv3 names kernels by their template arguments)
         pmc_prefix = {"k_walk": "k_walk<2,", "k_walk_general": "k_walk<0,", "k_walk_structured": "k_walk<3,",
@@ -370,6 +376,10 @@ def main() -> int:
             "value": total_frames / elapsed,
             "unit": "frames/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,  # dist.get_world_size() after init_process_group (backend nccl = RCCL); 1 without torch.distributed
+            "frame_range_table": [[int(a), int(b)] for a, b in table],  # what rank 0 broadcast: [first, count] per rank
+            "per_rank": [{"rank": int(r[0]), "local_rank": int(r[1]), "first_frame": int(r[2]), "frames": int(r[3]),
+                          "timed_region_s": float(r[4]), "frames_per_s": float(r[5])} for r in per_rank],  # all_gather over the ranks
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

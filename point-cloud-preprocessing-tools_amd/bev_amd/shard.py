@@ -40,6 +40,20 @@ def max_over_ranks(value: float, world_size: int, device="cpu", force_collective
     return float(t.item())
 
 
+def gather_per_rank(values, world_size: int, device="cpu", force_collective=False) -> np.ndarray:
+    """Every rank's row of float64 values, on every rank: (world_size, len(values)).  Reporting only (what each rank
+    measured: bench.py's line shows that the collective really ran over world_size ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([list(values)], dtype=torch.float64, device=device)
+    if world_size > 1 or force_collective:
+        out = [torch.zeros_like(t) for _ in range(world_size)]
+        dist.all_gather(out, t)
+        t = torch.cat(out, dim=0)
+    return t.cpu().numpy()
+
+
 def sum_over_ranks(value: float, world_size: int, device="cpu", force_collective=False) -> float:
     import torch
     import torch.distributed as dist

@@ -724,7 +724,9 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         int nl = e ? atoi(e) : 2;
         c->n_lanes = std::max(1, std::min(kMaxLanes, nl));
         c->n_lanes_active = c->n_lanes;
-        /* Frames whose points are in slot order up to a tail (what the selectors write) are read in place: no order
+        /* Frames whose points are in slot order up to a tail (a sweep written row by row with dropped returns ABSENT — none
+         * of the reference's three selectors writes exactly that: KITTI's structured clouds and MulRan's firing order have
+         * routes of their own, kFrameStructured / kFrameColMajor, Oxford's file order goes the general way) are read in place: no order
          * scan, no winner table, 5.6 MB less HBM traffic per HDL_64E frame.  k_probe decides per frame, the walk
          * verifies every point it consumes, a frame that fails is redone the general way: results never depend on the
          * mode.  Since round 3 (LDS-DMA windows, four workgroups per CU) ahead of the general path on every box measured
@@ -759,7 +761,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipMemset(ln.info, 0, nb * sizeof(FrameInfo)));
         CK(hipMalloc((void **)&ln.est, nb * (size_t)c->geo.N * c->geo.strips * sizeof(uint32_t)));
         if (c->allow_stream && c->geo.N <= kStreamMaxRows && c->geo.N * c->geo.strips <= kTailBuckets) {
-            CK(hipMalloc((void **)&ln.tail_list, (nb * (size_t)c->geo.N * c->geo.strips * kTailCap + 64) * sizeof(uint32_t))); /* (+ 64: the walk fetches 64 words per list) */
+            CK(hipMalloc((void **)&ln.tail_list, nb * (size_t)c->geo.N * c->geo.strips * kTailCap * sizeof(uint32_t))); /* (lanes past a list's count fetch its word 0) */
             CK(hipMalloc((void **)&ln.tail_cnt, nb * (size_t)c->geo.N * c->geo.strips * sizeof(uint32_t)));
         }
         CK(hipMalloc((void **)&ln.winner, nb * S * sizeof(uint32_t)));

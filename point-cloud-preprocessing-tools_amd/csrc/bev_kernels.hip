@@ -133,7 +133,7 @@ __device__ __forceinline__ uint32_t winner_index(uint32_t w, uint32_t tag, int s
 /* k_probe: which frames can be read in place.  getOrderedCloud (BatchMultiBevGen.cpp:102-116) scatters the input
  * point by point; when the input already IS in slot order — a sweep written row by row — the scatter is the identity
  * on positions, and reading the input a second time just to learn that (the order scan) is the largest avoidable
- * stream of the path.  One workgroup per frame looks at every 128th point: the leading samples that are in range and
+ * stream of the path.  One workgroup per frame looks at every 63rd point (kProbeStride): the leading samples that are in range and
  * strictly ascending bound a prefix [0, T) that is TAKEN for sorted; for every (row, strip) the position of its first
  * slot inside that prefix is estimated by interpolation between the two samples around it.  Nothing here is trusted:
  * the stream walk verifies every point it consumes and a frame that fails is redone the general way. */
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
     const uint32_t T0 = m ? (m - 1u) * kProbeStride + 1u : 0u;         /* the last of them is position T0 - 1 */
     /* ... and the points after it, one by one, up to the first that does not ascend (at the latest the successor of the
      * sample that failed): a sweep that is sorted to its end has no tail at all, and an appended block of other points
-     * starts exactly where the prefix ends — otherwise up to 126 sorted points of ONE (row, strip) would be "tail" */
+     * starts exactly where the prefix ends — otherwise up to 62 sorted points of ONE (row, strip) would be "tail" */
     __syncthreads();
     if (tid == 0) first_bad = T0 + (uint32_t)kProbeStride + 1u < n ? T0 + (uint32_t)kProbeStride + 1u : n;
     __syncthreads();
@@ -485,8 +485,8 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
 /* ------------------------------------------------------------------------- */
 /* getOrderedCloud gather + markGroundPoints phase A, as a COLUMN WALK.
  *
- * A workgroup owns kStripCols (252) adjacent columns of one frame plus two halo columns on each side (256 threads) and
- * walks the rows 0 .. N-1.  Thread tid sits on virtual column v = strip*252 + tid - 2 and, in row r, on flat slot
+ * A workgroup owns kStripCols (236) adjacent columns of one frame plus two halo columns on each side (240 virtual columns,
+ * 256 threads) and walks the rows 0 .. N-1.  Thread tid sits on virtual column v = strip*236 + tid - 2 and, in row r, on flat slot
  * index r*H + v (v >= H wraps to v - H in the SAME row, v < 0 is the flat index r*H + v, i.e. the tail of row r-1 —
  * exactly the two index rules of BatchMultiBevGen.cpp:146-154).  Consequences:
  *   - every input point is loaded exactly once, rows arrive as 8 KiB coalesced pieces, two rows ahead;
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void k_order_scan(const bev_point_t *__restric
  *   kSrcInPlace   the input's first T points are in strictly ascending slot order (k_probe): they are read IN PLACE,
  *                 coalesced, once — no order scan, no winner table.  Row rho's points of this strip's 256 virtual
  *                 columns are consecutive in the input and start near est[rho][strip]; the workgroup DMAs a window of
- *                 272 positions (est - 12 ...) into LDS, every thread looks at the (row, col) its window position
+ *                 256 positions (est - 12 ..., one per thread) into LDS, every thread looks at the (row, col) its window position
  *                 carries and enters the position into an index row at the point's column offset; the points listed for
  *                 the (row, strip) after the prefix ("tail", at most kTailCap, k_probe) are DMAed beside the window and
  *                 entered with a key that beats every prefix entry and every EARLIER tail point (LDS atomicMax: the

@@ -60,6 +60,9 @@ def test_single_rank_under_torch_distributed_run_goes_through_rccl():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 1 and d["value"] > 0
+    # the line shows by itself what RCCL saw: the world size after init_process_group, the broadcast table, every rank's own figures
+    assert d["ranks_seen"] == 1 and d["frame_range_table"] == [[0, 512]]
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["frames"] == 512 and d["per_rank"][0]["frames_per_s"] > 0
 
 
 @pytest.mark.gpu
@@ -73,3 +76,5 @@ def test_two_ranks_over_rccl_when_the_box_has_two_gpus():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 * 512 and d["value"] > 0
+    assert d["ranks_seen"] == 2 and d["frame_range_table"] == [[0, 512], [512, 512]]
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1] and all(r["frames_per_s"] > 0 for r in d["per_rank"])

@@ -34,6 +34,8 @@ def _worker(rank, world, port, q):
         local = float(np.arange(first, first + count).sum())
         total = shard.sum_over_ranks(local, world)
         slowest = shard.max_over_ranks(1.0 + rank, world)
+        rows = shard.gather_per_rank([rank, first, count, 10.0 * rank + 0.5], world)   # bench.py's per-rank report
+        assert rows.tolist() == [[0.0, 0.0, 1001.0, 0.5], [1.0, 1001.0, 1000.0, 10.5]]
         q.put((rank, table.tolist(), first, count, total, slowest))
     finally:
         dist.destroy_process_group()
