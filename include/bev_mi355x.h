@@ -237,10 +237,13 @@ int bev_profile_get(bev_ctx_t *ctx, bev_kernel_stat_t *out, int cap);
  * from the start of that sub-batch. */
 int bev_debug_get_cell_avg(bev_ctx_t *ctx, int first_frame, int n_frames, float *out);
 /* Test hook: how the frames of the LAST sub-batch reached their slots (getOrderedCloud, BatchMultiBevGen.cpp:94-117).
- * out[4 * i .. 4 * i + 3] = { T, mode, consumed, failed } of frame first_frame + i: mode 0 = order scan over all points,
- * 1 = the first T points were read in place (sorted prefix, verified: consumed == T, failed == 0), 2 = read in place,
- * verification failed, done again the general way.  Results never depend on the mode (reading in place is the default for
- * frames that qualify; BEV_STREAM=0 in the environment of bev_create turns it off). */
+ * out[4 * i .. 4 * i + 3] = { T, mode, consumed, failed } of frame first_frame + i.  mode 0 = order scan over all points
+ * (general path); 1 = the first T points were read in place (sorted prefix, verified: consumed == T, failed == 0);
+ * 2 = read in place, verification failed, done again the general way; 3 = a structured cloud of S records (record i =
+ * slot i's point or all-zero; KittiPointCloudSelect.cpp:206-207,240) read in place (consumed == T == S; failed bit 1: an
+ * all-zero record after the first was seen, bit 2: k_probe expected one); 4 = S returns in firing order
+ * (MulranPointCloudSelect.cpp:112-130) read in place.  Results never depend on the mode (reading in place is the default
+ * for frames that qualify; BEV_STREAM=0 in the environment of bev_create turns it off). */
 int bev_debug_get_frame_info(bev_ctx_t *ctx, int first_frame, int n_frames, uint32_t *out);
 /* Test hook: out[i] = how many raster-band code lists of frame first_frame + i of the LAST sub-batch did not hold their
  * codes (those bands of the frame's images were computed from the ordered cloud instead; normally 0; BEV_CODE_CAP in the

@@ -311,8 +311,8 @@ class BevContext:
         return out
 
     def frame_info(self, first_frame=0, n_frames=1):
-        """(n, 4) uint32: T, mode (0 general, 1 read in place, 2 read in place then redone), consumed, failed of the frames
-        of the last sub-batch."""
+        """(n, 4) uint32: T, mode (0 general, 1 sorted prefix read in place, 2 read in place then redone, 3 structured cloud
+        read in place, 4 firing order read in place), consumed, failed of the frames of the last sub-batch."""
         out = np.empty((n_frames, 4), dtype=np.uint32)
         self._check(self.lib.bev_debug_get_frame_info(self._h, first_frame, n_frames, _ptr(out)), "bev_debug_get_frame_info")
         return out

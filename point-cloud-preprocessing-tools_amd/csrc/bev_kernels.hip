@@ -621,7 +621,10 @@ constexpr int kWrapLead = 6;
 constexpr int kInPlaceSlot = (kWinPos + kWrapPos + kTailCap) * 32;
 constexpr uint32_t kIdxTail = 1u << 30;
 
-#ifdef BEV_EXP_WALK3 /* timing experiment: three walk workgroups per CU (by registers), LDS left for the other stream */
+#if defined(BEV_EXP_WALK2) /* timing experiment: two walk workgroups per CU (by registers): half of every CU's LDS and registers left for the other stream */
+#define BEV_WALK_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
+#define BEV_WALK_WAVES 2
+#elif defined(BEV_EXP_WALK3) /* timing experiment: three walk workgroups per CU (by registers), LDS left for the other stream */
 #define BEV_WALK_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
 #define BEV_WALK_WAVES 3
 #else
@@ -671,6 +674,9 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
     constexpr bool kColMajor = kSrc == kSrcColMajor, kIndexed = kInPlace || kColMajor;
 #ifdef BEV_EXP_WALK3
     asm volatile("" ::: "v135"); /* 136 registers: three waves per SIMD */
+#endif
+#ifdef BEV_EXP_WALK2
+    asm volatile("" ::: "v175"); /* 176 registers: two waves per SIMD */
 #endif
     static_assert(kWinPos == 256 && kStripVirt + 16 <= kWinPos && kTailCap == 64 && kWrapPos == 16, "DMA pieces of the in-place source");
     int f, strip;
