@@ -111,12 +111,16 @@ __global__ __launch_bounds__(256) void k_walk(const v4u* __restrict__ in, v4u* _
 }
 // the same loop with whole-line LOADS as well: lane l of a wave fetches 16-B unit l (then 64 + l) of the wave's 2 KiB of
 // a row — what the walk would see if its windows arrived as they lie in memory instead of as two half-line planes
-template <int kD>
+template <int kD, int kDelay = 0>
 __global__ __launch_bounds__(256) void k_walk_lines(const v4u* __restrict__ in, v4u* __restrict__ out, int nf, int strips, int N, int H)
 {
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int fl = j / strips, strip = j - fl * strips, f = fl * 8 + x;
     if (f >= nf) return;
+    if (kDelay) { /* workgroups start out of step with each other: up to kDelay x 64 sleeps of ~27 ns (does the lock step of a launch's workgroups — all reading, then all writing — cost bandwidth?) */
+        const unsigned h = (blockIdx.x * 2654435761u) >> 26; /* 0 .. 63 */
+        for (unsigned k = 0; k < h * kDelay; ++k) __builtin_amdgcn_s_sleep(1);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int c0 = strip * 252 - 2 + 64 * wv; /* first column of the wave */
     if (c0 < 0) c0 = 0;
@@ -255,6 +259,8 @@ int main(int argc, char** argv)
         time("walk shape, 4 rows in flight, whole-line stores", moved, [&] { hipLaunchKernelGGL((k_walk<4, true, false>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
         time("walk shape, 2 rows in flight, whole-line loads AND stores", moved, [&] { hipLaunchKernelGGL((k_walk_lines<2>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
         time("walk shape, 4 rows in flight, whole-line loads AND stores", moved, [&] { hipLaunchKernelGGL((k_walk_lines<4>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
+        time("walk shape, whole lines, 4 rows in flight, workgroups start up to 10 us apart", moved, [&] { hipLaunchKernelGGL((k_walk_lines<4, 6>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
+        time("walk shape, whole lines, 4 rows in flight, workgroups start up to 50 us apart", moved, [&] { hipLaunchKernelGGL((k_walk_lines<4, 30>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
         time("walk shape, whole lines, bursts of 2 rows (loads of 2 rows at once, then stores of 2)", moved, [&] { hipLaunchKernelGGL((k_walk_burst<2>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
         time("walk shape, whole lines, bursts of 4 rows", moved, [&] { hipLaunchKernelGGL((k_walk_burst<4>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
         time("walk shape, whole lines, bursts of 8 rows", moved, [&] { hipLaunchKernelGGL((k_walk_burst<8>), dim3(g), dim3(256), 0, 0, a, b, nf, strips, N, H); });
