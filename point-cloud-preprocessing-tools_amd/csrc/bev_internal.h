@@ -46,13 +46,14 @@ constexpr int kRasterThreads = BEV_RASTER_THREADS;
 constexpr int kRasterSplit = 8;   /* x-bands per frame in the raster kernel at the reference's 224 x 224 (see raster_bands_for) */
 constexpr int kMaxBands = 32;     /* coarse + fine raster bands (see RasterParams) */
 constexpr int kMaxStrips = 280;   /* ceil(65535 / kStripCols) rounded up */
-/* Entries of one (emitter, band) code list.  A benchmark frame's fullest list holds well under 2,000 codes of the 15,104
- * slots a strip has (the walk drops repeats of a code before they are listed); sized for the worst case the lists were
- * 21.6 MB per frame and workspace set, now 1.5 MB.  A writer whose list is full keeps counting and overwrites the list's
+/* Entries of one (emitter, band) code list.  Measured fill (scripts/list_fill.py: which capacities overflow on the
+ * synthetic layouts): HDL_64E sweeps stay under 2,048 codes per list, OS1_64 frames under 3,072 — of the 15,104 slots a
+ * strip has (the walk drops repeats of a code before they are listed); sized for the worst case the lists were 21.6 MB
+ * per frame and workspace set, now 3.0 MB.  A writer whose list is full keeps counting and overwrites the list's
  * last entry; k_bev_raster sees the count and computes that band of the frame from the ordered cloud instead (it reads
  * all S slots: slow, correct, and only for clouds piled up in one band).  BEV_CODE_CAP (environment of bev_create)
  * overrides the size: the tests run with tiny lists. */
-constexpr int kCodeListCap = 2048;
+constexpr int kCodeListCap = 4096;
 
 /* per-frame launch metadata, copied H2D once per sub-batch */
 struct FrameDesc {

@@ -40,7 +40,7 @@ fi
 if [ "$w" = others ]; then
 for wl in os1_firing oxford_concat hdl64_structured; do
   F=1000; if [ $wl = oxford_concat ]; then F=100; fi
-  timeout 900 python3 bench.py --no-build --steps 5 --warmup 2 --workload $wl --frames $F --cpu-sample 50 > $OUT/bench_$wl.log 2>$OUT/bench_$wl.err || exit 1
+  timeout 900 python3 bench.py --no-build --steps 20 --warmup 5 --workload $wl --frames $F --cpu-sample 50 > $OUT/bench_$wl.log 2>$OUT/bench_$wl.err || exit 1
   BEV_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -- python3 bench.py --no-build --steps 3 --warmup 1 --no-cpu --workload $wl --frames $F > $OUT/bench_under_rocprof_$wl.log 2>&1 || exit 1
 done
 fi

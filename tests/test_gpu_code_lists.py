@@ -67,3 +67,5 @@ def test_benchmark_frames_fit_their_lists_and_a_pile_in_one_band_does_not():
     ovf = _run(p, [synth.sweep(p, 85), synth.sweep(p, 86, keep=1.0, n_dup=0), synth.structured(p, 87, 0.98), pile])
     assert ovf[:3] == [0, 0, 0], ovf      # the layouts bench.py runs fit their lists
     assert ovf[3] != 0, ovf
+    p = bev_amd.params_for_sensor("OS1_64")   # (the sensor whose lists run fullest: a slower, equal raster if one overflows)
+    assert _run(p, [synth.firing_order(p, i) for i in range(3)] + [synth.sweep(p, i) for i in range(3)]) == [0] * 6
