@@ -138,12 +138,14 @@ struct bev_ctx {
     bool staged = true;     /* two-stage pipeline, see run_pipeline; BEV_STAGED=0 falls back to free-running lanes */
     int back_chunk = 1 << 30;  /* frames per launch of the back-stage kernels (BEV_BACK_CHUNK: experiment knob; default: the whole sub-batch) */
     bool allow_stream = true;  /* sorted-prefix frames are read in place (k_probe); BEV_STREAM=0 turns it off, see bev_create */
+    bool tile_walk = false;    /* BEV_TILE=1: structured clouds and bev_mark_ground through k_tile (row-block tiles) instead of the row loop */
     hipEvent_t fork_ev = nullptr;
     hipEvent_t stagger_ev = nullptr; /* recorded on a lane after its bandwidth-bound kernels */
     bool staggered[kMaxLanes] = {false, false, false, false};
     uint32_t *winner = nullptr;
     uint32_t *codes = nullptr;
     size_t codes_elems = 0;
+    uint32_t *tile_tab = nullptr; /* k_tile's tables (BatchPtrs::tile_tab) */
     float *last_avg = nullptr;
     uint32_t *last_ncode = nullptr;
     FrameInfo *last_info = nullptr;
@@ -464,6 +466,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.ncand = ln.ncand;
         b.code_main = ln.code_main;
         b.ncode = ln.ncode;
+        b.tile_tab = c->tile_tab;
         b.avg = ln.avg;
         b.gm = d_gm ? ln.gm : nullptr;
         b.multi = d_multi ? d_multi + (size_t)f0 * c->multi_bytes : nullptr;
@@ -472,7 +475,12 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         if (identity) {
             RoctxRange rr("bev:front (identity walk)");
             ProfScope ps(c, K_GATHER_GROUND, nb, st);
-            launch_gather_ground(g, b, nb, 1, kFrameGeneral, st);
+            if (c->tile_walk) {
+                HIPCK(c, hipMemsetAsync(ln.ncode, 0, (size_t)nb * g.emitters * g.raster_bands * sizeof(uint32_t), st));
+                launch_tile_walk(g, b, nb, 1, kFrameGeneral, st);
+            } else {
+                launch_gather_ground(g, b, nb, 1, kFrameGeneral, st);
+            }
         } else {
             RoctxRange rr("bev:front (probe, order scan, column walk)");
             uint32_t max_pts = 0;
@@ -499,13 +507,16 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
              * frame whose walk was not launched fails k_verdict's count and is redone the general way — the hint decides
              * speed, not results — and the next sub-batch of the set sees its mode in the word. */
             const uint32_t seen = c->allow_stream && ln.hint ? reinterpret_cast<volatile uint32_t *>(ln.hint)[1] : 0u;
+            if (c->tile_walk && c->allow_stream && n_exact_s > 0 && (seen & (1u << kFrameStructured))) /* the tiles of a strip ADD their counts to the strip's lists (before any walk of the sub-batch writes its own) */
+                HIPCK(c, hipMemsetAsync(ln.ncode, 0, (size_t)nb * g.emitters * g.raster_bands * sizeof(uint32_t), st));
             if (c->allow_stream && ln.tail_list && (seen & (1u << kFrameStream))) { /* frames k_probe found sorted up to a tail: read in place, verified */
                 ProfScope ps(c, K_GATHER_GROUND, nb, st);
                 launch_gather_ground(g, b, nb, 2, kFrameStream, st);
             }
             if (c->allow_stream && n_exact_s > 0 && (seen & (1u << kFrameStructured))) { /* structured clouds (only a frame of exactly S records can be one) */
                 ProfScope ps(c, K_WALK_STRUCTURED, nb, st);
-                launch_gather_ground(g, b, nb, 3, kFrameStructured, st);
+                if (c->tile_walk) launch_tile_walk(g, b, nb, 3, kFrameStructured, st);
+                else launch_gather_ground(g, b, nb, 3, kFrameStructured, st);
             }
             if (c->allow_stream && n_exact_s > 0 && (seen & (1u << kFrameColMajor))) { /* ... or S returns in firing order */
                 ProfScope ps(c, K_WALK_COLMAJOR, nb, st);
@@ -734,6 +745,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         const char *sm = getenv("BEV_STREAM");
         c->allow_stream = !(sm && atoi(sm) == 0);
         if (const char *bk = getenv("BEV_BACK_CHUNK")) c->back_chunk = std::max(1, atoi(bk));
+        if (const char *tw = getenv("BEV_TILE")) c->tile_walk = atoi(tw) != 0;
         const char *sg = getenv("BEV_STAGED");
         c->staged = (!sg || atoi(sg) != 0) && c->n_lanes >= 2;
     }
@@ -775,6 +787,16 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
     }
     c->winner = c->lanes[0].winner;
     CK(hipMalloc((void **)&c->codes, c->codes_elems * sizeof(uint32_t))); /* single-cloud entry points */
+    {   /* the tables every walk workgroup needs, once per context for k_tile */
+        uint32_t tab[kTileTabWords] = {};
+        int *ex = reinterpret_cast<int *>(tab), *ey = ex + bevx::kGridRows;
+        uint8_t *bt = reinterpret_cast<uint8_t *>(tab + bevx::kGridRows + bevx::kGridCols);
+        for (int i = 0; i < bevx::kGridRows; ++i) ex[i] = bevx::cell_edge_bin(i, 75.0f, c->geo.rp);
+        for (int i = 0; i < bevx::kGridCols; ++i) ey[i] = bevx::cell_edge_bin(i, 50.0f, c->geo.rp);
+        for (int x = 0; x < c->geo.rp.mat_size && x < 512; ++x) bt[x] = (uint8_t)bevx::raster_band_of_nodiv(x, c->geo.rp);
+        CK(hipMalloc((void **)&c->tile_tab, sizeof tab));
+        CK(hipMemcpy(c->tile_tab, tab, sizeof tab, hipMemcpyHostToDevice));
+    }
     /* >64 KiB dynamic LDS needs an explicit opt-in per kernel */
     CK(configure_kernels(c->geo));
     c->prof_pool.resize(kEventPairs);
@@ -815,7 +837,7 @@ void bev_destroy(bev_ctx_t *c)
     if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     for (auto e : c->out_ready)
         if (e) (void)hipEventDestroy(e);
-    void *dev[] = {c->st_in, c->st_ordered, c->st_multi, c->st_single, c->st_gm, c->kitti_buf, c->codes};
+    void *dev[] = {c->st_in, c->st_ordered, c->st_multi, c->st_single, c->st_gm, c->kitti_buf, c->codes, c->tile_tab};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     for (int k = 0; k < kDescRing; ++k) {
