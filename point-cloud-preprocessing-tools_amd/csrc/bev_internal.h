@@ -93,7 +93,10 @@ struct FrameInfo {
                         * all-zero record after the first, bit 2: k_probe guessed that there is one */
 };
 constexpr uint32_t kInfoFailed = 1u, kInfoZeroSeen = 2u, kInfoZeroGuess = 4u;
-constexpr int kProbeStride = 63;    /* k_probe looks at every 63rd point (odd: no resonance with firing orders of 2^k beams); the position of a
+#ifndef BEV_PROBE_STRIDE
+#define BEV_PROBE_STRIDE 63
+#endif
+constexpr int kProbeStride = BEV_PROBE_STRIDE;    /* k_probe looks at every 63rd point (odd: no resonance with firing orders of 2^k beams); the position of a
                                      * slot between two samples is interpolated: its error grows with the root of the stride */
 constexpr int kMaxSamples = 8192;   /* => stream mode for frames of up to 2^20 points; longer ones go the general way */
 constexpr int kStreamMinPrefix = 2048;
