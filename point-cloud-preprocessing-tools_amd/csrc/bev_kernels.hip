@@ -316,9 +316,11 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
             if (c < 2 && st > 0) append(row, st - 1, kStripCols + 2 + c, i);
             if (c >= kStripCols - 2 && st + 1 < g.strips) append(row, st + 1, c - (kStripCols - 2), i);
             if (col >= g.H - 2 && row + 1 < g.N) append(row + 1, 0, col - (g.H - 2), i);
-            if (col < 2) {
-                const int off = g.H + col - ((g.strips - 1) * kStripCols - 2);
-                if (off < kStripThreads) append(row, g.strips - 1, off, i);
+            if (col < 2) { /* the wrap-around halo of the last strip — and of the one before it when the last strip owns one column */
+                for (int ws = g.strips - 1; ws >= 0 && ws >= g.strips - 2; --ws) {
+                    const int off = g.H + col - (ws * kStripCols - 2);
+                    if (off < kStripVirt && ws * kStripCols < g.H) append(row, ws, off, i);
+                }
             }
         }
     }
@@ -783,7 +785,11 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
 
     /* ---- in place ---- */
     const uint32_t T = kIndexed ? b.info[f].T : 0u;
-    const bool last_strip = strip == strips - 1;
+    /* the strips whose virtual columns reach past the row's end and wrap to its start: the last one — and the one before it
+     * when the last strip owns a single column (H mod 236 == 1: column H - 2 then belongs to the strip before, and its
+     * (c + 2) % H fallback is column 0).  Found by the round-4 property test on a 473-column sensor: until then only the
+     * last strip fetched its wrap-around halo in the indexed sources. */
+    const bool last_strip = strip * kStripCols - 2 + kStripVirt > H;
     const int first_col = strip * kStripCols - 2; /* virtual column of offset 0 */
     const int own_cols = (H - first_col - 2) < kStripCols ? (H - first_col - 2) : kStripCols; /* own columns of this strip */
     const int row_span = (H - first_col) < kStripVirt ? (H - first_col) : kStripVirt;        /* offsets that belong to the row */

@@ -161,6 +161,33 @@ def test_gaps_that_shift_a_window_off_its_halo_columns_are_caught_or_harmless():
             ctx.close()
 
 
+def test_a_last_strip_of_one_column_leaves_the_wrap_around_halo_to_the_strip_before():
+    """H mod 236 == 1: column H - 2 belongs to the strip BEFORE the last, and its (c + 2) % H fallback
+    (BatchMultiBevGen.cpp:146-149) is column 0 — that strip's virtual column H.  Found by the round-4 property test on a
+    473-column sensor (until then only the last strip fetched a wrap-around halo in the indexed sources).  Invalid returns
+    at (r, H - 2) make the fallback count; sorted sweeps with a tail and firing order, both read in place."""
+    for n, h, g in [(24, 473, 4), (40, 709, 30), (16, 237, 10)]:
+        p = bev_amd.params_for_sensor("HDL_32E")
+        p.n_scan, p.horizon_scan, p.ground_upper_scan = n, h, g
+        rng = np.random.default_rng(h)
+        frames = []
+        for fid, dup in [(1, 0), (2, 300), (3, 0)]:
+            f = synth.sweep(p, 400 + fid, keep=1.0 if fid != 3 else 0.9, n_dup=dup)
+            edge = (f["col"] >= h - 3) | (f["col"] <= 2)
+            f["intensity"][edge & (rng.random(len(f)) < 0.7)] = -1.0
+            frames.append(f)
+        fo = synth.firing_order(p, 404)
+        edge = (fo["col"] >= h - 3) | (fo["col"] <= 2)
+        fo["intensity"][edge & (rng.random(len(fo)) < 0.7)] = -1.0
+        frames.append(fo)
+        ctx = bev_amd.BevContext(p, device=0, max_batch=16, max_points=max(len(f) for f in frames))
+        try:
+            info = _run(p, ctx, frames)
+            assert [int(m) for m in info[:, 1]] == [3, 1, 1, 4], (n, h, g, info)   # (the full sweep without a tail is a structured cloud)
+        finally:
+            ctx.close()
+
+
 def test_stream_and_general_frames_mixed_in_one_sub_batch_and_the_knob():
     import os
     p = bev_amd.params_for_sensor("HDL_32E")
@@ -198,7 +225,7 @@ _SPECIAL = np.array([0.0, -0.0, 0.5, -75.0, -75.000008, 75.0, -50.0, 49.999996, 
 @st.composite
 def _sorted_frames(draw):
     n = draw(st.integers(8, 40))
-    h = draw(st.sampled_from([300, 504, 505, 506, 757, 1024]))   # 2 .. 5 strips, strip edges on / next to the row end
+    h = draw(st.sampled_from([300, 473, 504, 505, 506, 709, 757, 1024]))   # 2 .. 5 strips, strip edges on / next to the row end (473, 709: the last strip owns ONE column)
     g = draw(st.integers(1, n - 2))
     frames = []
     for _ in range(draw(st.integers(1, 3))):
