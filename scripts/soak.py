@@ -1,5 +1,7 @@
 """Soak: many different BASELINE-config frames through the pipelined device-resident path, EVERY frame compared with the
-oracle.  usage (GPU box): python scripts/soak.py [rounds] [frames_per_round] [hdl64_sweep | os1_firing | hdl32_sweep | hdl64_adversarial | hdl64_structured] [sub_batch]
+oracle.  usage (GPU box): python scripts/soak.py [rounds] [frames_per_round] [hdl64_sweep | os1_firing | hdl32_sweep | hdl64_adversarial | hdl64_structured | hdl64_gappy] [sub_batch]
+(hdl64_gappy: sorted sweeps with BURSTS of dropped returns — runs of 1 to 400 slots at random places, next to row starts and strip
+boundaries too —, a tenth of the returns invalid, appended points: what shifts the in-place source's windows off their spans)
 (sub_batch defaults to 500, bench.py's launch size)"""
 import sys, os, time
 from concurrent.futures import ThreadPoolExecutor
@@ -15,7 +17,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 workload = sys.argv[3] if len(sys.argv) > 3 else "hdl64_sweep"
 sub_batch = int(sys.argv[4]) if len(sys.argv) > 4 else 500
 p = bev_amd.params_for_sensor({"hdl64_sweep": "HDL_64E", "os1_firing": "OS1_64", "hdl32_sweep": "HDL_32E", "hdl64_adversarial": "HDL_64E",
-                               "hdl64_structured": "HDL_64E"}[workload])
+                               "hdl64_structured": "HDL_64E", "hdl64_gappy": "HDL_64E"}[workload])
 sp = orc.sensor_from_params(p)
 
 
@@ -23,6 +25,25 @@ def make_frame(rnd, f):
     fid = 100000 + rnd * n + f
     if workload == "os1_firing":
         return synth.firing_order(p, fid)
+    if workload == "hdl64_gappy":
+        rng = np.random.default_rng(fid)
+        base = synth.sweep(p, fid, keep=1.0 - 0.01 * (f % 4), n_dup=(0, 200, 3000)[f % 3])
+        keep = np.ones(len(base), bool)
+        n_sorted = len(base) - (0, 200, 3000)[f % 3]
+        H = p.horizon_scan
+        for _ in range(int(rng.integers(0, 60))):
+            ln = int(min(400, rng.geometric(0.02)))
+            where = int(rng.integers(0, 4))
+            row = int(rng.integers(0, p.n_scan))
+            if where == 0:   start = row * H + int(rng.integers(0, 8))                              # just after a row start
+            elif where == 1: start = row * H + 236 * int(rng.integers(1, 9)) - int(rng.integers(0, ln + 4))   # around a strip boundary
+            elif where == 2: start = row * H + H - ln - int(rng.integers(0, 6))                       # before the row's end
+            else:            start = int(rng.integers(0, n_sorted))
+            slot = base["row"][:n_sorted].astype(np.int64) * H + base["col"][:n_sorted]
+            keep[:n_sorted] &= ~((slot >= start) & (slot < start + ln))
+        out = np.ascontiguousarray(base[keep])
+        out["intensity"][rng.random(len(out)) < 0.1] = -1.0
+        return out
     if workload == "hdl64_structured":
         return synth.structured(p, fid, keep=0.98 - 0.3 * (rnd % 3), kitti_intensity=bool(rnd % 2))
     if workload == "hdl64_adversarial":

@@ -89,7 +89,8 @@ _ROUTES = collections.Counter()
 @st.composite
 def layout_frames(draw):
     n = draw(st.integers(3, 40))
-    h = draw(st.sampled_from([5, 17, 59, 64, 236, 237, 300, 473, 505]))   # one wave, one strip, strip edges on / next to the row end
+    h = draw(st.one_of(st.sampled_from([5, 17, 59, 64, 236, 237, 300, 473, 505]),   # one wave, one strip, strip edges on / next to the row end
+                       st.integers(5, 1000)))
     g = draw(st.integers(1, n - 2))
     res = draw(st.sampled_from([0.25, 0.5, 1.0]))
     S = n * h

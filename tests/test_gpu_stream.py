@@ -225,7 +225,8 @@ _SPECIAL = np.array([0.0, -0.0, 0.5, -75.0, -75.000008, 75.0, -50.0, 49.999996, 
 @st.composite
 def _sorted_frames(draw):
     n = draw(st.integers(8, 40))
-    h = draw(st.sampled_from([300, 473, 504, 505, 506, 709, 757, 1024]))   # 2 .. 5 strips, strip edges on / next to the row end (473, 709: the last strip owns ONE column)
+    h = draw(st.one_of(st.sampled_from([300, 473, 504, 505, 506, 709, 757, 1024]),   # 2 .. 5 strips, strip edges on / next to the row end (473, 709: the last strip owns ONE column)
+                       st.integers(230, 1100)))
     g = draw(st.integers(1, n - 2))
     frames = []
     for _ in range(draw(st.integers(1, 3))):
