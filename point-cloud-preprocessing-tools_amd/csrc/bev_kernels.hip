@@ -1172,7 +1172,9 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
                     const uint32_t t8 = total << 8;
                     const uint32_t starts = t8 + (t8 << 8) + (t8 << 16) + before;
                     const uint32_t rank = __builtin_amdgcn_ubfe(starts, q2 << 3, 8u) + ((p2.fl >> kFlRankShift) & 63u);
+#ifndef BEV_ABL_NOCAND /* timing-only ablation: the candidates' stores (results are wrong without them) */
                     fcand[seg * (uint32_t)kSeg + rank] = u32x2{p2.key, p2.lo.z}; /* key | height */
+#endif
                 }
                 if (tid == 2) fncand[seg] = total;
             }
@@ -1183,7 +1185,11 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
                  * and so does one whose code this strip has listed before and still remembers (rings hit the same cells
                  * at the same heights again and again: a HDL_64E frame lists 74 k codes of which 24 k are distinct).  The
                  * rasters are idempotent, so a stale or racing memo entry only costs a duplicate. */
+#ifdef BEV_ABL_NOLIST /* timing-only ablation: no code is listed (the rasters get nothing) */
+                bool has = false;
+#else
                 bool has = outcol && !cand2 && p2.code != kSkip;
+#endif
                 /* (the left neighbour's code and flag by DPP: no LDS round trip) */
                 const uint32_t left_code = (uint32_t)__builtin_amdgcn_update_dpp((int)kSkip, (int)p2.code, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                 const bool left_has = __builtin_amdgcn_update_dpp(0, has ? 1 : 0, 0x138, 0xf, 0xf, false) != 0;
@@ -1248,7 +1254,11 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
         /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
         PHA(5);
         int s_r = kSteep;
+#ifdef BEV_ABL_NOSTATUS /* timing-only ablation: no status, hence no candidates */
+        if (false) {
+#else
         if (r >= lo_row && r < N) { /* workgroup-uniform */
+#endif
             /* row r-1 of the threads two to the right / left */
             XYZI right{from_right2(prev.x), from_right2(prev.y), from_right2(prev.z), from_right2(prev.i)};
             XYZI left{from_left2(prev.x), from_left2(prev.y), from_left2(prev.z), from_left2(prev.i)};
@@ -1308,7 +1318,11 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
         p0.hi = cur_hi;
         p0.fl = (uint32_t)(s_r + 1) | (1u << 2);
         p0.key = 0u;
+#ifdef BEV_ABL_NOCODE /* timing-only ablation: no BEV code */
+        p0.code = kSkip;
+#else
         p0.code = code_t<kPow2>(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w & 0xffffu), rp);
+#endif
 
         /* ---- in place: published for the next step: row r's edge lanes, the candidates of row r-1 per wave ---- */
         if constexpr (kIndexed) {
