@@ -318,7 +318,10 @@ class BevContext:
         return out
 
     def code_overflow(self, first_frame=0, n_frames=1):
-        """(n,) uint32: BEV codes of each frame of the last sub-batch that went through the overflow list"""
+        """(n,) uint32: per frame of the last sub-batch, the number of (writer, raster band) code lists that overflowed;
+        those bands were rastered from the ordered cloud instead"""
+        if not hasattr(self.lib, "bev_debug_get_code_overflow"):
+            raise BevError("this build of libbev_mi355x.so (selected through BEV_AMD_LIB?) has no bev_debug_get_code_overflow")
         out = np.empty(n_frames, dtype=np.uint32)
         self._check(self.lib.bev_debug_get_code_overflow(self._h, first_frame, n_frames, _ptr(out)), "bev_debug_get_code_overflow")
         return out

@@ -46,6 +46,7 @@ struct Lane {
     hipEvent_t front_done = nullptr, back_done = nullptr; /* staged mode: workspace hand-over between the two stages */
     FrameInfo *info = nullptr;  /* per frame: how its points reach their slots (k_probe / k_verdict) */
     uint32_t *hint = nullptr;   /* mapped host words (k_verdict): [0] frames of the set's last sub-batch that were NOT read in place, [1] the modes k_probe gave its frames (bit = mode) */
+    int mode_absent[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* looks at hint[1] since it last showed the mode (see run_pipeline) */
     uint32_t *est = nullptr;    /* stream frames: estimated input position of every (row, strip)'s first slot */
     uint32_t *tail_list = nullptr, *tail_cnt = nullptr; /* ... and their tail points per (row, strip) (stream mode only) */
     uint32_t *winner = nullptr;
@@ -137,15 +138,15 @@ struct bev_ctx {
     int n_lanes_active = 1; /* <= n_lanes; bev_set_lanes */
     bool staged = true;     /* two-stage pipeline, see run_pipeline; BEV_STAGED=0 falls back to free-running lanes */
     int back_chunk = 1 << 30;  /* frames per launch of the back-stage kernels (BEV_BACK_CHUNK: experiment knob; default: the whole sub-batch) */
+    int mode_ttl = 8;          /* a mode's in-place walk stays launched for this many sub-batches of a workspace set after the set last saw the mode (BEV_MODE_TTL) */
     bool allow_stream = true;  /* sorted-prefix frames are read in place (k_probe); BEV_STREAM=0 turns it off, see bev_create */
-    bool tile_walk = false;    /* BEV_TILE=1: structured clouds and bev_mark_ground through k_tile (row-block tiles) instead of the row loop */
     hipEvent_t fork_ev = nullptr;
     hipEvent_t stagger_ev = nullptr; /* recorded on a lane after its bandwidth-bound kernels */
     bool staggered[kMaxLanes] = {false, false, false, false};
     uint32_t *winner = nullptr;
     uint32_t *codes = nullptr;
     size_t codes_elems = 0;
-    uint32_t *tile_tab = nullptr; /* k_tile's tables (BatchPtrs::tile_tab) */
+    uint32_t *ctx_tab = nullptr; /* per-context tables (BatchPtrs::ctx_tab) */
     float *last_avg = nullptr;
     uint32_t *last_ncode = nullptr;
     FrameInfo *last_info = nullptr;
@@ -411,13 +412,6 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             }
             c->h_desc[ds][f].in_offset = a;
             c->h_desc[ds][f].n_pts = (uint32_t)(b - a);
-#ifdef BEV_EXP_ALIAS /* timing experiment: every frame reads the input of frame f % BEV_EXP_ALIAS (cache-resident input) */
-            {
-                const int src = f % BEV_EXP_ALIAS;
-                c->h_desc[ds][f].in_offset = h_offsets[src];
-                c->h_desc[ds][f].n_pts = (uint32_t)(h_offsets[src + 1] - h_offsets[src]);
-            }
-#endif
             c->h_desc[ds][f]._pad = 0;
         }
         HIPCK(c, hipMemcpyAsync(c->d_desc[ds], c->h_desc[ds], (size_t)n_frames * sizeof(FrameDesc),
@@ -466,7 +460,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.ncand = ln.ncand;
         b.code_main = ln.code_main;
         b.ncode = ln.ncode;
-        b.tile_tab = c->tile_tab;
+        b.ctx_tab = c->ctx_tab;
         b.avg = ln.avg;
         b.gm = d_gm ? ln.gm : nullptr;
         b.multi = d_multi ? d_multi + (size_t)f0 * c->multi_bytes : nullptr;
@@ -475,12 +469,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         if (identity) {
             RoctxRange rr("bev:front (identity walk)");
             ProfScope ps(c, K_GATHER_GROUND, nb, st);
-            if (c->tile_walk) {
-                HIPCK(c, hipMemsetAsync(ln.ncode, 0, (size_t)nb * g.emitters * g.raster_bands * sizeof(uint32_t), st));
-                launch_tile_walk(g, b, nb, 1, kFrameGeneral, st);
-            } else {
-                launch_gather_ground(g, b, nb, 1, kFrameGeneral, st);
-            }
+            launch_gather_ground(g, b, nb, 1, kFrameGeneral, st);
         } else {
             RoctxRange rr("bev:front (probe, order scan, column walk)");
             uint32_t max_pts = 0;
@@ -501,22 +490,28 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                 ProfScope ps(c, K_PROBE, nb, st);
                 launch_probe(g, b, nb, c->allow_stream, st);
             }
-            /* The walks of the modes that read in place.  Which of them are launched follows the modes k_probe gave the
-             * frames of this workspace set's last finished sub-batch (a word k_verdict leaves in mapped host memory, read
-             * without waiting; everything while nothing is known): an empty launch costs 5-8 us of a 1 ms sub-batch.  A
-             * frame whose walk was not launched fails k_verdict's count and is redone the general way — the hint decides
-             * speed, not results — and the next sub-batch of the set sees its mode in the word. */
-            const uint32_t seen = c->allow_stream && ln.hint ? reinterpret_cast<volatile uint32_t *>(ln.hint)[1] : 0u;
-            if (c->tile_walk && c->allow_stream && n_exact_s > 0 && (seen & (1u << kFrameStructured))) /* the tiles of a strip ADD their counts to the strip's lists (before any walk of the sub-batch writes its own) */
-                HIPCK(c, hipMemsetAsync(ln.ncode, 0, (size_t)nb * g.emitters * g.raster_bands * sizeof(uint32_t), st));
+            /* The walks of the modes that read in place.  A mode's walk is launched unless the last mode_ttl looks at the
+             * word k_verdict leaves in mapped host memory (the modes k_probe gave the frames of this workspace set's last
+             * finished sub-batch; read without waiting; all ones while nothing is known) did not show the mode: an empty
+             * launch costs 5-8 us of a 1 ms sub-batch, a frame whose walk was NOT launched fails k_verdict's count and is
+             * redone the general way — the hint decides speed, not results.  Sticky since round 5 (round 4 followed the
+             * last word alone: a directory that alternates layouts, or batches that cross a layout change, had every
+             * frame of such a sub-batch redone; BEV_MODE_TTL=1 is that rule). */
+            uint32_t seen = 0u;
+            if (c->allow_stream && ln.hint) {
+                const uint32_t word = reinterpret_cast<volatile uint32_t *>(ln.hint)[1];
+                for (int m = 0; m < 8; ++m) {
+                    ln.mode_absent[m] = (word >> m) & 1u ? 0 : std::min(ln.mode_absent[m] + 1, 1 << 20);
+                    if (ln.mode_absent[m] < c->mode_ttl) seen |= 1u << m;
+                }
+            }
             if (c->allow_stream && ln.tail_list && (seen & (1u << kFrameStream))) { /* frames k_probe found sorted up to a tail: read in place, verified */
                 ProfScope ps(c, K_GATHER_GROUND, nb, st);
                 launch_gather_ground(g, b, nb, 2, kFrameStream, st);
             }
             if (c->allow_stream && n_exact_s > 0 && (seen & (1u << kFrameStructured))) { /* structured clouds (only a frame of exactly S records can be one) */
                 ProfScope ps(c, K_WALK_STRUCTURED, nb, st);
-                if (c->tile_walk) launch_tile_walk(g, b, nb, 3, kFrameStructured, st);
-                else launch_gather_ground(g, b, nb, 3, kFrameStructured, st);
+                launch_gather_ground(g, b, nb, 3, kFrameStructured, st);
             }
             if (c->allow_stream && n_exact_s > 0 && (seen & (1u << kFrameColMajor))) { /* ... or S returns in firing order */
                 ProfScope ps(c, K_WALK_COLMAJOR, nb, st);
@@ -745,7 +740,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         const char *sm = getenv("BEV_STREAM");
         c->allow_stream = !(sm && atoi(sm) == 0);
         if (const char *bk = getenv("BEV_BACK_CHUNK")) c->back_chunk = std::max(1, atoi(bk));
-        if (const char *tw = getenv("BEV_TILE")) c->tile_walk = atoi(tw) != 0;
+        if (const char *mt = getenv("BEV_MODE_TTL")) c->mode_ttl = std::max(1, atoi(mt));
         const char *sg = getenv("BEV_STAGED");
         c->staged = (!sg || atoi(sg) != 0) && c->n_lanes >= 2;
     }
@@ -787,15 +782,15 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
     }
     c->winner = c->lanes[0].winner;
     CK(hipMalloc((void **)&c->codes, c->codes_elems * sizeof(uint32_t))); /* single-cloud entry points */
-    {   /* the tables every walk workgroup needs, once per context for k_tile */
-        uint32_t tab[kTileTabWords] = {};
+    {   /* tables that depend on the parameters only, once per context: BEV bins of the ground grid's cell edges, x bin -> raster band */
+        uint32_t tab[kCtxTabWords] = {};
         int *ex = reinterpret_cast<int *>(tab), *ey = ex + bevx::kGridRows;
         uint8_t *bt = reinterpret_cast<uint8_t *>(tab + bevx::kGridRows + bevx::kGridCols);
         for (int i = 0; i < bevx::kGridRows; ++i) ex[i] = bevx::cell_edge_bin(i, 75.0f, c->geo.rp);
         for (int i = 0; i < bevx::kGridCols; ++i) ey[i] = bevx::cell_edge_bin(i, 50.0f, c->geo.rp);
         for (int x = 0; x < c->geo.rp.mat_size && x < 512; ++x) bt[x] = (uint8_t)bevx::raster_band_of_nodiv(x, c->geo.rp);
-        CK(hipMalloc((void **)&c->tile_tab, sizeof tab));
-        CK(hipMemcpy(c->tile_tab, tab, sizeof tab, hipMemcpyHostToDevice));
+        CK(hipMalloc((void **)&c->ctx_tab, sizeof tab));
+        CK(hipMemcpy(c->ctx_tab, tab, sizeof tab, hipMemcpyHostToDevice));
     }
     /* >64 KiB dynamic LDS needs an explicit opt-in per kernel */
     CK(configure_kernels(c->geo));
@@ -837,7 +832,7 @@ void bev_destroy(bev_ctx_t *c)
     if (c->dl_stream) (void)hipStreamDestroy(c->dl_stream);
     for (auto e : c->out_ready)
         if (e) (void)hipEventDestroy(e);
-    void *dev[] = {c->st_in, c->st_ordered, c->st_multi, c->st_single, c->st_gm, c->kitti_buf, c->codes, c->tile_tab};
+    void *dev[] = {c->st_in, c->st_ordered, c->st_multi, c->st_single, c->st_gm, c->kitti_buf, c->codes, c->ctx_tab};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     for (int k = 0; k < kDescRing; ++k) {

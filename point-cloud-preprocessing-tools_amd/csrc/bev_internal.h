@@ -54,7 +54,7 @@ constexpr int kMaxStrips = 280;   /* ceil(65535 / kStripCols) rounded up */
  * all S slots: slow, correct, and only for clouds piled up in one band).  BEV_CODE_CAP (environment of bev_create)
  * overrides the size: the tests run with tiny lists. */
 constexpr int kCodeListCap = 4096;
-constexpr int kTileTabWords = bevx::kGridRows + bevx::kGridCols + 512 / 4;
+constexpr int kCtxTabWords = bevx::kGridRows + bevx::kGridCols + 512 / 4; /* BatchPtrs::ctx_tab */
 
 /* per-frame launch metadata, copied H2D once per sub-batch */
 struct FrameDesc {
@@ -151,7 +151,7 @@ struct BatchPtrs {
     uint32_t *ncand;             /* [nf][segs] */
     uint32_t *code_main;         /* [nf][emitters][bands][code_stride] */
     uint32_t *ncode;             /* [nf][emitters][bands]: codes the writer had for the list (more than code_cap: the list is incomplete) */
-    const uint32_t *tile_tab;    /* [kTileTabWords] per context: edge_x[75], edge_y[50] (BEV bins of the ground grid's cell edges), band_tab[512] bytes (x bin -> raster band): what every walk workgroup computes for itself, k_tile loads */
+    const uint32_t *ctx_tab;     /* [kCtxTabWords] per context: edge_x[75], edge_y[50] (BEV bins of the ground grid's cell edges), band_tab[512] bytes (x bin -> raster band) */
     float *avg;                  /* [nf][3750] */
     int8_t *gm;                  /* [nf][S] or nullptr: phase-A ground_mat */
     uint8_t *multi;              /* [nf][L*M*M] */
@@ -190,8 +190,6 @@ void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t m
  * mode = kFrameStream); 3: structured clouds (frames of mode kFrameStructured: pass that mode); 4: clouds in firing
  * order (kFrameColMajor) */
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int source, uint32_t mode, hipStream_t st);
-/* the same as tiles (k_tile): source 1 (identity) or 3 (structured clouds); b.ncode of the frames' strips must be zero */
-void launch_tile_walk(const Geometry &g, const BatchPtrs &b, int nf, int source, uint32_t mode, hipStream_t st);
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st);
 void launch_verdict(const BatchPtrs &b, int nf, uint32_t *host_hint, hipStream_t st);
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);

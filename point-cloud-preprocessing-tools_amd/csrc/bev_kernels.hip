@@ -623,16 +623,6 @@ constexpr int kWrapLead = 6;
 constexpr int kInPlaceSlot = (kWinPos + kWrapPos + kTailCap) * 32;
 constexpr uint32_t kIdxTail = 1u << 30;
 
-#if defined(BEV_EXP_WALK2) /* timing experiment: two walk workgroups per CU (by registers): half of every CU's LDS and registers left for the other stream */
-#define BEV_WALK_OCC __attribute__((amdgpu_waves_per_eu(2, 2)))
-#define BEV_WALK_WAVES 2
-#elif defined(BEV_EXP_WALK3) /* timing experiment: three walk workgroups per CU (by registers), LDS left for the other stream */
-#define BEV_WALK_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
-#define BEV_WALK_WAVES 3
-#else
-#define BEV_WALK_OCC
-#define BEV_WALK_WAVES 4
-#endif
 #ifdef BEV_CS_CLOCK /* developer build: start, end, HW_ID, XCC_ID of every workgroup of the last in-place walk launch */
 constexpr int kWalkTlCap = 8192;
 __device__ long long g_walk_tl[kWalkTlCap][4];
@@ -667,19 +657,13 @@ __device__ __forceinline__ uint32_t quarter_scan(bool c, uint32_t q, uint32_t *r
 constexpr int kFlRankShift = 8; /* WalkRow::fl bits 8..13: the lane's rank among its wave's candidates of its quarter */
 
 template <int kSrc, bool kPow2, bool kGm>
-__global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_WAVES) BEV_WALK_OCC void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
+__global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : 4) void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
     /* kStructured: the identity source over the caller's INPUT (record i = slot i's point or an all-zero record), every
      * record checked; kIdentity below covers both (no winner table, position = slot) */
     constexpr bool kStructured = kSrc == kSrcStructured, kIdentity = kSrc == kSrcIdentity || kStructured, kInPlace = kSrc == kSrcInPlace;
     /* kIndexed: the sources whose points reach their columns through an index row (LDS atomicMax), after the step's barrier */
     constexpr bool kColMajor = kSrc == kSrcColMajor, kIndexed = kInPlace || kColMajor;
-#ifdef BEV_EXP_WALK3
-    asm volatile("" ::: "v135"); /* 136 registers: three waves per SIMD */
-#endif
-#ifdef BEV_EXP_WALK2
-    asm volatile("" ::: "v175"); /* 176 registers: two waves per SIMD */
-#endif
     static_assert(kWinPos == 256 && kStripVirt + 16 <= kWinPos && kTailCap == 64 && kWrapPos == 16, "DMA pieces of the in-place source");
     int f, strip;
 #ifdef BEV_CS_CLOCK
@@ -953,7 +937,7 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
             /* flat: columns H - 2, H - 1 of row rho - 1 at offsets 0, 1; wrap: columns 0, 1 of row rho at H - first_col + 0, 1 */
             const uint32_t off = flat ? col - (uint32_t)(H - 2) : (uint32_t)(H - first_col) + col;
             const bool ok = (lane < kSideFirings) & ((unsigned)fr < (unsigned)H) & (want_row >= 0) & (row == (uint32_t)want_row) &
-                            (flat ? (col < (uint32_t)H) & (off < 2u) : (col < 2u));
+                            (flat ? (col < (uint32_t)H) & (off < 2u) : (col < 2u) & (off < (uint32_t)kStripVirt));
             atomicMax(&irow[ok ? off : (uint32_t)kStripThreads], (uint32_t)(kStripThreads + (flat ? 0 : kSideFirings) + i) + 1u);
         }
     };
@@ -1172,9 +1156,7 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
                     const uint32_t t8 = total << 8;
                     const uint32_t starts = t8 + (t8 << 8) + (t8 << 16) + before;
                     const uint32_t rank = __builtin_amdgcn_ubfe(starts, q2 << 3, 8u) + ((p2.fl >> kFlRankShift) & 63u);
-#ifndef BEV_ABL_NOCAND /* timing-only ablation: the candidates' stores (results are wrong without them) */
                     fcand[seg * (uint32_t)kSeg + rank] = u32x2{p2.key, p2.lo.z}; /* key | height */
-#endif
                 }
                 if (tid == 2) fncand[seg] = total;
             }
@@ -1185,11 +1167,7 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
                  * and so does one whose code this strip has listed before and still remembers (rings hit the same cells
                  * at the same heights again and again: a HDL_64E frame lists 74 k codes of which 24 k are distinct).  The
                  * rasters are idempotent, so a stale or racing memo entry only costs a duplicate. */
-#ifdef BEV_ABL_NOLIST /* timing-only ablation: no code is listed (the rasters get nothing) */
-                bool has = false;
-#else
                 bool has = outcol && !cand2 && p2.code != kSkip;
-#endif
                 /* (the left neighbour's code and flag by DPP: no LDS round trip) */
                 const uint32_t left_code = (uint32_t)__builtin_amdgcn_update_dpp((int)kSkip, (int)p2.code, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                 const bool left_has = __builtin_amdgcn_update_dpp(0, has ? 1 : 0, 0x138, 0xf, 0xf, false) != 0;
@@ -1220,12 +1198,8 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
                 /* (this lane's unit of row q: a byte offset into the frame kept per lane and advanced by one row per step —
                  * base register + 32-bit offset, no 64-bit address arithmetic) */
                 const gptr<char> orow = (gptr<char>)fordered + ord_off;
-#ifndef BEV_EXP_NOSTORE /* timing experiment: what the ordered cloud's stores cost (results are wrong without them) */
                 if ((owners >> (lane >> 1)) & 1ull) __builtin_nontemporal_store(pa, (gptr<u32x4>)(orow - 1024));
                 if ((owners >> (32 + (lane >> 1))) & 1ull) __builtin_nontemporal_store(pb, (gptr<u32x4>)orow);
-#else
-                if (pa.x == 0x12345678u && pb.x == 0x9abcdef0u && owners) __builtin_nontemporal_store(pa, (gptr<u32x4>)(orow - 1024)); /* keeps the values alive */
-#endif
                 if (kGm && outcol) fgm[(uint32_t)(q * H + v)] = (int8_t)wr_gflag(p2.fl);
             }
         }
@@ -1254,11 +1228,7 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
         /* ---- status of row r (BatchMultiBevGen.cpp:142-182) ---- */
         PHA(5);
         int s_r = kSteep;
-#ifdef BEV_ABL_NOSTATUS /* timing-only ablation: no status, hence no candidates */
-        if (false) {
-#else
         if (r >= lo_row && r < N) { /* workgroup-uniform */
-#endif
             /* row r-1 of the threads two to the right / left */
             XYZI right{from_right2(prev.x), from_right2(prev.y), from_right2(prev.z), from_right2(prev.i)};
             XYZI left{from_left2(prev.x), from_left2(prev.y), from_left2(prev.z), from_left2(prev.i)};
@@ -1318,11 +1288,7 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
         p0.hi = cur_hi;
         p0.fl = (uint32_t)(s_r + 1) | (1u << 2);
         p0.key = 0u;
-#ifdef BEV_ABL_NOCODE /* timing-only ablation: no BEV code */
-        p0.code = kSkip;
-#else
         p0.code = code_t<kPow2>(cur.x, cur.y, cur.z, (int)(int16_t)(cur_hi.w & 0xffffu), rp);
-#endif
 
         /* ---- in place: published for the next step: row r's edge lanes, the candidates of row r-1 per wave ---- */
         if constexpr (kIndexed) {
@@ -1365,278 +1331,6 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : BEV_WALK_
             if (failed) atomicOr(&b.info[f].failed, failed);
         }
     }
-}
-
-/* ------------------------------------------------------------------------- */
-/* The same work as k_walk<identity / structured>, as TILES (round 4; BEV_TILE=1 in the environment of bev_create selects it
- * for structured clouds and for bev_mark_ground until it has won on the box).  What the row loop of k_walk is bound by is
- * its shape — long-lived workgroups that each walk one stream of 8-KiB row pieces reach 5.0-5.25 TB/s as a pure copy
- * whatever their prefetch depth, occupancy or phase, short-lived workgroups that request everything up front 5.5-5.9
- * (DESIGN.md section 8).  Here a WAVE owns 59 adjacent columns (+ 2 halo columns on either side: 63 lanes) and
- * kTileRows rows; the records of rows r0 - 2 .. r0 + kTileRows (what phase A's stencil needs around the tile: the two
- * fallback rows above, the row below whose status decides the last row's ground flag) are requested at once into
- * registers; neighbours' values are lane permutes: no LDS edge exchange and no barrier per row.  The four waves of a
- * workgroup are a strip of 4 x 59 = 236 columns, so that candidates (one segment per (row, strip), four quarter runs in
- * column order), code lists and everything behind them keep their layout: the waves meet once per tile to add up their
- * candidate counts, and the workgroup reserves its share of the strip's code lists with one global atomic per band. */
-/* workgroup barrier for LDS data only, in a form the compiler understands (fences on the LDS address space): unlike the
- * inline-asm lds_barrier() it does not make hipcc wait for the global loads and stores in flight */
-__device__ __forceinline__ void lds_only_barrier()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-#ifndef BEV_TILE_ROWS
-#define BEV_TILE_ROWS 8 /* (make exp EXPFLAGS=-DBEV_TILE_ROWS=6: rows per tile: registers against halo rows) */
-#endif
-constexpr int kTileRows = BEV_TILE_ROWS;
-constexpr int kTileWaveCols = kStripCols / 4;
-static_assert(kTileWaveCols * 4 == kStripCols && kTileWaveCols + 4 <= 64 && kStripThreads == 256, "four waves of 59 columns + halo");
-
-template <int kSrc, bool kPow2, bool kGm>
-__global__ __launch_bounds__(kStripThreads, kTileRows <= 4 ? 6 : (kTileRows <= 6 ? 5 : 4)) void k_tile(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
-{
-    constexpr bool kStructured = kSrc == kSrcStructured;
-    constexpr int R = kTileRows, RL = kTileRows + 3;
-    static_assert(kSrc == kSrcStructured || kSrc == kSrcIdentity, "sources whose records sit at their slots");
-    const int N = g.N, H = g.H, lo_row = g.N - g.G, strips = g.strips, bands = g.raster_bands;
-    const int n_rb = (N + R - 1) / R;
-    int f, t;
-    if (!map_block_xcd(blockIdx.x, nf, strips * n_rb, f, t)) return;
-    if (kStructured && b.info[f].mode != want_mode) return;
-    const int rb = t / strips, strip = t - rb * strips, r0 = rb * R; /* consecutive workgroups: adjacent strips of one row block */
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t frame_off = (size_t)f * g.S;
-
-    __shared__ __attribute__((aligned(16))) char xp[4][2048];   /* per wave: a row's 59 points on their way to whole-line stores */
-    __shared__ __attribute__((aligned(16))) uint32_t wave_cnt[R][4];
-    __shared__ uint32_t band_cursor[kMaxBands], band_base[kMaxBands];
-    __shared__ uint32_t seen[256];
-    __shared__ uint32_t tabs[256]; /* the context's table: edge_x[75], edge_y[50], band_tab[512 bytes] */
-    const int *edge_x = reinterpret_cast<const int *>(tabs), *edge_y = edge_x + kGridRows;
-    const uint8_t *band_tab = reinterpret_cast<const uint8_t *>(tabs + kGridRows + kGridCols);
-    PH_DECL;
-    PH();
-    const uint32_t tab_word = b.tile_tab[tid < kTileTabWords ? tid : 0]; /* (the first load: the records' loads behind it stay in flight while it is used) */
-
-    const int c_w0 = strip * kStripCols + wv * kTileWaveCols;     /* the wave's first own column */
-    const int v = c_w0 - 2 + lane;                                /* virtual column: >= H wraps inside the row, < 0 is the flat index */
-    const bool provider = lane < kTileWaveCols + 4 && v < H + 2 && (v >= 0 || strip == 0);
-    const bool outcol = lane >= 2 && lane < 2 + kTileWaveCols && v < H;
-    const int vcol = v >= H ? v - H : v;
-    const int n_own = H - c_w0 < kTileWaveCols ? (H - c_w0 > 0 ? H - c_w0 : 0) : kTileWaveCols; /* own columns of this wave */
-    const bev_point_t *fpts = kSrc == kSrcIdentity ? (b.pts + frame_off) : (b.pts + b.frames[f].in_offset);
-    const char *fbytes = reinterpret_cast<const char *>(fpts);
-
-    /* ---- every record the tile needs, requested at once (a lane without a slot in a row fetches the frame's first record
-     * and ignores it: no predicated loads) ---- */
-    u32x4 lo[RL], hi[RL];
-    uint32_t have = 0u; /* bit i: row r0 - 2 + i holds a record for this lane */
-#pragma unroll
-    for (int i = 0; i < RL; ++i) {
-        const int q = r0 - 2 + i;
-        const int flat = q * H + vcol;
-        const bool ok = provider && q >= 0 && q < N && flat >= 0;
-        have |= ok ? 1u << i : 0u;
-        const char *p = fbytes + (size_t)(ok ? flat : 0) * 32u;
-        lo[i] = *reinterpret_cast<const u32x4 *>(p);
-        if (i >= 2 && i < R + 2) hi[i] = *reinterpret_cast<const u32x4 *>(p + 16);
-        else hi[i] = u32x4{*reinterpret_cast<const uint32_t *>(p + 16), 0u, 0u, 0u}; /* rows around the tile: x, y, z and the intensity (their own tiles check and write them) */
-    }
-    if (tid < kMaxBands) band_cursor[tid] = 0u;
-    seen[tid] = kSkip;
-    PH(); /* issue */
-
-    uint32_t consumed = 0u, failed = 0u;
-    const uint32_t st_rowadj = v < 0 ? 1u : 0u, st_col = (uint32_t)(v < 0 ? H + v : vcol) << 16;
-    const bool st_zero_guess = kStructured && (b.info[f].failed & kInfoZeroGuess) != 0u;
-#pragma unroll
-    for (int i = 0; i < RL; ++i) {
-        const int q = r0 - 2 + i;
-        const bool rec = (have >> i) & 1u;
-        if (!rec) {
-            lo[i] = u32x4{0u, 0u, 0u, 0u};
-            hi[i] = u32x4{0u, 0u, 0u, 0u};
-        }
-        if constexpr (kStructured) { /* as k_walk<structured>: the slot's point, or all-zero; slot 0 by the probe's verified guess */
-            const bool first = (q == 0) & (vcol == 0);
-            if (i >= 2 && i < R + 2) { /* the tile's own rows (every lane checks what it holds: halo columns twice, harmlessly) */
-                const uint32_t any = lo[i].x | lo[i].y | lo[i].z | lo[i].w | hi[i].x | hi[i].y | hi[i].z | hi[i].w;
-                const bool real = hi[i].y == (((uint32_t)q - st_rowadj) | st_col);
-                failed |= (rec & !real & (any != 0u)) ? kInfoFailed : 0u;
-                failed |= (rec & (any == 0u) & !first) ? kInfoZeroSeen : 0u;
-                consumed += (rec & outcol) ? 1u : 0u;
-            }
-            if (first & st_zero_guess) {
-                lo[i] = u32x4{0u, 0u, 0u, 0u};
-                hi[i] = u32x4{0u, 0u, 0u, 0u};
-            }
-        }
-    }
-
-    const int sh_right = ((lane + 2) & 63) << 2, sh_left = ((lane - 2) & 63) << 2;
-    auto from_right2 = [&](uint32_t x) -> float { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sh_right, (int)x)); };
-    auto from_left2 = [&](uint32_t x) -> float { return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(sh_left, (int)x)); };
-    RasterParams rp = g.rp;
-    rp.max_range_f = in_vgpr(rp.max_range_f);
-    rp.lidar_to_ground = in_vgpr(rp.lidar_to_ground);
-    rp.mat_size = in_vgpr(rp.mat_size);
-    rp.n_layers = in_vgpr(rp.n_layers);
-    if (kPow2) {
-        rp.inv_interval = in_vgpr(rp.inv_interval);
-        rp.inv_height_res = in_vgpr(rp.inv_height_res);
-    } else {
-        rp.interval = in_vgpr(rp.interval);
-        rp.height_res = in_vgpr(rp.height_res);
-    }
-    const gptr<u32x2> fcand = (gptr<u32x2>)(b.cand + (size_t)f * g.segs * kSeg);
-    const gptr<uint32_t> fncand = (gptr<uint32_t>)(b.ncand + (size_t)f * g.segs);
-    const gptr<char> fordered = (gptr<char>)(b.ordered + frame_off);
-    const gptr<int8_t> fgm = (gptr<int8_t>)(kGm ? b.gm + frame_off : nullptr);
-    /* the write-out's transposition (as k_walk: halves swapped in every second group of four points: conflict-free) */
-    const int k_own = lane - 2;
-    const uint32_t xp_sw = ((uint32_t)k_own >> 2) & 1u;
-    const uint32_t xp_wlo = (uint32_t)(2 * k_own) * 16u + 16u * xp_sw, xp_whi = (uint32_t)(2 * k_own) * 16u + 16u * (xp_sw ^ 1u);
-    auto xp_unit = [&](uint32_t u) -> uint32_t { return ((u & ~1u) | ((u & 1u) ^ ((u >> 3) & 1u))) * 16u; };
-    char *xpw = &xp[wv][0];
-
-    tabs[tid] = tab_word;
-    lds_only_barrier(); /* the tables (first needed by the first row's code and key: their load has come in with the records') */
-    PH(); /* records arrived, checked */
-    int status[RL];
-#pragma unroll
-    for (int i = 0; i < RL; ++i) status[i] = kSteep;
-    uint32_t val[R], aux[R]; /* per row of the tile: a candidate's key | 0x80000000 + quarter << 8 + rank; a listed code | band << 16 + position; else aux = 0x7fffffff */
-    float zref = __uint_as_float(0x7fc00000u);
-#pragma unroll
-    for (int i = 2; i < RL; ++i) {
-        const int q = r0 - 2 + i;
-        /* ---- status of row q (BatchMultiBevGen.cpp:142-182), rows r0 .. r0 + R ---- */
-        if (q >= lo_row && q < N) { /* workgroup-uniform */
-            const XYZI cur{__uint_as_float(lo[i].x), __uint_as_float(lo[i].y), __uint_as_float(lo[i].z), __uint_as_float(hi[i].x)};
-            const XYZI prev{__uint_as_float(lo[i - 1].x), __uint_as_float(lo[i - 1].y), __uint_as_float(lo[i - 1].z), __uint_as_float(hi[i - 1].x)};
-            const XYZI prevprev{__uint_as_float(lo[i - 2].x), __uint_as_float(lo[i - 2].y), __uint_as_float(lo[i - 2].z), __uint_as_float(hi[i - 2].x)};
-            const XYZI right{from_right2(lo[i - 1].x), from_right2(lo[i - 1].y), from_right2(lo[i - 1].z), from_right2(hi[i - 1].x)};
-            const XYZI left{from_left2(lo[i - 1].x), from_left2(lo[i - 1].y), from_left2(lo[i - 1].z), from_left2(hi[i - 1].x)};
-            XYZI up = prev;                                  /* (q-1, c)                  :143     */
-            if (up.i == -1.0f) up = right;                   /* (q-1, (c+2) % H)          :146-149 */
-            if (up.i == -1.0f) up = left;                    /* flat (q-1)*H + c - 2      :151-154 */
-            if ((up.i == -1.0f) & (q >= 2)) up = prevprev;   /* (q-2, c)                  :157-160 */
-            const bool ground = angle_is_ground_nodiv(up.x - cur.x, up.y - cur.y, up.z - cur.z); /* :169-182 */
-            status[i] = ((cur.i == -1.0f) | (up.i == -1.0f)) ? kInvalid : (ground ? kGround : kSteep); /* :162-167 */
-        }
-        if (i < 3) continue;
-        /* ---- row q1 = q - 1 is decided: ground flag (closed form, bev_exact.h), candidate, code, record ---- */
-        const int i1 = i - 1, q1 = q - 1, j = i1 - 2; /* j: the tile's row 0 .. R-1 */
-        val[j] = 0u;
-        aux[j] = 0x7fffffffu;
-        if (q1 >= N) continue; /* (uniform) */
-        int gf = 0;
-        if (q1 >= lo_row) gf = (status[i1] == kInvalid) ? -1 : (status[i1] == kGround ? 1 : (status[i] == kGround ? 1 : 0));
-        else if (q1 == lo_row - 1) gf = (status[i] == kGround) ? 1 : 0;
-        const bool cand = outcol && gf == 1;
-        const float zq = __uint_as_float(lo[i1].z);
-        const int label = (int)(int16_t)(hi[i1].w & 0xffffu);
-        const bool plain = (hi[i1].w & 0xffffu) == 0xfffeu;
-        const bool pred = cand && (!plain || zq - zref >= 0.3f); /* provisional label: see k_walk */
-        if (cand && !pred) zref = zq;
-        const uint32_t code = code_t<kPow2>(__uint_as_float(lo[i1].x), __uint_as_float(lo[i1].y), zq, label, rp);
-        uint32_t q2 = 0u;
-        if (cand) {
-            int cr, cc;
-            const int cell = ground_cell_rc(__uint_as_float(lo[i1].x), __uint_as_float(lo[i1].y), &cr, &cc);
-            val[j] = candidate_key_edges(cell, wv * kTileWaveCols + k_own, pred, code, label, edge_x[cr], edge_y[cc]);
-            q2 = val[j] & 3u;
-        }
-        {   /* the wave's candidates per cell quarter; the waves' counts meet after the loop */
-            uint32_t rank;
-            const uint32_t scan = quarter_scan(cand, q2, &rank);
-            if (lane == 63) wave_cnt[j][wv] = scan;
-            if (cand) aux[j] = 0x80000000u | (q2 << 8) | rank;
-        }
-        {   /* BEV code of a slot that is not a candidate: final; listed under its raster band (k_walk: repeats dropped) */
-            bool has = outcol && !cand && code != kSkip;
-            const uint32_t left_code = (uint32_t)__builtin_amdgcn_update_dpp((int)kSkip, (int)code, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            const bool left_has = __builtin_amdgcn_update_dpp(0, has ? 1 : 0, 0x138, 0xf, 0xf, false) != 0;
-            has = has & !((lane > 0) & left_has & (left_code == code));
-            const uint32_t slot = (code * 0x9E3779B1u) >> 24;
-            const uint32_t remembered = seen[slot];
-            const int band = band_tab[code_x(code) & 511];
-            has = has & (remembered != code);
-            if (has) {
-                seen[slot] = code;
-                val[j] = code;
-                aux[j] = ((uint32_t)band << 16) | atomicAdd(&band_cursor[band], 1u);
-            }
-        }
-        {   /* the ordered cloud's row q1, as whole lines */
-            u32x4 h1 = hi[i1];
-            if (cand && !pred) h1.w &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
-            if (outcol) {
-                *reinterpret_cast<u32x4 *>(xpw + xp_wlo) = lo[i1];
-                *reinterpret_cast<u32x4 *>(xpw + xp_whi) = h1;
-            }
-            asm volatile("" ::: "memory");
-            const u32x4 pa = *reinterpret_cast<const u32x4 *>(xpw + xp_unit((uint32_t)lane));
-            const u32x4 pb = *reinterpret_cast<const u32x4 *>(xpw + xp_unit(64u + (uint32_t)lane));
-            asm volatile("" ::: "memory");
-            const gptr<char> orow = fordered + ((size_t)q1 * H + c_w0) * 32u;
-            if (lane < 2 * n_own) __builtin_nontemporal_store(pa, (gptr<u32x4>)(orow + lane * 16));
-            if (64 + lane < 2 * n_own) __builtin_nontemporal_store(pb, (gptr<u32x4>)(orow + (64 + lane) * 16));
-            if (kGm && outcol) fgm[(uint32_t)(q1 * H + v)] = (int8_t)gf;
-        }
-    }
-
-    PH(); /* rows */
-    lds_only_barrier(); /* every wave's candidate counts and code cursors (the rows' stores stay in flight) */
-    PH(); /* barrier (drains the rows' stores) */
-    if (tid < bands) { /* the workgroup's share of the strip's code lists */
-        const uint32_t n = band_cursor[tid];
-        band_base[tid] = n ? atomicAdd(&b.ncode[((size_t)f * g.emitters + strip) * bands + tid], n) : 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        const int q1 = r0 + j, rr = q1 - (lo_row - 1);
-        if (q1 >= N || rr < 0) continue; /* (uniform) only rows lo-1 .. N-1 can hold candidates */
-        const u32x4 wc = *reinterpret_cast<const u32x4 *>(&wave_cnt[j][0]);
-        const uint32_t total = wc.x + wc.y + wc.z + wc.w; /* four byte-wide sums (a segment's quarters hold at most 236 each) */
-        const uint32_t before = (wv > 0 ? wc.x : 0u) + (wv > 1 ? wc.y : 0u) + (wv > 2 ? wc.z : 0u);
-        const uint32_t seg = (uint32_t)(rr * strips + strip);
-        if (aux[j] & 0x80000000u) {
-            const uint32_t t8 = total << 8;
-            const uint32_t starts = t8 + (t8 << 8) + (t8 << 16) + before;
-            const uint32_t pos = __builtin_amdgcn_ubfe(starts, ((aux[j] >> 8) & 3u) << 3, 8u) + (aux[j] & 63u);
-            fcand[seg * (uint32_t)kSeg + pos] = u32x2{val[j], lo[j + 2].z};
-        }
-        if (tid == 2) fncand[seg] = total;
-    }
-    PH(); /* candidates */
-    lds_only_barrier(); /* band_base */
-    PH(); /* barrier (the reservation's atomics) */
-    {
-        const gptr<uint32_t> flist = (gptr<uint32_t>)(b.code_main + ((size_t)f * g.emitters + strip) * bands * (size_t)g.code_stride);
-        const uint32_t code_last = g.code_cap - 1u;
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            if (aux[j] >= 0x7fffffffu) continue; /* no code to list (or a candidate) */
-            const uint32_t band = aux[j] >> 16, pos = band_base[band] + (aux[j] & 0xffffu);
-            flist[band * g.code_stride + (pos < code_last ? pos : code_last)] = val[j];
-        }
-    }
-    if constexpr (kStructured) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            consumed += __shfl_xor(consumed, d);
-            failed |= __shfl_xor(failed, d);
-        }
-        if (lane == 0) {
-            if (consumed) atomicAdd(&b.info[f].consumed, consumed);
-            if (failed) atomicOr(&b.info[f].failed, failed);
-        }
-    }
-    PH();
-    PH_PRINT("tile issue arrive rows barrier cands barrier codes", lane == 0 && (blockIdx.x == 3000 || blockIdx.x == 20001 || blockIdx.x == 30007));
 }
 
 /* getOrderedCloud alone (bev_order_cloud): no ground work. */
@@ -2568,23 +2262,6 @@ void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int sou
     else if (source == kSrcStructured) launch_walk<kSrcStructured>(g, b, nf, mode, grid, st);
     else if (source == kSrcColMajor) launch_walk<kSrcColMajor>(g, b, nf, mode, grid, st);
     else launch_walk<kSrcGather>(g, b, nf, mode, grid, st);
-}
-void launch_tile_walk(const Geometry &g, const BatchPtrs &b, int nf, int source, uint32_t mode, hipStream_t st)
-{
-    if (nf == 0) return;
-    const bool pow2 = g.rp.inv_interval != 0.0f && g.rp.inv_height_res != 0.0f;
-    const int tiles = g.strips * ((g.N + kTileRows - 1) / kTileRows);
-    const dim3 gr(xcd_grid(nf, tiles)), bl(kStripThreads);
-#define BEV_TILE_LAUNCH(SRC)                                                                                  \
-    do {                                                                                                      \
-        if (pow2 && !b.gm) hipLaunchKernelGGL((k_tile<SRC, true, false>), gr, bl, 0, st, b, g, nf, mode);     \
-        else if (pow2) hipLaunchKernelGGL((k_tile<SRC, true, true>), gr, bl, 0, st, b, g, nf, mode);          \
-        else if (!b.gm) hipLaunchKernelGGL((k_tile<SRC, false, false>), gr, bl, 0, st, b, g, nf, mode);       \
-        else hipLaunchKernelGGL((k_tile<SRC, false, true>), gr, bl, 0, st, b, g, nf, mode);                   \
-    } while (0)
-    if (source == kSrcIdentity) BEV_TILE_LAUNCH(kSrcIdentity);
-    else BEV_TILE_LAUNCH(kSrcStructured);
-#undef BEV_TILE_LAUNCH
 }
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st)
 {

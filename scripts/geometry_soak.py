@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random SENSOR GEOMETRIES (N_SCAN, Horizon_SCAN, GROUND_UPPER_SCAN, HEIGHT_RES, interval) through the whole hot path, every
 layout, every frame against the oracle: what depends on how the columns fall into strips, waves and raster bands (round 4's
-one-column last strip was such a case).  Column counts are biased towards multiples of 236 (the walk's strip), 59 (k_tile's
+one-column last strip was such a case).  Column counts are biased towards multiples of 236 (the walk's strip), 59 (a quarter strip:
 wave) and 64, plus or minus a few.
 usage (GPU box): python3 scripts/geometry_soak.py [seed] [geometries]"""
 import os, sys, time
@@ -43,11 +43,7 @@ for it in range(count):
     frames = [inv(synth.sweep(p, it, keep=float(rng.choice([1.0, 0.98, 0.7])), n_dup=int(rng.choice([0, 50, 700])))), st,
               inv(synth.firing_order(p, it)), synth.adversarial(p, int(rng.integers(1, 2 * n * h + 2)), it, bool(it % 2)),
               np.empty(0, bev_amd.POINT_DTYPE), inv(synth.sweep(p, it + 7, keep=0.9, n_dup=0))]
-    os.environ["BEV_TILE"] = str(it % 2)
-    try:
-        ctx = bev_amd.BevContext(p, device=0, max_batch=16, max_points=max(8, max(len(f) for f in frames)))
-    finally:
-        os.environ.pop("BEV_TILE", None)
+    ctx = bev_amd.BevContext(p, device=0, max_batch=16, max_points=max(8, max(len(f) for f in frames)))
     try:
         ordered, multi, single, gm = ctx.process_batch(frames, want_ground_mat=True)
         info = ctx.frame_info(0, len(frames))
@@ -63,7 +59,7 @@ for it in range(count):
                         and np.array_equal(single[i], orc.single_bev(o_ord, p.interval).reshape(M, M))
             if not ok:
                 bad += 1
-                print(f"MISMATCH geometry N={n} H={h} G={g} res={p.height_res} interval={p.interval} tile={it % 2} frame {i} mode {int(info[i, 1])}", flush=True)
+                print(f"MISMATCH geometry N={n} H={h} G={g} res={p.height_res} interval={p.interval} frame {i} mode {int(info[i, 1])}", flush=True)
     finally:
         ctx.close()
     if (it + 1) % 50 == 0:

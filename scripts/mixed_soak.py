@@ -54,9 +54,8 @@ for rnd in range(rounds):
     with ThreadPoolExecutor(16) as ex:
         frames = list(ex.map(lambda a: make(a[1], 100000 * rnd + a[0]), enumerate(kinds)))
     os.environ["BEV_LANES"] = str(lanes)
-    os.environ["BEV_TILE"] = str(rnd % 2)
     ctx = bev_amd.BevContext(p, device=0, max_batch=sub, max_points=max(len(f) for f in frames))
-    os.environ.pop("BEV_LANES"); os.environ.pop("BEV_TILE")
+    os.environ.pop("BEV_LANES")
     offs = np.zeros(n + 1, np.uint64); offs[1:] = np.cumsum([len(f) for f in frames])
     d_in = torch.from_numpy(np.concatenate(frames).view(np.uint8).reshape(-1)).to(dev)
     outs = [torch.zeros(n * k, dtype=torch.uint8, device=dev) for k in (S * 32, L * M * M, M * M)]
@@ -76,6 +75,6 @@ for rnd in range(rounds):
     with ThreadPoolExecutor(16) as ex:
         bad = [i for i, ok in enumerate(ex.map(check, range(n))) if not ok]
     bad_total += len(bad)
-    print(f"round {rnd}: {n} frames, sub-batch {sub}, {lanes} sets, tile {rnd % 2}: {len(bad)} differ {[(i, kinds[i]) for i in bad[:5]]}", flush=True)
+    print(f"round {rnd}: {n} frames, sub-batch {sub}, {lanes} sets: {len(bad)} differ {[(i, kinds[i]) for i in bad[:5]]}", flush=True)
 print(f"mixed soak ({sensor}): seed {seed}, {rounds} rounds, {bad_total} mismatches, modes of the last sub-batches {modes}, {time.time() - t00:.0f} s")
 sys.exit(1 if bad_total else 0)
