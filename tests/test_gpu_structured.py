@@ -139,10 +139,12 @@ def test_knob_off_and_sensors_the_in_place_source_cannot_take():
     assert modes == [STRUCTURED, GENERAL]
 
 
-def test_a_walk_that_was_not_launched_costs_time_not_results():
-    """The host launches the walk of a mode only while the workspace set's last sub-batch had frames of that mode (a hint
-    k_verdict leaves in mapped host memory).  A structured cloud that arrives after sweeps finds its walk not launched:
-    its count fails, it is redone the general way (mode 2) — same outputs — and the next call sees the mode again."""
+def test_a_walk_that_was_not_launched_costs_time_not_results(monkeypatch):
+    """The host launches the walk of a mode only while the workspace set's last BEV_MODE_TTL looks at k_verdict's word
+    (mapped host memory: the modes k_probe gave the set's last finished sub-batch) showed the mode.  With a TTL of 1
+    (round 4's rule) a structured cloud that arrives after sweeps finds its walk not launched: its count fails, it is
+    redone the general way (mode 2) — same outputs — and the next call sees the mode again."""
+    monkeypatch.setenv("BEV_MODE_TTL", "1")
     p = bev_amd.params_for_sensor("HDL_32E")
     sp = orc.sensor_from_params(p)
     calls = [[synth.sweep(p, 60 + i, n_dup=300) for i in range(3)], [synth.structured(p, 63 + i, 0.9) for i in range(3)],
@@ -159,5 +161,30 @@ def test_a_walk_that_was_not_launched_costs_time_not_results():
                 assert ordered[i].tobytes() == o_ord.tobytes() and np.array_equal(gm[i], o_gm), (want, i)
                 assert np.array_equal(multi[i], o_multi) and np.array_equal(single[i], o_single), (want, i)
             assert modes == want, (modes, want)
+    finally:
+        ctx.close()
+
+
+def test_alternating_layouts_are_read_in_place_after_warm_up():
+    """Round 5 (advisor, round 4): the mode hint is sticky (default TTL 8 looks per workspace set).  Calls that alternate
+    layouts — sweeps, structured clouds, firing order, one after the other — are all read in place: no frame is redone."""
+    p = bev_amd.params_for_sensor("HDL_32E")
+    sp = orc.sensor_from_params(p)
+    makers = [lambda i: synth.sweep(p, 200 + i, n_dup=300), lambda i: synth.structured(p, 200 + i, 0.9),
+              lambda i: synth.firing_order(p, 200 + i)]
+    want = [STREAM, STRUCTURED, COLMAJOR]
+    frames0 = [m(0) for m in makers]
+    ctx = bev_amd.BevContext(p, device=0, max_batch=16, max_points=max(len(f) for f in frames0))
+    try:
+        for rnd in range(12):
+            k = rnd % 3
+            frames = [makers[k](3 * rnd + j) for j in range(2)]
+            ordered, multi, single, gm = ctx.process_batch(frames, want_ground_mat=True)
+            modes = [int(m) for m in ctx.frame_info(0, len(frames))[:, 1]]
+            assert modes == [want[k]] * 2, (rnd, modes)
+            for i, pts in enumerate(frames):
+                o_ord, o_gm, o_multi, o_single = orc.process_frame(sp, pts)
+                assert ordered[i].tobytes() == o_ord.tobytes() and np.array_equal(gm[i], o_gm), (rnd, i)
+                assert np.array_equal(multi[i], o_multi) and np.array_equal(single[i], o_single), (rnd, i)
     finally:
         ctx.close()
