@@ -23,7 +23,7 @@ constexpr int kStripCols = 236;                 /* (256 input positions cover th
 constexpr int kStripVirt = kStripCols + 4;
 constexpr int kSeg = 256;                       /* capacity of one candidate segment = one (row, strip) */
 constexpr int kMaxSegs = 1024;                  /* (G + 1) * strips must not exceed this (bev_create checks) */
-constexpr int kGndThreads = 512;  /* k_ground: phases B and C, four workgroups per frame (cells by cell mod 4) */
+constexpr int kGndThreads = 256;  /* k_ground: phases B and C, four workgroups per frame (cells by cell mod 4), the size of a column-walk workgroup */
 constexpr int kResolveParts = 4;  /* code lists per frame written by phase C: one per cell quarter */
 #ifndef BEV_RASTER_THREADS
 #define BEV_RASTER_THREADS 512 /* (overridable for `make exp`: bev_kernels.hip is the only user) */

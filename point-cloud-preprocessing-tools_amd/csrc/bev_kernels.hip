@@ -1400,28 +1400,28 @@ constexpr int kCells = kGridCells;
 constexpr int kSumQ = 4;                               /* workgroups per frame: cells by cell mod 4 */
 static_assert(kSumQ == kResolveParts, "one code list set per quarter");
 constexpr int kGndWaves = kGndThreads / 64;
-constexpr int kGndSlots = 8;                           /* slices a wave works on per part */
+constexpr int kGndSlots = 16;                          /* slices a wave keeps in registers per part */
 constexpr int kPartSlices = kGndWaves * kGndSlots;     /* 64 slices = at most 4096 candidates per part */
-constexpr int kGndKeep = 4;                            /* parts whose candidates stay in registers until phase C */
 constexpr uint32_t kMeetSpins = 1u << 22;              /* polls (>= 1 us each) before a workgroup gives up on its siblings */
+constexpr int kHitSlots = 4; /* phase C: slices a wave tests at a time; their hits are gathered before it builds their codes */
 struct GndDims {
     static constexpr int cells = (kCells + kSumQ - 1) / kSumQ;
     static constexpr int hist_stride = ((cells + 1) / 2 + 3) / 4 * 4; /* words per wave's histogram: two 16-bit counters per word */
     static constexpr int touch_words = (cells + 31) / 32;
     static constexpr int tlist_words = ((cells + 1) / 2 + 3) / 4 * 4;
     /* hist, start, zbuf (these three also: phase C's per-wave hit lists), sumv, cntv (also: minavg, the context's tables),
-     * tbits, tlist (u16), misc, then per segment: cpre (u32, T + 1), adj (i32, T), seg0 (u32, T) */
+     * tbits, tlist (u16), misc, then per segment: cpre (u32, T + 1), rs8 (u8, T) */
     static constexpr size_t front_words = (size_t)kGndWaves * hist_stride + cells + (size_t)kPartSlices * 64;
     static constexpr size_t fixed_words = front_words + 2 * (size_t)cells + 32 + tlist_words + 16;
-    static constexpr size_t seg_words(int T) { return (size_t)(T + 1) + 2 * (size_t)T; }
-    static constexpr size_t lds_bytes(int T) { return sizeof(uint32_t) * (fixed_words + seg_words(T)); } /* HDL_64E (459 segments): 49 KB */
+    static constexpr size_t seg_words(int T) { return (size_t)(T + 1) + (size_t)(T + 3) / 4; }
+    static constexpr size_t lds_bytes(int T) { return sizeof(uint32_t) * (fixed_words + seg_words(T)); } /* HDL_64E (459 segments): 39.6 KB — four per CU, and one fits wherever a walk workgroup has left */
     static_assert(front_words >= (size_t)kCells, "the frame's averages fit phase B's buffers");
-    static_assert(front_words >= (size_t)kGndWaves * kGndSlots * 64 * 2, "a part's hit lists (key | height, 8 x 64 per wave) fit phase B's buffers");
+    static_assert(front_words >= (size_t)kGndWaves * kHitSlots * 64 * 2, "the hit lists (key | height, kHitSlots x 64 per wave) fit phase B's buffers");
     static_assert(2 * cells >= cells + kCtxTabWords + kMaxBands, "minavg, the tables and the band cursors fit the sums' words");
     static_assert(touch_words <= 32, "one word of marks per lane of half a wave");
 };
 static_assert(kPartSlices * 64 <= 4096, "a part's run start (12 bits) and length (13 bits) share a word with room to spare");
-static_assert(2 * kGndThreads >= kMaxSegs, "every thread takes two segments");
+static_assert(4 * kGndThreads >= kMaxSegs, "every thread takes four segments");
 size_t ground_lds_bytes(int segs) { return GndDims::lds_bytes(segs); }
 
 template <bool kPow2>
@@ -1437,17 +1437,16 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
     float *cntv = sumv + kCellsQ;                          /* [kCellsQ] running counts */
     uint32_t *tbits = reinterpret_cast<uint32_t *>(cntv + kCellsQ); /* [32]: cells this part has touched */
     uint16_t *tlist = reinterpret_cast<uint16_t *>(tbits + 32); /* [kCellsQ]: ... listed, in any order */
-    uint32_t *misc = tbits + 32 + D::tlist_words;          /* [0..1] list lengths (by part parity), [2] gave up, [4..11] wave sums, [12] carry */
+    uint32_t *misc = tbits + 32 + D::tlist_words;          /* [0..1] list lengths (by part parity), [2] gave up, [4..7] wave sums, [12] carry */
     const int T = g.segs;
     uint32_t *cpre = misc + 16;                            /* [T + 1]: this quarter's candidates before segment t */
-    int *adj = reinterpret_cast<int *>(cpre + T + 1);      /* [T]: candidate i of the quarter's stream, if it lies in segment t, is cand[adj[t] + i] */
-    uint32_t *seg0 = reinterpret_cast<uint32_t *>(adj + T); /* [T]: flat slot index of segment t's column offset 0 */
+    uint8_t *rs8 = reinterpret_cast<uint8_t *>(cpre + T + 1); /* [T]: where this quarter's run starts inside segment t */
     uint16_t *hist16 = reinterpret_cast<uint16_t *>(hist); /* the same counters, cell c of wave w at [w * 2 * kHistStride + c] */
 
     int f, quarter;
     if (!map_block_xcd(blockIdx.x, nf, kSumQ, f, quarter)) return; /* the quarters of a frame on one XCD: they read the same lines */
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint2 *ccand = b.cand + (size_t)f * T * kSeg; /* key | height */
+    const gptr<const u32x2> gcand = (gptr<const u32x2>)(b.cand + (size_t)f * T * kSeg); /* key | height */
     const uint32_t *fn = b.ncand + (size_t)f * T;
     const int H = g.H, strips = g.strips, lo_row = g.N - g.G;
     PH_DECL;
@@ -1461,21 +1460,17 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
         cntv[c] = 0.01f;  /* :135-136 */
     }
     /* this quarter's run of every segment (where it starts inside the segment) and the number of the quarter's candidates
-     * before it.  The walk wrote a segment's four counts as four bytes; T <= kMaxSegs = 2 * 512: every thread takes two
+     * before it.  The walk wrote a segment's four counts as four bytes; T <= kMaxSegs = 4 * 256: every thread takes four
      * consecutive segments */
     {
-        uint32_t cq[2], rs[2], mine = 0u;
+        uint32_t cq[4], rs[4], mine = 0u;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int t = 2 * tid + k;
+        for (int k = 0; k < 4; ++k) {
+            const int t = 4 * tid + k;
             const uint32_t w = t < T ? fn[t] : 0u;
             const uint32_t sh = 8u * (uint32_t)quarter;
             cq[k] = (w >> sh) & 0xffu;
             rs[k] = ((w * 0x01010100u) >> sh) & 0xffu; /* the quarters below it (no byte exceeds the segment's 236) */
-            if (t < T) {
-                const int rr = t / strips, strip = t - rr * strips;
-                seg0[t] = (uint32_t)((rr + lo_row - 1) * H + strip * kStripCols);
-            }
             mine += cq[k];
         }
         uint32_t incl = mine;
@@ -1489,37 +1484,40 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
         uint32_t base = incl - mine;
         for (int w = 0; w < wv; ++w) base += misc[4 + w];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int t = 2 * tid + k;
+        for (int k = 0; k < 4; ++k) {
+            const int t = 4 * tid + k;
             if (t <= T) cpre[t] = base;
-            if (t < T) adj[t] = t * kSeg + (int)rs[k] - (int)base;
+            if (t < T) rs8[t] = (uint8_t)rs[k];
             base += cq[k];
         }
-        if (tid == kGndThreads - 1 && 2 * kGndThreads <= T) cpre[T] = base; /* (T == 1024 exactly) */
+        if (tid == kGndThreads - 1 && 4 * kGndThreads <= T) cpre[T] = base; /* (T == 1024 exactly) */
         lds_barrier();
         if (tid < kGndWaves) misc[4 + tid] = 0u;
     }
     const int GC = (int)cpre[T];                              /* candidates of this quarter */
     const int G = (GC + 63) >> 6;                             /* slices */
     const int P = (G + kPartSlices - 1) / kPartSlices;
-    auto slice_n = [&](int p, int j) -> int { /* candidates in slice j of this wave in part p (wave-uniform; 0: no such slice) */
-        const int gs = p * kPartSlices + wv * kGndSlots + j;
+    auto slice_count = [&](int gs) -> int { /* candidates in slice gs of the quarter's stream (0: no such slice) */
         return gs < G ? (GC - 64 * gs < 64 ? GC - 64 * gs : 64) : 0;
     };
+    auto slice_n = [&](int p, int j) -> int { /* ... in slice j of this wave in part p (wave-uniform) */
+        return slice_count(p * kPartSlices + wv * kGndSlots + j);
+    };
 
-    /* A wave's slices of part p are slices p * 64 + 8 * wave + j.  Lane j <= 8 finds the segment of slice j's first
+    /* A wave's slices of part p are slices p * 64 + 16 * wave + j.  Lane j <= 16 finds the segment of slice j's first
      * candidate by itself (binary search over the candidate prefix: the searches run side by side); a slice then spans
      * the segments from its own start to the next slice's, and a lane's segment is the slice's first plus the segment
      * starts at or before the lane's candidate (a slice spans two or three segments: a quarter's run of a segment is
      * 35 candidates on average). */
     auto seg_of = [&](int t0, int t1, uint32_t i) -> int { /* (wave-uniform trip count, broadcast reads) */
         int t = t0;
-        for (int u = t0 + 1; u <= t1; ++u) t += cpre[u] <= i ? 1 : 0;
+#pragma unroll 1
+        for (int u = t0 + 1; u <= t1; ++u) t += cpre[u] <= i ? 1 : 0; /* (one to three turns: hipcc unrolls this sixteen-fold otherwise) */
         return t;
     };
-    auto request = [&](int p, uint32_t (&key)[kGndSlots], float (&z)[kGndSlots], int &lo_out) {
-        const int g0 = p * kPartSlices + wv * kGndSlots;
-        const int gl = g0 + (lane < kGndSlots + 1 ? lane : kGndSlots);
+    auto request = [&](auto NS, int g0, uint32_t (&key)[decltype(NS)::value], float (&z)[decltype(NS)::value], int &lo_out) { /* slices g0 .. g0 + NS - 1 */
+        constexpr int kN = decltype(NS)::value;
+        const int gl = g0 + (lane < kN + 1 ? lane : kN);
         int lo = 0;
         if (gl < G) {
             const uint32_t x = 64u * (uint32_t)gl;
@@ -1533,37 +1531,50 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
         }
         lo_out = lo;
 #pragma unroll
-        for (int j = 0; j < kGndSlots; ++j) {
+        for (int j = 0; j < kN; ++j) {
             key[j] = 0u;
             z[j] = 0.f;
             if (g0 + j < G) { /* wave-uniform */
                 const uint32_t i = 64u * (uint32_t)(g0 + j) + (uint32_t)lane; /* this lane's candidate (past the end in the last slice) */
-                const int t = seg_of(__builtin_amdgcn_readlane(lo, j), __builtin_amdgcn_readlane(lo, j + 1), i);
+                /* the lane's segment: the slice's first plus the segment starts at or before the lane's candidate — the
+                 * next three without a loop (their reads are requested side by side; a loop over them waits for the LDS
+                 * at every turn: 5.7 us per part against 2), the rest, if the slice spans more, by seg_of */
+                const int t0 = __builtin_amdgcn_readlane(lo, j), t1 = __builtin_amdgcn_readlane(lo, j + 1);
+                int t = t0;
+#pragma unroll
+                for (int k = 1; k <= 3; ++k) {
+                    const int u = t0 + k < t1 ? t0 + k : t1; /* (uniform) */
+                    t += (cpre[u] <= i && t0 + k <= t1) ? 1 : 0;
+                }
+                if (t1 - t0 > 3) t += seg_of(t0 + 3, t1, i) - (t0 + 3); /* (uniform, rare) */
                 /* lanes past the stream's end read the last run's stale tail (allocated memory) and are masked where
                  * the values are used */
-                const uint2 kz = ccand[adj[t] + (int)i];
+                const u32x2 kz = gcand[(uint32_t)t * (uint32_t)kSeg + rs8[t] + (i - cpre[t])]; /* (scalar base + 32-bit offset) */
                 key[j] = kz.x;
                 z[j] = __uint_as_float(kz.y);
             }
         }
     };
+    const std::integral_constant<int, kGndSlots> kPartN{};
 
     uint32_t *myhist = hist + wv * kHistStride;
     PHA_DECL;
     /* one part: rank, scan, place, sum (the keys and heights are the caller's registers) */
-    auto do_part = [&](int p, const uint32_t (&key)[kGndSlots], const float (&z)[kGndSlots]) {
+    auto do_part = [&](int p, uint32_t (&enc)[kGndSlots], const float (&z)[kGndSlots]) { /* enc: in: the slot's cell in the quarter (0xfff: no candidate); out: cell | rank << 12 | size << 18 */
         PHA(7);
         const int par = p & 1;
-        uint32_t enc[kGndSlots]; /* cell | rank << 12 | size << 18 (0xfff: no candidate) */
 #pragma unroll
         for (int j = 0; j < kGndSlots; ++j) {
-            const int n = slice_n(p, j);
-            enc[j] = 0xfffu;
-            if (n == 0) continue; /* wave-uniform */
-            const uint32_t c = lane < n ? ((key[j] & kKeyCellMask) >> 2) : 0xfffu;
+            if (slice_n(p, j) == 0) continue; /* wave-uniform */
+            const uint32_t c = enc[j];
+            /* Lanes of a 64-slice that hold the same cell find each other in one turn per distinct cell of the slice (4 on
+             * average in a benchmark frame, 13 at most): the cell of the first lane still without a group, the lanes that
+             * hold it, their ranks (v_mbcnt) and the group's size (s_bcnt1) — a dozen instructions per turn, half of them
+             * scalar, no branch inside.  (Rounds 3-4: one ballot per bit of the cell number, ten per slice, 80 vector
+             * instructions whatever the slice held; same box, the loop is 9 % ahead in this kernel's time.) */
             unsigned long long rem = __ballot(c != 0xfffu);
             uint32_t e = 0xfffu;
-            while (rem) { /* one turn per distinct cell of the slice, no branch inside: a dozen instructions, half of them scalar */
+            while (rem) {
                 const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)c, __ffsll((long long)rem) - 1);
                 const bool mine = c == cc;
                 const unsigned long long m = __ballot(mine);
@@ -1664,57 +1675,69 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
             int q = (int)(se & 0xffffu);
             const int e = q + (int)(se >> 16);
             float sj = sumv[c];
+            __builtin_amdgcn_s_setprio(3); /* the chain below is what the other waves of the workgroup wait for */
             /* the count of the run in one go (bev_exact.h: the reference's "cnt = cnt + 1" steps are exact inside a
              * binade): the loop below is the sum's chain alone */
             cntv[c] = count_advance(cntv[c], se >> 16); /* :205-206 */
-            /* the adds of one cell are a serial chain (that IS the reference's order); what can be hidden is the LDS
-             * latency: the next 8 heights are requested before the current 8 are added */
-            if (q + 8 <= e) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = zbuf[q + u];
+            /* the adds of one cell are a serial chain (that IS the reference's order): what can be saved is everything
+             * around the additions.  The heights come as 16-byte reads, THREE reads ahead of their use (a read requested one
+             * quad ahead was waited for in every turn: 16 cycles per addition), into four register quads that take turns
+             * (no moves). */
+            for (; q < e && (q & 3); ++q) sj += zbuf[q];
+            {
+                const float4 *z4 = reinterpret_cast<const float4 *>(zbuf);
+                auto add4 = [&](const float4 &v) { sj += v.x; sj += v.y; sj += v.z; sj += v.w; }; /* :198-199 */
+                if (q + 12 <= e) {
+                    float4 a = z4[q >> 2], bq = z4[(q >> 2) + 1], cq = z4[(q >> 2) + 2];
 #pragma unroll 1
-                for (; q + 16 <= e; q += 8) {
-                    float nx[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) nx[u] = zbuf[q + 8 + u];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) sj += v[u]; /* :198-199 */
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = nx[u];
+                    while (q + 28 <= e) { /* at the top: a, bq, cq = quads q, q + 4, q + 8 */
+                        const float4 dq = z4[(q >> 2) + 3];
+                        add4(a);
+                        a = z4[(q >> 2) + 4];
+                        add4(bq);
+                        bq = z4[(q >> 2) + 5];
+                        add4(cq);
+                        cq = z4[(q >> 2) + 6];
+                        add4(dq);
+                        q += 16;
+                    }
+                    add4(a);
+                    add4(bq);
+                    add4(cq);
+                    q += 12;
                 }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) sj += v[u];
-                q += 8;
+#pragma unroll 1
+                for (; q + 4 <= e; q += 4) add4(z4[q >> 2]);
             }
 #pragma unroll 1
             for (; q < e; ++q) sj += zbuf[q];
             sumv[c] = sj;
+            __builtin_amdgcn_s_setprio(0);
         }
         lds_barrier(); /* the next part overwrites start and zbuf; hist and tbits are clean */
         PHA(4);
     };
 
-    /* ---- phase B, in rounds of kGndKeep parts: every candidate of a round is requested before the first is used, and
-     * the LAST round's candidates (a benchmark frame has one round) stay in registers for phase C ---- */
-    uint32_t kkey[kGndKeep][kGndSlots];
-    float kz[kGndKeep][kGndSlots];
-    int klo[kGndKeep];
-    auto request_round = [&](int r) {
-#pragma unroll
-        for (int q = 0; q < kGndKeep; ++q) request(r * kGndKeep + q, kkey[q], kz[q], klo[q]);
-    };
-    const int R = (P + kGndKeep - 1) / kGndKeep;
+    /* ---- phase B: keys and heights one part ahead (the next part's loads are in flight while a part is worked on) ---- */
+    uint32_t nkey[kGndSlots];
+    float nz[kGndSlots];
+    int nlo;
+    request(kPartN, wv * kGndSlots, nkey, nz, nlo);
     lds_barrier(); /* LDS state initialised */
     PH();
 #pragma unroll 1
-    for (int r = 0; r < R; ++r) {
-        request_round(r);
+    for (int p = 0; p < P; ++p) {
+        uint32_t cell[kGndSlots];
+        float zz[kGndSlots];
 #pragma unroll
-        for (int q = 0; q < kGndKeep; ++q)
-            if (r * kGndKeep + q < P) do_part(r * kGndKeep + q, kkey[q], kz[q]); /* (workgroup-uniform) */
+        for (int j = 0; j < kGndSlots; ++j) {
+            cell[j] = lane < slice_n(p, j) ? ((nkey[j] & kKeyCellMask) >> 2) : 0xfffu;
+            zz[j] = nz[j];
+        }
+        request(kPartN, (p + 1) * kPartSlices + wv * kGndSlots, nkey, nz, nlo);
+        do_part(p, cell, zz);
     }
-    PHA_PRINT("ground tlist - scan place sum - rank looptop", tid == 0 && blockIdx.x == 100);
+    PHA_PRINT("ground tlist - scan place sum - rank looptop", tid == 0 && blockIdx.x == 1500);
     PH();
 
     /* ---- the quarter's averages; meet the frame's other three quarters ---- */
@@ -1755,7 +1778,7 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
     const int *edge_x = reinterpret_cast<const int *>(tabs), *edge_y = edge_x + kGridRows;
     const uint8_t *band_tab = reinterpret_cast<const uint8_t *>(tabs + kGridRows + kGridCols);
     uint32_t *band_cursor = tabs + kCtxTabWords;                /* [kMaxBands] */
-    uint2 *hits = reinterpret_cast<uint2 *>(lds) + (size_t)wv * kGndSlots * 64; /* this wave's un-grounded candidates of a part: key | height */
+    uint2 *hits = reinterpret_cast<uint2 *>(lds) + (size_t)wv * kHitSlots * 64; /* this wave's un-grounded candidates of kHitSlots slices: key | height */
     const bool gave_up = misc[2] != 0u;
     for (int c = tid; c < kCells; c += kGndThreads) avg_all[c] = __hip_atomic_load(favg + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lds_barrier(); /* (the sums have been read: their words take minavg and the tables) */
@@ -1804,11 +1827,23 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
     /* A part's candidates against their cells' thresholds.  The un-grounded ones ("hits", an eighth of a benchmark
      * frame's candidates, in every slice) are first gathered per wave — their codes are then built from full waves of
      * hits instead of once per slice for a handful of lanes; wrong guesses (2 %) are patched on the spot. */
-    auto resolve = [&](int p, const uint32_t (&key)[kGndSlots], const float (&z)[kGndSlots], int lo) {
+    auto flush = [&](uint32_t &n_hits) { /* (this wave's own list: written and read in program order) */
+        for (uint32_t h0 = 0; h0 < n_hits; h0 += 64u) {
+            const bool on = h0 + (uint32_t)lane < n_hits;
+            const uint2 e = hits[on ? h0 + (uint32_t)lane : 0u];
+            const uint32_t cell = e.x & kKeyCellMask;
+            const uint32_t code = code_from_bins_t<kPow2>(edge_x[cell / kGridCols] + (int)((e.x >> kKeyDxShift) & 3u),
+                                                          edge_y[cell % kGridCols] + (int)((e.x >> kKeyDyShift) & 3u), __uint_as_float(e.y), rp);
+            list_code(on ? code : kSkip);
+        }
+        n_hits = 0u;
+    };
+    const uint32_t strips_magic = small_div_magic(strips); /* t / strips for t < 1024 (t * (magic * strips - 2^20) < 2^20) */
+    auto resolve = [&](int gs0, const uint32_t (&key)[kHitSlots], const float (&z)[kHitSlots], int lo) { /* slices gs0 .. gs0 + kHitSlots - 1 */
         uint32_t n_hits = 0u; /* (wave-uniform) */
 #pragma unroll
-        for (int j = 0; j < kGndSlots; ++j) {
-            const int n = slice_n(p, j);
+        for (int j = 0; j < kHitSlots; ++j) {
+            const int n = slice_count(gs0 + j);
             if (n == 0) continue; /* wave-uniform */
             const uint32_t kk = key[j];
             const bool have = lane < n;
@@ -1822,9 +1857,10 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
                 hits[n_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u))] = make_uint2(kk, __float_as_uint(z[j]));
             n_hits += (uint32_t)__popcll(lm);
             if (__ballot(wrong || escapes)) { /* (wave-uniform) the flat slot index: the candidate's segment + its column inside the strip */
-                const uint32_t i = 64u * (uint32_t)(p * kPartSlices + wv * kGndSlots + j) + (uint32_t)lane;
+                const uint32_t i = 64u * (uint32_t)(gs0 + j) + (uint32_t)lane;
                 const int t = seg_of(__builtin_amdgcn_readlane(lo, j), __builtin_amdgcn_readlane(lo, j + 1), have ? i : 0u);
-                const uint32_t idx = seg0[t] + ((kk >> kKeyColShift) & 0xffu);
+                const int rr = small_div(t, strips_magic), strip = t - rr * strips; /* segment t = (row lo_row - 1 + rr, strip) */
+                const uint32_t idx = (uint32_t)((rr + lo_row - 1) * H + strip * kStripCols) + ((kk >> kKeyColShift) & 0xffu);
                 if (escapes) {
                     const float4 a = *reinterpret_cast<const float4 *>(fordered + idx);
                     list_code(code_t<kPow2>(a.x, a.y, a.z, 1 /* not 0: no kKeyNoCodeBit */, rp));
@@ -1834,28 +1870,33 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
                 if (wrong) flabel[16u * idx + 14u] = hit ? (uint16_t)(int16_t)-2 : (uint16_t)0;
             }
         }
-        for (uint32_t h0 = 0; h0 < n_hits; h0 += 64u) { /* (this wave's own list: written and read in program order) */
-            const bool on = h0 + (uint32_t)lane < n_hits;
-            const uint2 e = hits[on ? h0 + (uint32_t)lane : 0u];
-            const uint32_t cell = e.x & kKeyCellMask;
-            const uint32_t code = code_from_bins_t<kPow2>(edge_x[cell / kGridCols] + (int)((e.x >> kKeyDxShift) & 3u),
-                                                          edge_y[cell % kGridCols] + (int)((e.x >> kKeyDyShift) & 3u), __uint_as_float(e.y), rp);
-            list_code(on ? code : kSkip);
-        }
+        flush(n_hits);
     };
-    if (!gave_up) { /* (workgroup-uniform) */
+    if (!gave_up) { /* (workgroup-uniform) the candidates once more: a wave takes kHitSlots consecutive slices at a time (no
+                     * order to keep here), the next ones' loads in flight while it tests these */
+        const std::integral_constant<int, kHitSlots> kHitN{};
+        uint32_t nk[kHitSlots];
+        float nzz[kHitSlots];
+        int nl;
+        request(kHitN, wv * kHitSlots, nk, nzz, nl);
 #pragma unroll 1
-        for (int r = R - 1; r >= 0; --r) { /* the last round is still in the registers; earlier ones (more than 16,384 candidates in the quarter) are read again */
-            if (r != R - 1) request_round(r);
+        for (int gs0 = wv * kHitSlots; gs0 < G; gs0 += kGndWaves * kHitSlots) {
+            uint32_t key[kHitSlots];
+            float zz[kHitSlots];
+            const int lo = nl;
 #pragma unroll
-            for (int q = 0; q < kGndKeep; ++q)
-                if (r * kGndKeep + q < P) resolve(r * kGndKeep + q, kkey[q], kz[q], klo[q]);
+            for (int j = 0; j < kHitSlots; ++j) {
+                key[j] = nk[j];
+                zz[j] = nzz[j];
+            }
+            request(kHitN, gs0 + kGndWaves * kHitSlots, nk, nzz, nl);
+            resolve(gs0, key, zz, lo);
         }
     }
     lds_barrier();
     if (tid < bands) b.ncode[((size_t)f * g.emitters + g.strips + quarter) * bands + tid] = band_cursor[tid];
     PH();
-    PH_PRINT("ground init parts meet phaseC", tid == 0 && blockIdx.x == 100);
+    PH_PRINT("ground init parts meet phaseC", tid == 0 && blockIdx.x == 1500);
 }
 
 /* ------------------------------------------------------------------------- */
