@@ -42,8 +42,7 @@ typedef enum bev_status {
     BEV_ERR_HIP = -3,           /* a HIP runtime call failed (see bev_last_error) */
     BEV_ERR_OOM = -4,
     BEV_ERR_UNSUPPORTED = -5,   /* parameter combination outside the built kernels */
-    BEV_ERR_TOO_LARGE = -6,     /* n_frames / n_points above what bev_create sized */
-    BEV_ERR_INTERNAL = -7       /* a kernel gave up (see bev_last_error): outputs since the last synchronisation are incomplete */
+    BEV_ERR_TOO_LARGE = -6      /* n_frames / n_points above what bev_create sized */
 } bev_status_t;
 
 /* In-memory layout of pcl::PointXYZIRCT (BatchMultiBevGen.h:43-54): 32 bytes,

@@ -55,7 +55,6 @@ struct Lane {
     uint32_t *ncand = nullptr;
     uint32_t *code_main = nullptr, *ncode = nullptr; /* per-(strip, band) lists of final BEV codes */
     float *avg = nullptr;
-    uint32_t *meet = nullptr; /* k_ground's per-frame counters (zeroed once: they advance by 4 per frame and launch) */
     int8_t *gm = nullptr; /* lazily allocated */
 };
 
@@ -148,7 +147,6 @@ struct bev_ctx {
     uint32_t *codes = nullptr;
     size_t codes_elems = 0;
     uint32_t *ctx_tab = nullptr; /* per-context tables (BatchPtrs::ctx_tab) */
-    uint32_t *err_word = nullptr; /* mapped host word a kernel raises when it gives up (BatchPtrs::err) */
     float *last_avg = nullptr;
     uint32_t *last_ncode = nullptr;
     FrameInfo *last_info = nullptr;
@@ -250,17 +248,6 @@ int hip_fail(bev_ctx *c, hipError_t e, const char *what, int line)
         if (e_ != hipSuccess) return hip_fail((ctx), e_, #expr, __LINE__); \
     } while (0)
 
-/* a kernel that gave up (k_ground's bounded wait for a frame's other quarters) has raised the context's error word: the
- * results of the calls since the last synchronisation are incomplete */
-int device_error(bev_ctx *c)
-{
-    if (c->err_word && *reinterpret_cast<volatile uint32_t *>(c->err_word) != 0u) {
-        c->last_error = "k_ground: a workgroup gave up waiting for the other quarters of its frame; outputs of the calls since the last synchronisation are incomplete";
-        return BEV_ERR_INTERNAL;
-    }
-    return BEV_OK;
-}
-
 int mat_size_of(const bev_params_t *p)
 {
     /* static int MAT_SIZE = MAX_RANGE*2 / interval;  BatchMultiBevGen.cpp:267 */
@@ -308,8 +295,8 @@ void fill_geometry(const bev_params_t *p, Geometry *g)
         g->raster_bands = g->rp.bands;
     }
     g->emitters = g->strips + kResolveParts;
-    {   /* worst case: every slot of a strip / every candidate of the frame (all in one cell quarter) in one band; normally far fewer (kCodeListCap) */
-        const uint32_t worst = std::max((uint32_t)g->N * (uint32_t)kStripCols, (uint32_t)g->segs * (uint32_t)kStripCols);
+    {   /* worst case: every slot of a strip / every candidate of a resolve part in one band; normally far fewer (kCodeListCap) */
+        const uint32_t worst = std::max((uint32_t)g->N * (uint32_t)kStripCols, (uint32_t)((g->segs + kResolveParts - 1) / kResolveParts + 1) * (uint32_t)kSeg);
         uint32_t cap = (uint32_t)kCodeListCap;
         if (const char *e = getenv("BEV_CODE_CAP")) cap = (uint32_t)std::max(1, atoi(e));
         g->code_cap = std::min(worst, cap);
@@ -474,8 +461,6 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.ncode = ln.ncode;
         b.ctx_tab = c->ctx_tab;
         b.avg = ln.avg;
-        b.meet = ln.meet;
-        b.err = c->err_word;
         b.gm = d_gm ? ln.gm : nullptr;
         b.multi = d_multi ? d_multi + (size_t)f0 * c->multi_bytes : nullptr;
         b.single = d_single ? d_single + (size_t)f0 * c->single_bytes : nullptr;
@@ -565,7 +550,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                 c->staggered[nxt] = true;
             }
         }
-        RoctxRange rb("bev:back (ground phases B and C, rasters)");
+        RoctxRange rb("bev:back (cell sums, resolve, rasters)");
         /* (BEV_BACK_CHUNK cuts the back stage into pieces of that many frames: measured with 512-frame sub-batches and
          * pieces of 256 — one k_cell_sums workgroup per CU and piece — the serialised pieces cost more than the second
          * round of workgroups they avoid: 270 k against 287 k frames/s) */
@@ -575,20 +560,23 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             bc.cand = b.cand + (size_t)c0 * g.segs * kSeg;
             bc.ncand = b.ncand + (size_t)c0 * g.segs;
             bc.avg = b.avg + (size_t)c0 * bevx::kGridCells;
-            bc.meet = b.meet + c0;
             bc.code_main = b.code_main + (size_t)c0 * g.emitters * g.raster_bands * g.code_stride;
             bc.ncode = b.ncode + (size_t)c0 * g.emitters * g.raster_bands;
             bc.ordered = b.ordered + (size_t)c0 * S;
             bc.gm = b.gm ? b.gm + (size_t)c0 * S : nullptr;
             bc.multi = b.multi ? b.multi + (size_t)c0 * c->multi_bytes : nullptr;
             bc.single = b.single ? b.single + (size_t)c0 * c->single_bytes : nullptr;
-            {   /* phases B and C for the candidates: per-cell averages; labels, codes of the un-grounded ones */
-                ProfScope ps(c, K_GROUND, cn, st);
-                launch_ground(g, bc, cn, st);
+            {
+                ProfScope ps(c, K_CELL_SUMS, cn, st);
+                launch_cell_sums(g, bc, cn, st);
             }
             if (d_gm) {
                 ProfScope ps(c, K_GROUND_MAT, cn, st);
                 launch_ground_mat(g, bc, d_gm + (size_t)(f0 + c0) * S, cn, st);
+            }
+            {   /* phase C for the candidates: labels, codes of the un-grounded ones */
+                ProfScope ps(c, K_GROUND_RESOLVE, cn, st);
+                launch_ground_resolve(g, bc, cn, st);
             }
             if (d_multi || d_single) {
                 ProfScope ps(c, K_BEV_RASTER, cn, st);
@@ -651,7 +639,6 @@ const char *bev_strerror(int status)
     case BEV_ERR_OOM: return "out of device memory";
     case BEV_ERR_UNSUPPORTED: return "parameter combination not supported by the built kernels";
     case BEV_ERR_TOO_LARGE: return "batch or point count larger than the context was created for";
-    case BEV_ERR_INTERNAL: return "a kernel gave up: outputs since the last synchronisation are incomplete (see bev_last_error)";
     default: return "unknown status";
     }
 }
@@ -758,8 +745,6 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
     }
     CK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
     CK(hipEventCreateWithFlags(&c->stagger_ev, hipEventDisableTiming));
-    CK(hipHostMalloc((void **)&c->err_word, sizeof(uint32_t), hipHostMallocMapped));
-    *c->err_word = 0u;
     c->staggered[0] = true;
     /* Streams of equal priority may be multiplexed onto ONE hardware queue (observed:
      * two such lanes never overlapped); streams of different priority get different
@@ -793,8 +778,6 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         CK(hipMalloc((void **)&ln.code_main, nb * (size_t)c->geo.emitters * c->geo.raster_bands * c->geo.code_stride * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.ncode, nb * (size_t)c->geo.emitters * c->geo.raster_bands * sizeof(uint32_t)));
         CK(hipMalloc((void **)&ln.avg, nb * (size_t)bevx::kGridCells * sizeof(float)));
-        CK(hipMalloc((void **)&ln.meet, nb * sizeof(uint32_t)));
-        CK(hipMemset(ln.meet, 0, nb * sizeof(uint32_t)));
     }
     c->winner = c->lanes[0].winner;
     CK(hipMalloc((void **)&c->codes, c->codes_elems * sizeof(uint32_t))); /* single-cloud entry points */
@@ -829,7 +812,7 @@ void bev_destroy(bev_ctx_t *c)
     for (int l = 0; l < kMaxLanes; ++l) {
         Lane &ln = c->lanes[l];
         if (ln.st) (void)hipStreamSynchronize(ln.st);
-        void *ws[] = {ln.info, ln.est, ln.tail_list, ln.tail_cnt, ln.winner, ln.cand, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.meet, ln.gm};
+        void *ws[] = {ln.info, ln.est, ln.tail_list, ln.tail_cnt, ln.winner, ln.cand, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
         for (void *p : ws)
             if (p) (void)hipFree(p);
         if (ln.hint) (void)hipHostFree(ln.hint);
@@ -870,7 +853,7 @@ int bev_synchronize(bev_ctx_t *c)
 {
     if (!c) return BEV_ERR_INVALID_ARG;
     HIPCK(c, hipStreamSynchronize(c->stream));
-    return device_error(c);
+    return BEV_OK;
 }
 
 int bev_process_device_resident(bev_ctx_t *c, int n_frames, const bev_point_t *d_pts, const uint64_t *h_offsets,
@@ -944,7 +927,7 @@ int bev_process_batch(bev_ctx_t *c, int n_frames, const bev_point_t *const *pts,
     dl.wait_finished(k); /* every chunk that was handed over has reached the caller's buffers */
     if (rc == BEV_OK && dl.err != hipSuccess) rc = hip_fail(c, dl.err, "device -> host copy", __LINE__);
     if (rc != BEV_OK) (void)hipDeviceSynchronize();
-    return rc == BEV_OK ? device_error(c) : rc;
+    return rc;
 }
 
 int bev_host_alloc(void **out, size_t bytes)
@@ -1020,7 +1003,7 @@ int bev_mark_ground(bev_ctx_t *c, bev_point_t *ordered, int8_t *ground_mat_out)
     HIPCK(c, hipMemcpyAsync(ordered, c->st_ordered, S * sizeof(bev_point_t), hipMemcpyDeviceToHost, c->stream));
     if (ground_mat_out) HIPCK(c, hipMemcpyAsync(ground_mat_out, c->st_gm, S, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    return device_error(c);
+    return BEV_OK;
 }
 
 static int raster_cloud(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, uint8_t *multi_out, uint8_t *single_out)

@@ -23,8 +23,14 @@ constexpr int kStripCols = 236;                 /* (256 input positions cover th
 constexpr int kStripVirt = kStripCols + 4;
 constexpr int kSeg = 256;                       /* capacity of one candidate segment = one (row, strip) */
 constexpr int kMaxSegs = 1024;                  /* (G + 1) * strips must not exceed this (bev_create checks) */
-constexpr int kGndThreads = 256;  /* k_ground: phases B and C, four workgroups per frame (cells by cell mod 4), the size of a column-walk workgroup */
-constexpr int kResolveParts = 4;  /* code lists per frame written by phase C: one per cell quarter */
+constexpr int kSumWaves = 4;      /* waves of the per-frame cell-sum workgroup: the size of a column-walk workgroup */
+constexpr int kSumThreads = kSumWaves * 64;
+constexpr int kResolveThreads = 512;
+constexpr int kResolveParts = 4;  /* code lists per frame written by k_ground_resolve (a contiguous quarter of the segments each) */
+/* workgroups per frame in k_ground_resolve, kResolveParts / kResolveWgs consecutive parts each: a workgroup's tables
+ * (3,750 averages, their neighbour minima, edge bins, band table) cost as much as a part's candidates */
+constexpr int kResolveWgs = 1;
+static_assert(kResolveParts % kResolveWgs == 0, "whole parts per workgroup");
 #ifndef BEV_RASTER_THREADS
 #define BEV_RASTER_THREADS 512 /* (overridable for `make exp`: bev_kernels.hip is the only user) */
 #endif
@@ -100,7 +106,7 @@ constexpr int kStreamMaxRows = 64;   /* sensors with more rows go the general wa
  *                                                  (final when the walk writes them), one list per raster band, appended
  *                                                  row by row by the strip's workgroup (no atomics)
  *   ncode u32                  [nf][emitters][bands]
- *   (k_ground appends the codes of the candidates phase C un-grounds to lists of the same kind, one set per cell quarter) */
+ *   (k_ground_resolve appends the codes of the candidates phase C un-grounds to lists of the same kind, one set per part) */
 static_assert(sizeof(bev_point_t) == 32, "bev_point_t must be 32 bytes");
 
 struct Geometry {
@@ -110,7 +116,7 @@ struct Geometry {
     int strips;        /* ceil(H / kStripCols): column strips of the walk kernel */
     int segs;          /* (G + 1) * strips: candidate segments per frame, row-major */
     int raster_bands;  /* x-bands per frame in the raster kernel (= rp.bands: coarse ones outside, fine ones in the middle) */
-    int emitters;      /* strips + kResolveParts: writers of code lists per frame (the walk's strips, phase C's quarters) */
+    int emitters;      /* strips + kResolveParts: writers of code lists per frame (the walk's strips, the resolve's parts) */
     uint32_t code_cap; /* capacity of one (emitter, band) code list: kCodeListCap, or the worst case (every slot of a strip /
                         * every candidate of a resolve part in one band) where that is smaller; a raster band with a list
                         * that does not hold its codes is computed from the ordered cloud instead */
@@ -138,8 +144,6 @@ struct BatchPtrs {
     uint32_t *ncode;             /* [nf][emitters][bands]: codes the writer had for the list (more than code_cap: the list is incomplete) */
     const uint32_t *ctx_tab;     /* [kCtxTabWords] per context: edge_x[75], edge_y[50] (BEV bins of the ground grid's cell edges), band_tab[512] bytes (x bin -> raster band) */
     float *avg;                  /* [nf][3750] */
-    uint32_t *meet;              /* [nf]: k_ground: how many quarter workgroups of the frame have published their averages (advances by 4 per launch, never reset) */
-    uint32_t *err;               /* mapped host word: a kernel gave up (k_ground's bounded wait) */
     int8_t *gm;                  /* [nf][S] or nullptr: phase-A ground_mat */
     uint8_t *multi;              /* [nf][L*M*M] */
     uint8_t *single;             /* [nf][M*M] */
@@ -148,7 +152,8 @@ struct BatchPtrs {
 enum KernelId {
     K_ORDER_SCAN = 0,
     K_GATHER_GROUND,
-    K_GROUND,
+    K_CELL_SUMS,
+    K_GROUND_RESOLVE,
     K_BEV_RASTER,
     K_GATHER_ONLY,
     K_GROUND_MAT,
@@ -179,8 +184,8 @@ void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int sou
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st);
 void launch_verdict(const BatchPtrs &b, int nf, uint32_t *host_hint, hipStream_t st);
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
-/* markGroundPoints phases B and C for the sub-batch's candidates (b.meet, b.ctx_tab set) */
-void launch_ground(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
+void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
+void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
 /* the rasters of a sub-batch from its code lists */
 void launch_bev_raster(const Geometry &g, const BatchPtrs &b, bool want_multi, bool want_single, int nf, hipStream_t st);
 /* rasters of ONE arbitrary cloud from a dense code array (bev_multi_bev / bev_single_bev) */
@@ -210,7 +215,7 @@ void launch_project_kitti(const float *xyzi, uint32_t n, const KittiWork &w, bev
 void launch_angle_debug(const float *dx, const float *dy, const float *dz, uint8_t *out, size_t n, hipStream_t st);
 /* opt in to > 64 KiB of dynamic LDS for the kernels that need it */
 hipError_t configure_kernels(const Geometry &g);
-size_t ground_lds_bytes(int segs);
+size_t cell_sums_lds_bytes();
 size_t raster_lds_bytes(const Geometry &g);
 
 } /* namespace bevk */

@@ -9,9 +9,9 @@
  *   order_scan      per input point : winner[slot] = max(index+1)          (getOrderedCloud, last writer wins)
  *   gather_ground   per slot        : ordered cloud, phase-A ground flag,
  *                                     BEV code, candidate list               (getOrderedCloud + markGroundPoints phase A)
- *   ground          per frame, x 4  : stable counting sort of candidates by
- *                                     2 m cell, IN-ORDER float sums, then the
- *                                     4-neighbour height test and label fix-up (markGroundPoints phases B and C)
+ *   cell_sums       per frame       : stable counting sort of candidates by
+ *                                     2 m cell, then IN-ORDER float sums     (markGroundPoints phase B + divide)
+ *   ground_resolve  per frame row   : 4-neighbour height test, label fix-up (markGroundPoints phase C)
  *   bev_raster      per frame band  : LDS atomics, then coalesced 16 B stores
  *                                     of the 24 occupancy planes + max-height
  *                                     plane                                  (computeAndSave{Multi,Single}Bev rasters)
@@ -61,7 +61,7 @@ using namespace bevx;
 namespace bevk {
 
 static const char *const kNames[K_COUNT] = {
-    "k_order_scan", "k_walk", "k_ground", "k_bev_raster",
+    "k_order_scan", "k_walk", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project", "k_transform",
     "k_probe", "k_walk_general", "k_walk_structured", "k_walk_colmajor", "k_verdict",
 };
@@ -1357,105 +1357,80 @@ __global__ __launch_bounds__(kGatherThreads) void k_gather_only(BatchPtrs b, Geo
 }
 
 /* ------------------------------------------------------------------------- */
-/* markGroundPoints phases B and C in ONE launch (round 5): BatchMultiBevGen.cpp:187-210 (per-cell sums and averages)
- * and :216-250 (the 4-neighbour height test) for the candidates.
+/* markGroundPoints phase B + divide, BatchMultiBevGen.cpp:187-210.
  *
- * Phase B, what must be reproduced: per 2 m cell, sum += z in ROW-MAJOR SLOT ORDER in float32 (and cnt = cnt + 1 from
- * 0.01f).  Cells are independent; only the order inside a cell matters.  Candidates arrive in slot order (segments in
+ * What must be reproduced: per 2 m cell, sum += z in ROW-MAJOR SLOT ORDER in float32 (and cnt = cnt + 1 from 0.01f).
+ * Cells are independent; only the order inside a cell matters.  Candidates arrive in slot order (segments in
  * (row, strip) order, compacted in column order), so a STABLE sort by cell puts every cell's heights in the order the
  * reference adds them; then one lane per cell adds its run sequentially.
  *
- * FOUR workgroups per frame, by cell mod 4 (a cell lies in one quarter, so the order inside a cell is untouched).  The
- * walk keeps every segment's candidates as four consecutive runs, one per quarter, each in column order; workgroup q
- * reads run q of every segment.  The quarter's candidates, segment after segment, are ONE stream in slot order; a slice
- * is 64 consecutive candidates of it, a part 64 consecutive slices (8 per wave, 8 waves).  Per part, in LDS and registers:
- *   rank    the lanes of a slice that hold the same cell find each other: the wave takes the cell of its first
- *           unranked lane (v_readlane), one compare gives the lanes that share it (their rank is a v_mbcnt, the group's
- *           size an s_bcnt1), and so on until no lane is left — a slice holds 4 distinct cells on average (benchmark
- *           frames; 13 at most), where rounds 3-4 took ten ballots and forty vector selects per slice whatever it held;
- *           the group's first lane adds the size to its wave's histogram and marks the cell touched
+ * Round 3: FOUR workgroups per frame, by cell mod 4 (cells are independent and a cell lies in one quarter, so the order
+ * inside a cell is untouched).  The walk keeps every segment's candidates as four consecutive runs, one per quarter, each
+ * in column order; workgroup q reads run q of every segment.  A quarter's run of a segment is 35 candidates on average
+ * — one 64-slice — so the unit of work is the SLICE: the quarter's slices are numbered in slot order (a prefix sum over
+ * the segments' slice counts, once per workgroup), a part is 64 consecutive slices — 16 per wave, in registers — and a
+ * quarter walks 8 parts where the one-workgroup form of rounds 1-2 walked 37 (16 segments each): the kernel is a chain
+ * of per-part latencies (histogram, scan, placement, sums, five barriers), not of bytes.  39 KB of LDS instead of 99: four
+ * workgroups per CU, and room beside the column walk of the other stream.  (Round 2's four-workgroup form kept the
+ * 16-segment parts: 37 parts per quarter, 17 % shorter alone and slower in the pipeline; removed, then rebuilt this way.)
+ * Per part, everything happens in LDS and registers:
+ *   hist    every wave counts its 16 slices' candidates per cell (LDS atomics, two 16-bit counters per word); keys and
+ *           heights stay in registers
  *   scan    per-cell totals over the waves, exclusive scan over the touched cells -> the part's runs
- *   place   stable placement into the part's height buffer (run start + the wave's cursor + the lane's rank)
+ *   place   stable placement into the part's height buffer: lanes of a slice that share a cell rank themselves with
+ *           ballots (one per bit of the quarter's cell number, ten: nothing but vector / scalar ALU): constant work
+ *           however many distinct cells a slice has
  *   sum     one thread per touched cell continues the cell's running (sum, cnt) through its run of this part
- * Every candidate of a round of kGndKeep parts (16,384 per quarter; a benchmark frame has 16 k) is requested up front
- * and the last round's STAY IN REGISTERS (key, height): no intermediate of phase B touches HBM, and phase C needs no second
- * pass over the candidates — rounds 1-4 read them again in k_ground_resolve, 0.65 MB per HDL_64E frame from DRAM (its
- * L2 hit rate was 0.20), and rebuilt the frame's tables once more.
- *
- * Phase C needs the averages of a cell's four NEIGHBOURS, and those lie in the other three quarters (c +- 1 and
- * c +- 50 all change c mod 4): the four workgroups of a frame meet.  Each publishes its quarter's averages, adds one to
- * the frame's counter and waits until the counter has gone up by four (the counters advance by four per frame and launch
- * and are never reset).  Workgroups are dispatched in the order of their numbers, and the quarters of a frame are numbers
- * b, b + 8, b + 16, b + 24 of one XCD's queue: whenever a workgroup waits, every workgroup before it has been dispatched
- * and runs without waiting on anything later — the frame whose quarters straddle the dispatch front is the only one that
- * can wait for a sibling not yet resident, and every other resident frame finishes and makes room.  The wait is bounded
- * all the same: a workgroup that gives up leaves the frame's candidates unresolved and raises the context's error word
- * (mapped host memory; the next API call that synchronises returns BEV_ERR_INTERNAL).
- * A candidate that is higher than a neighbour cell's average + 0.30 stops being ground ("hit"): it keeps / gets back
- * its own label, and its BEV code — rebuilt from key and height, bev_exact.h — is appended to a code list of the raster
- * band it falls into, exactly like the walk's lists (an LDS cursor per band, no global atomics): k_bev_raster reads
- * both kinds the same way; kSumQ lists per frame, one per quarter.  The walk wrote each candidate's label for its guess
- * (key bit kKeyPredBit); only wrong guesses are patched. */
+ * while the next part's keys and heights are already in flight, so the only memory round trip that is ever exposed is
+ * the first one.  No intermediate of phase B touches HBM. */
 constexpr int kCells = kGridCells;
 constexpr int kSumQ = 4;                               /* workgroups per frame: cells by cell mod 4 */
-static_assert(kSumQ == kResolveParts, "one code list set per quarter");
-constexpr int kGndWaves = kGndThreads / 64;
-constexpr int kGndSlots = 16;                          /* slices a wave keeps in registers per part */
-constexpr int kPartSlices = kGndWaves * kGndSlots;     /* 64 slices = at most 4096 candidates per part */
-constexpr uint32_t kMeetSpins = 1u << 22;              /* polls (>= 1 us each) before a workgroup gives up on its siblings */
-constexpr int kHitSlots = 4; /* phase C: slices a wave tests at a time; their hits are gathered before it builds their codes */
-struct GndDims {
+constexpr int kSlots = 16;                             /* slices a wave keeps in registers per part */
+constexpr int kPartSlices = kSumWaves * kSlots;        /* 64 slices = at most 4096 candidates per part */
+struct SumDims {
     static constexpr int cells = (kCells + kSumQ - 1) / kSumQ;
     static constexpr int hist_stride = ((cells + 1) / 2 + 3) / 4 * 4; /* words per wave's histogram: two 16-bit counters per word */
     static constexpr int touch_words = (cells + 31) / 32;
-    static constexpr int tlist_words = ((cells + 1) / 2 + 3) / 4 * 4;
-    /* hist, start, zbuf (these three also: phase C's per-wave hit lists), sumv, cntv (also: minavg, the context's tables),
-     * tbits, tlist (u16), misc, then per segment: cpre (u32, T + 1), rs8 (u8, T) */
-    static constexpr size_t front_words = (size_t)kGndWaves * hist_stride + cells + (size_t)kPartSlices * 64;
-    static constexpr size_t fixed_words = front_words + 2 * (size_t)cells + 32 + tlist_words + 16;
+    /* hist, start, zbuf, sumv, cntv, tbits, tlist (u16), misc, then per segment: cpre (u32, T + 1), rs8 (u8, T) */
+    static constexpr int start_words = (cells + 3) / 4 * 4; /* (padded: the height buffer behind it is read 16 bytes at a time) */
+    static constexpr size_t fixed_words = (size_t)kSumWaves * hist_stride + start_words + (size_t)kPartSlices * 64 + 2 * (size_t)cells + touch_words +
+                                          (cells + 1) / 2 + 16;
     static constexpr size_t seg_words(int T) { return (size_t)(T + 1) + (size_t)(T + 3) / 4; }
-    static constexpr size_t lds_bytes(int T) { return sizeof(uint32_t) * (fixed_words + seg_words(T)); } /* HDL_64E (459 segments): 39.6 KB — four per CU, and one fits wherever a walk workgroup has left */
-    static_assert(front_words >= (size_t)kCells, "the frame's averages fit phase B's buffers");
-    static_assert(front_words >= (size_t)kGndWaves * kHitSlots * 64 * 2, "the hit lists (key | height, kHitSlots x 64 per wave) fit phase B's buffers");
-    static_assert(2 * cells >= cells + kCtxTabWords + kMaxBands, "minavg, the tables and the band cursors fit the sums' words");
-    static_assert(touch_words <= 32, "one word of marks per lane of half a wave");
+    static constexpr size_t lds_bytes(int T) { return sizeof(uint32_t) * (fixed_words + seg_words(T)); } /* HDL_64E (459 segments): 39.5 KB */
 };
 static_assert(kPartSlices * 64 <= 4096, "a part's run start (12 bits) and length (13 bits) share a word with room to spare");
-static_assert(4 * kGndThreads >= kMaxSegs, "every thread takes four segments");
-size_t ground_lds_bytes(int segs) { return GndDims::lds_bytes(segs); }
+size_t cell_sums_lds_bytes() { return SumDims::lds_bytes(kMaxSegs); }
 
-template <bool kPow2>
-__global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry g, int nf)
+__global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geometry g, int nf)
 {
-    using D = GndDims;
+    using D = SumDims;
     constexpr int kCellsQ = D::cells, kHistStride = D::hist_stride, kTouchWords = D::touch_words;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *hist = lds;                                 /* [kGndWaves][kHistStride]: 16-bit counts, cells 2i | 2i+1 << 16 */
-    uint32_t *start = hist + kGndWaves * kHistStride;     /* [kCellsQ]: the part's runs, start | length << 16 */
-    float *zbuf = reinterpret_cast<float *>(start + kCellsQ); /* [kPartSlices * 64]: the part's heights by cell */
+    uint32_t *hist = lds;                                 /* [kSumWaves][kHistStride]: 16-bit counts, cells 2i | 2i+1 << 16 */
+    uint32_t *start = hist + kSumWaves * kHistStride;     /* [kCellsQ]: the part's runs, start | length << 16 */
+    float *zbuf = reinterpret_cast<float *>(start + D::start_words); /* [kPartSlices * 64]: the part's heights by cell (16-byte aligned) */
     float *sumv = zbuf + kPartSlices * 64;                /* [kCellsQ] running sums */
     float *cntv = sumv + kCellsQ;                          /* [kCellsQ] running counts */
-    uint32_t *tbits = reinterpret_cast<uint32_t *>(cntv + kCellsQ); /* [32]: cells this part has touched */
-    uint16_t *tlist = reinterpret_cast<uint16_t *>(tbits + 32); /* [kCellsQ]: ... listed, in any order */
-    uint32_t *misc = tbits + 32 + D::tlist_words;          /* [0..1] list lengths (by part parity), [2] gave up, [4..7] wave sums, [12] carry */
+    uint32_t *tbits = reinterpret_cast<uint32_t *>(cntv + kCellsQ); /* [kTouchWords]: cells this part has touched */
+    uint16_t *tlist = reinterpret_cast<uint16_t *>(tbits + kTouchWords); /* [kCellsQ]: ... listed, in any order */
+    uint32_t *misc = reinterpret_cast<uint32_t *>(tlist) + (kCellsQ + 1) / 2; /* [0..1] list lengths (by part parity), [4..7] wave sums, [8] carry */
     const int T = g.segs;
     uint32_t *cpre = misc + 16;                            /* [T + 1]: this quarter's candidates before segment t */
-    uint8_t *rs8 = reinterpret_cast<uint8_t *>(cpre + T + 1); /* [T]: where this quarter's run starts inside segment t */
+    uint8_t *rs8 = reinterpret_cast<uint8_t *>(cpre + T + 1); /* [T]: where its run starts inside segment t */
     uint16_t *hist16 = reinterpret_cast<uint16_t *>(hist); /* the same counters, cell c of wave w at [w * 2 * kHistStride + c] */
 
     int f, quarter;
     if (!map_block_xcd(blockIdx.x, nf, kSumQ, f, quarter)) return; /* the quarters of a frame on one XCD: they read the same lines */
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const gptr<const u32x2> gcand = (gptr<const u32x2>)(b.cand + (size_t)f * T * kSeg); /* key | height */
+    const uint2 *ccand = b.cand + (size_t)f * T * kSeg; /* key | height */
     const uint32_t *fn = b.ncand + (size_t)f * T;
-    const int H = g.H, strips = g.strips, lo_row = g.N - g.G;
     PH_DECL;
     PH();
 
-    for (int k = tid; k < kGndWaves * kHistStride; k += kGndThreads) hist[k] = 0u;
-    if (tid < 32) tbits[tid] = 0u;
+    for (int k = tid; k < kSumWaves * kHistStride; k += kSumThreads) hist[k] = 0u;
+    for (int k = tid; k < kTouchWords; k += kSumThreads) tbits[k] = 0u;
     if (tid < 16) misc[tid] = 0u;
-    for (int c = tid; c < kCellsQ; c += kGndThreads) {
+    for (int c = tid; c < kCellsQ; c += kSumThreads) {
         sumv[c] = 0.0f;   /* :133-134 */
         cntv[c] = 0.01f;  /* :135-136 */
     }
@@ -1463,14 +1438,14 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
      * before it.  The walk wrote a segment's four counts as four bytes; T <= kMaxSegs = 4 * 256: every thread takes four
      * consecutive segments */
     {
-        uint32_t cq[4], rs[4], mine = 0u;
+        uint32_t cq[4], mine = 0u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int t = 4 * tid + k;
             const uint32_t w = t < T ? fn[t] : 0u;
             const uint32_t sh = 8u * (uint32_t)quarter;
             cq[k] = (w >> sh) & 0xffu;
-            rs[k] = ((w * 0x01010100u) >> sh) & 0xffu; /* the quarters below it (no byte exceeds the segment's 236) */
+            if (t < T) rs8[t] = (uint8_t)(((w * 0x01010100u) >> sh) & 0xffu); /* the quarters below it (no byte exceeds the segment's 236) */
             mine += cq[k];
         }
         uint32_t incl = mine;
@@ -1487,37 +1462,28 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
         for (int k = 0; k < 4; ++k) {
             const int t = 4 * tid + k;
             if (t <= T) cpre[t] = base;
-            if (t < T) rs8[t] = (uint8_t)rs[k];
             base += cq[k];
         }
-        if (tid == kGndThreads - 1 && 4 * kGndThreads <= T) cpre[T] = base; /* (T == 1024 exactly) */
+        if (tid == kSumThreads - 1 && 4 * kSumThreads <= T) cpre[T] = base; /* (T == 1024 exactly) */
         lds_barrier();
-        if (tid < kGndWaves) misc[4 + tid] = 0u;
+        if (tid == 0) misc[4] = misc[5] = misc[6] = misc[7] = 0u;
     }
+    /* The quarter's candidates, segment after segment, are ONE stream in slot order; a slice is 64 consecutive candidates
+     * of it — full, whatever the segments' run lengths (a run of a (segment, quarter) is 35 candidates on average: slices
+     * cut at segment ends were 55 % full, 1,930 of them per frame where 1,000 do) */
     const int GC = (int)cpre[T];                              /* candidates of this quarter */
     const int G = (GC + 63) >> 6;                             /* slices */
     const int P = (G + kPartSlices - 1) / kPartSlices;
-    auto slice_count = [&](int gs) -> int { /* candidates in slice gs of the quarter's stream (0: no such slice) */
-        return gs < G ? (GC - 64 * gs < 64 ? GC - 64 * gs : 64) : 0;
-    };
-    auto slice_n = [&](int p, int j) -> int { /* ... in slice j of this wave in part p (wave-uniform) */
-        return slice_count(p * kPartSlices + wv * kGndSlots + j);
-    };
 
-    /* A wave's slices of part p are slices p * 64 + 16 * wave + j.  Lane j <= 16 finds the segment of slice j's first
-     * candidate by itself (binary search over the candidate prefix: the searches run side by side); a slice then spans
-     * the segments from its own start to the next slice's, and a lane's segment is the slice's first plus the segment
-     * starts at or before the lane's candidate (a slice spans two or three segments: a quarter's run of a segment is
-     * 35 candidates on average). */
-    auto seg_of = [&](int t0, int t1, uint32_t i) -> int { /* (wave-uniform trip count, broadcast reads) */
-        int t = t0;
-#pragma unroll 1
-        for (int u = t0 + 1; u <= t1; ++u) t += cpre[u] <= i ? 1 : 0; /* (one to three turns: hipcc unrolls this sixteen-fold otherwise) */
-        return t;
-    };
-    auto request = [&](auto NS, int g0, uint32_t (&key)[decltype(NS)::value], float (&z)[decltype(NS)::value], int &lo_out) { /* slices g0 .. g0 + NS - 1 */
-        constexpr int kN = decltype(NS)::value;
-        const int gl = g0 + (lane < kN + 1 ? lane : kN);
+    /* software pipeline: keys + heights one part ahead.  A wave's 16 slices of part p are slices p * 64 + 16 * wave + j */
+    uint32_t key_n[kSlots]; /* next part (raw keys; lanes past the slice's count hold garbage) */
+    float z_n[kSlots];
+    int n_n[kSlots];        /* candidates in the slice (0: no such slice) */
+    auto request = [&](int p) {
+        /* lane j <= 16 finds the segment of slice g0 + j's first candidate by itself (binary search over the candidate
+         * prefix: the searches run side by side); a slice then spans the segments from its own start to the next slice's */
+        const int g0 = p * kPartSlices + wv * kSlots;
+        const int gl = g0 + (lane < kSlots + 1 ? lane : kSlots);
         int lo = 0;
         if (gl < G) {
             const uint32_t x = 64u * (uint32_t)gl;
@@ -1529,67 +1495,74 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
         } else {
             lo = T - 1;
         }
-        lo_out = lo;
 #pragma unroll
-        for (int j = 0; j < kN; ++j) {
-            key[j] = 0u;
-            z[j] = 0.f;
-            if (g0 + j < G) { /* wave-uniform */
-                const uint32_t i = 64u * (uint32_t)(g0 + j) + (uint32_t)lane; /* this lane's candidate (past the end in the last slice) */
-                /* the lane's segment: the slice's first plus the segment starts at or before the lane's candidate — the
-                 * next three without a loop (their reads are requested side by side; a loop over them waits for the LDS
-                 * at every turn: 5.7 us per part against 2), the rest, if the slice spans more, by seg_of */
+        for (int j = 0; j < kSlots; ++j) {
+            const bool on = g0 + j < G; /* wave-uniform */
+            n_n[j] = on ? (GC - 64 * (g0 + j) < 64 ? GC - 64 * (g0 + j) : 64) : 0;
+            key_n[j] = 0u;
+            z_n[j] = 0.f;
+            if (on) {
                 const int t0 = __builtin_amdgcn_readlane(lo, j), t1 = __builtin_amdgcn_readlane(lo, j + 1);
+                const uint32_t i = 64u * (uint32_t)(g0 + j) + (uint32_t)lane; /* this lane's candidate (past the end in the last slice) */
                 int t = t0;
-#pragma unroll
-                for (int k = 1; k <= 3; ++k) {
-                    const int u = t0 + k < t1 ? t0 + k : t1; /* (uniform) */
-                    t += (cpre[u] <= i && t0 + k <= t1) ? 1 : 0;
-                }
-                if (t1 - t0 > 3) t += seg_of(t0 + 3, t1, i) - (t0 + 3); /* (uniform, rare) */
+                for (int u = t0 + 1; u <= t1; ++u) t += cpre[u] <= i ? 1 : 0; /* (wave-uniform trip count, broadcast reads) */
                 /* lanes past the stream's end read the last run's stale tail (allocated memory) and are masked where
                  * the values are used */
-                const u32x2 kz = gcand[(uint32_t)t * (uint32_t)kSeg + rs8[t] + (i - cpre[t])]; /* (scalar base + 32-bit offset) */
-                key[j] = kz.x;
-                z[j] = __uint_as_float(kz.y);
+                const uint2 kz = ccand[(size_t)t * kSeg + rs8[t] + (i - cpre[t])];
+                key_n[j] = kz.x;
+                z_n[j] = __uint_as_float(kz.y);
             }
         }
     };
-    const std::integral_constant<int, kGndSlots> kPartN{};
+    request(0);
+    lds_barrier(); /* LDS state initialised */
 
     uint32_t *myhist = hist + wv * kHistStride;
     PHA_DECL;
-    /* one part: rank, scan, place, sum (the keys and heights are the caller's registers) */
-    auto do_part = [&](int p, uint32_t (&enc)[kGndSlots], const float (&z)[kGndSlots]) { /* enc: in: the slot's cell in the quarter (0xfff: no candidate); out: cell | rank << 12 | size << 18 */
+    for (int p = 0; p < P; ++p) {
         PHA(7);
         const int par = p & 1;
+        /* part p's data into the "current" registers, part p + 1 requested */
+        uint32_t cell[kSlots];
+        float zz[kSlots];
+        int nn[kSlots];
 #pragma unroll
-        for (int j = 0; j < kGndSlots; ++j) {
-            if (slice_n(p, j) == 0) continue; /* wave-uniform */
-            const uint32_t c = enc[j];
-            /* Lanes of a 64-slice that hold the same cell find each other in one turn per distinct cell of the slice (4 on
-             * average in a benchmark frame, 13 at most): the cell of the first lane still without a group, the lanes that
-             * hold it, their ranks (v_mbcnt) and the group's size (s_bcnt1) — a dozen instructions per turn, half of them
-             * scalar, no branch inside.  (Rounds 3-4: one ballot per bit of the cell number, ten per slice, 80 vector
-             * instructions whatever the slice held; same box, the loop is 9 % ahead in this kernel's time.) */
-            unsigned long long rem = __ballot(c != 0xfffu);
-            uint32_t e = 0xfffu;
-            while (rem) {
-                const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)c, __ffsll((long long)rem) - 1);
-                const bool mine = c == cc;
-                const unsigned long long m = __ballot(mine);
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                const uint32_t t = (((uint32_t)__popcll(m) << 6) | rank) << 12;
-                e = mine ? t : e;
-                rem &= ~m;
+        for (int j = 0; j < kSlots; ++j) {
+            nn[j] = n_n[j];
+            cell[j] = lane < nn[j] ? ((key_n[j] & kKeyCellMask) >> 2) : 0xfffu; /* 0xfff: no candidate */
+            zz[j] = z_n[j];
+        }
+        request(p + 1);
+        PHA(5);
+
+        /* hist.  Lanes of a 64-slice that hold the same cell find each other with one ballot per key bit (10 bits cover
+         * the quarter's 938 cells; 0xfff is not a cell): constant work however many distinct cells the slice has, and
+         * nothing but vector / scalar ALU (rounds 1-2 took six ballots, fetched the group leader's cell through the LDS
+         * pipe to verify and took the other bits only on a mismatch: a round trip per slice on the critical path).  Every
+         * lane keeps its rank inside its group, the group's size and whether it leads the group in the spare bits of its
+         * cell register (cell | rank << 12 | size << 18 | leader << 25), so the placement below needs no second look.
+         * Only leaders touch the histogram (64 LDS atomics on one address would serialise) and mark their cell touched —
+         * without waiting for an answer: the list of touched cells is made from the marks after the barrier. */
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+            if (nn[j] == 0) break; /* wave-uniform */
+            const uint32_t c = cell[j];
+            const bool valid = c != 0xfffu;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 10; ++bit) {
+                const bool one = (c >> bit) & 1u;
+                const unsigned long long bal = __ballot(one);
+                peers &= one ? bal : ~bal;
             }
-            enc[j] = e | c;
-            /* only the group's first lane touches the histogram (64 LDS atomics on one address would serialise) and marks
-             * its cell touched — without waiting for an answer: the list of touched cells is made after the barrier */
-            if (c != 0xfffu && (e & (63u << 12)) == 0u) {
-                atomicAdd(&myhist[c >> 1], (e >> 18) << (16 * (c & 1u)));
+            const unsigned long long lower = peers & ((1ull << lane) - 1ull);
+            const uint32_t size = (uint32_t)__popcll(peers), rank = (uint32_t)__popcll(lower);
+            const bool leader = valid && lower == 0ull;
+            if (leader) {
+                atomicAdd(&myhist[c >> 1], size << (16 * (c & 1u)));
                 atomicOr(&tbits[c >> 5], 1u << (c & 31u));
             }
+            if (valid) cell[j] = c | (rank << 12) | (size << 18) | (leader ? 1u << 25 : 0u);
         }
         PHA(6);
         lds_barrier();
@@ -1603,6 +1576,7 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
                 const uint32_t v = __shfl_up(incl, d);
                 if (lane >= d) incl += v;
             }
+            static_assert(kTouchWords <= 32, "one word of marks per lane of half a wave");
             if (lane == kTouchWords - 1) misc[par] = incl;
             uint32_t at = incl - mine;
             while (word) { /* (at most 32 turns, for the few lanes whose cells are all touched) */
@@ -1618,13 +1592,13 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
          * exclusive scan over the list -> every listed cell's run in zbuf (any order of the cells will do) */
         const int nT = (int)misc[par];
         if (tid == 0) misc[par ^ 1] = 0u; /* the other parity's length, for the next part (nobody reads it now) */
-        for (int i0 = 0; i0 < nT; i0 += kGndThreads) {
+        for (int i0 = 0; i0 < nT; i0 += kSumThreads) {
             const int i = i0 + tid;
             uint32_t c = 0u, tot = 0u;
             if (i < nT) {
                 c = tlist[i];
 #pragma unroll
-                for (int w = 0; w < kGndWaves; ++w) {
+                for (int w = 0; w < kSumWaves; ++w) {
                     const uint32_t v = hist16[w * 2 * kHistStride + c];
                     hist16[w * 2 * kHistStride + c] = (uint16_t)tot;
                     tot += v;
@@ -1638,51 +1612,50 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
             }
             if (lane == 63) misc[4 + wv] = incl;
             lds_barrier();
-            uint32_t run = misc[12] + incl - tot;
+            uint32_t run = misc[8] + incl - tot;
             for (int w = 0; w < wv; ++w) run += misc[4 + w];
             if (i < nT) start[c] = run | (tot << 16);
             lds_barrier(); /* wave sums and the carry have been read */
-            if (tid == kGndThreads - 1) misc[12] = run + tot; /* carry into the next 512 listed cells */
+            if (tid == kSumThreads - 1) misc[8] = run + tot; /* carry into the next 256 listed cells */
         }
         lds_barrier();
-        if (tid == 0) misc[12] = 0u;
+        if (tid == 0) misc[8] = 0u;
         PHA(2);
 
         /* stable placement: slices in slot order; position = the cell's run start + this wave's cursor inside the run +
          * the lane's rank in its group; the group's leader then advances the cursor (the reads are issued before that
          * update: same wave, program order; two cells of one word may both advance: atomic) */
 #pragma unroll
-        for (int j = 0; j < kGndSlots; ++j) {
-            if (slice_n(p, j) == 0) continue; /* wave-uniform */
-            const uint32_t v = enc[j];
+        for (int j = 0; j < kSlots; ++j) {
+            if (nn[j] == 0) break; /* wave-uniform */
+            const uint32_t v = cell[j];
             const uint32_t c = v & 0xfffu;
             if (c != 0xfffu) {
                 const uint32_t off = (myhist[c >> 1] >> (16 * (c & 1u))) & 0xffffu;
-                zbuf[(start[c] & 0xffffu) + off + ((v >> 12) & 63u)] = z[j];
-                if ((v & (63u << 12)) == 0u) atomicAdd(&myhist[c >> 1], (v >> 18) << (16 * (c & 1u)));
+                zbuf[(start[c] & 0xffffu) + off + ((v >> 12) & 63u)] = zz[j];
+                if (v & (1u << 25)) atomicAdd(&myhist[c >> 1], ((v >> 18) & 127u) << (16 * (c & 1u)));
             }
         }
         lds_barrier();
         PHA(3);
 
         /* in-order sums of the listed cells, one thread per cell; the part's traces are wiped on the way */
-        if (tid < 32) tbits[tid] = 0u;
-        for (int i = tid; i < nT; i += kGndThreads) {
+        for (int k = tid; k < kTouchWords; k += kSumThreads) tbits[k] = 0u;
+        for (int i = tid; i < nT; i += kSumThreads) {
             const uint32_t c = tlist[i];
             const uint32_t se = start[c];
 #pragma unroll
-            for (int w = 0; w < kGndWaves; ++w) hist16[w * 2 * kHistStride + c] = 0;
+            for (int w = 0; w < kSumWaves; ++w) hist16[w * 2 * kHistStride + c] = 0;
             int q = (int)(se & 0xffffu);
             const int e = q + (int)(se >> 16);
             float sj = sumv[c];
-            __builtin_amdgcn_s_setprio(3); /* the chain below is what the other waves of the workgroup wait for */
             /* the count of the run in one go (bev_exact.h: the reference's "cnt = cnt + 1" steps are exact inside a
              * binade): the loop below is the sum's chain alone */
             cntv[c] = count_advance(cntv[c], se >> 16); /* :205-206 */
             /* the adds of one cell are a serial chain (that IS the reference's order): what can be saved is everything
-             * around the additions.  The heights come as 16-byte reads, THREE reads ahead of their use (a read requested one
-             * quad ahead was waited for in every turn: 16 cycles per addition), into four register quads that take turns
-             * (no moves). */
+             * around the additions.  The heights come as 16-byte reads, THREE reads ahead of their use, into four register
+             * quads that take turns (no moves) (rounds 3-4: eight 4-byte reads one group ahead and eight moves per eight
+             * additions). */
             for (; q < e && (q & 3); ++q) sj += zbuf[q];
             {
                 const float4 *z4 = reinterpret_cast<const float4 *>(zbuf);
@@ -1712,191 +1685,16 @@ __global__ __launch_bounds__(kGndThreads, 4) void k_ground(BatchPtrs b, Geometry
 #pragma unroll 1
             for (; q < e; ++q) sj += zbuf[q];
             sumv[c] = sj;
-            __builtin_amdgcn_s_setprio(0);
         }
         lds_barrier(); /* the next part overwrites start and zbuf; hist and tbits are clean */
         PHA(4);
-    };
-
-    /* ---- phase B: keys and heights one part ahead (the next part's loads are in flight while a part is worked on) ---- */
-    uint32_t nkey[kGndSlots];
-    float nz[kGndSlots];
-    int nlo;
-    request(kPartN, wv * kGndSlots, nkey, nz, nlo);
-    lds_barrier(); /* LDS state initialised */
+    }
+    PHA_PRINT("cell_sums barrier0 - scan place sum request histloop looptop", tid == 0 && blockIdx.x == 100);
     PH();
-#pragma unroll 1
-    for (int p = 0; p < P; ++p) {
-        uint32_t cell[kGndSlots];
-        float zz[kGndSlots];
-#pragma unroll
-        for (int j = 0; j < kGndSlots; ++j) {
-            cell[j] = lane < slice_n(p, j) ? ((nkey[j] & kKeyCellMask) >> 2) : 0xfffu;
-            zz[j] = nz[j];
-        }
-        request(kPartN, (p + 1) * kPartSlices + wv * kGndSlots, nkey, nz, nlo);
-        do_part(p, cell, zz);
-    }
-    PHA_PRINT("ground tlist - scan place sum - rank looptop", tid == 0 && blockIdx.x == 1500);
-    PH();
-
-    /* ---- the quarter's averages; meet the frame's other three quarters ---- */
-    /* (The averages travel with agent-scope stores and loads and the counter with agent-scope atomics: coherent wherever
-     * the four workgroups run, without a release fence — which would write back the XCD's whole L2, the walk's dirty lines
-     * included, once per wave.  __syncthreads() waits for the stores of every thread: they have reached their coherence
-     * point before the counter says so.) */
-    float *favg = b.avg + (size_t)f * kCells;
-    for (int c = tid; c < kCellsQ; c += kGndThreads)
-        if (c * kSumQ + quarter < kCells)
-            __hip_atomic_store(favg + c * kSumQ + quarter, sumv[c] / cntv[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* :210 */
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t *ctr = b.meet + f;
-        const uint32_t old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t target = (old & ~(uint32_t)(kSumQ - 1)) + (uint32_t)kSumQ; /* the counters advance by kSumQ per frame and launch */
-        uint32_t spins = 0u;
-        while ((int32_t)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            if (++spins > kMeetSpins) { /* (never seen: see the dispatch-order argument above) */
-                misc[2] = 1u;
-                if (b.err) __hip_atomic_store(b.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(32);
-        }
-    }
-    __syncthreads();
-    PH();
-
-    /* ---- phase C, BatchMultiBevGen.cpp:216-250 ---- */
-    /* Per cell, the LOWEST of its in-range 4-neighbours' averages: "any neighbour n with fl(z - avg[n]) >= 0.3f" is
-     * "fl(z - min_n avg[n]) >= 0.3f" — fl(z - a) does not increase with a, and the minimum passes over NaN averages exactly
-     * as the comparisons do (a difference with a NaN is never >= 0.3f).  One look-up and one subtraction per candidate
-     * instead of four of each with their range tests (bev_exact.h above_neighbour_ground, BatchMultiBevGen.cpp:227-241). */
-    float *avg_all = reinterpret_cast<float *>(lds);            /* [kCells]: over phase B's buffers, until minavg is made */
-    float *minavg = sumv;                                       /* [kCellsQ]: of the quarter's own cells */
-    uint32_t *tabs = reinterpret_cast<uint32_t *>(cntv);        /* the context's tables: edge_x[75], edge_y[50], band_tab[512 bytes] */
-    const int *edge_x = reinterpret_cast<const int *>(tabs), *edge_y = edge_x + kGridRows;
-    const uint8_t *band_tab = reinterpret_cast<const uint8_t *>(tabs + kGridRows + kGridCols);
-    uint32_t *band_cursor = tabs + kCtxTabWords;                /* [kMaxBands] */
-    uint2 *hits = reinterpret_cast<uint2 *>(lds) + (size_t)wv * kHitSlots * 64; /* this wave's un-grounded candidates of kHitSlots slices: key | height */
-    const bool gave_up = misc[2] != 0u;
-    for (int c = tid; c < kCells; c += kGndThreads) avg_all[c] = __hip_atomic_load(favg + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    lds_barrier(); /* (the sums have been read: their words take minavg and the tables) */
-    for (int cq = tid; cq < kCellsQ; cq += kGndThreads) {
-        const int c = cq * kSumQ + quarter;
-        float m = __uint_as_float(0x7fc00000u); /* NaN: no neighbour yet (fminf returns the other operand) */
-        if (c < kCells) {
-            const int sr = c / kGridCols, sc = c - sr * kGridCols;
-            if (sr - 1 >= 0) m = fminf(m, avg_all[c - kGridCols]);
-            if (sc + 1 < kGridCols) m = fminf(m, avg_all[c + 1]);
-            if (sc - 1 >= 0) m = fminf(m, avg_all[c - 1]);
-            if (sr + 1 < kGridRows) m = fminf(m, avg_all[c + kGridCols]);
-        }
-        minavg[cq] = m;
-    }
-    if (tid < kCtxTabWords) tabs[tid] = b.ctx_tab[tid];
-    if (tid < kMaxBands) band_cursor[tid] = 0u;
-    lds_barrier(); /* (the averages have been read: their words take the hit lists) */
-
-    const int bands = g.raster_bands;
-    const uint32_t code_cap = g.code_cap;
-    const gptr<uint16_t> flabel = (gptr<uint16_t>)(b.ordered + (size_t)f * g.S); /* label @28 of point i: [16 * i + 14] */
-    const bev_point_t *fordered = b.ordered + (size_t)f * g.S;
-    const gptr<uint32_t> flist = (gptr<uint32_t>)(b.code_main + ((size_t)f * g.emitters + g.strips + quarter) * bands * (size_t)g.code_stride);
-    RasterParams rp = g.rp; /* the fields the BEV code needs, in vector registers */
-    rp.max_range_f = in_vgpr(rp.max_range_f);
-    rp.lidar_to_ground = in_vgpr(rp.lidar_to_ground);
-    rp.mat_size = in_vgpr(rp.mat_size);
-    rp.n_layers = in_vgpr(rp.n_layers);
-    if (kPow2) {
-        rp.inv_interval = in_vgpr(rp.inv_interval);
-        rp.inv_height_res = in_vgpr(rp.inv_height_res);
-    } else {
-        rp.interval = in_vgpr(rp.interval);
-        rp.height_res = in_vgpr(rp.height_res);
-        rp.inv_interval = 0.0f;
-        rp.inv_height_res = 0.0f;
-    }
-    auto list_code = [&](uint32_t code) { /* one BEV code into this quarter's list of its raster band (an LDS cursor per band) */
-        if (code != kSkip) {
-            const int band = band_tab[code_x(code)];
-            const uint32_t pos = atomicAdd(&band_cursor[band], 1u);
-            flist[(uint32_t)band * g.code_stride + (pos < code_cap ? pos : code_cap - 1u)] = code;
-        }
-    };
-    /* A part's candidates against their cells' thresholds.  The un-grounded ones ("hits", an eighth of a benchmark
-     * frame's candidates, in every slice) are first gathered per wave — their codes are then built from full waves of
-     * hits instead of once per slice for a handful of lanes; wrong guesses (2 %) are patched on the spot. */
-    auto flush = [&](uint32_t &n_hits) { /* (this wave's own list: written and read in program order) */
-        for (uint32_t h0 = 0; h0 < n_hits; h0 += 64u) {
-            const bool on = h0 + (uint32_t)lane < n_hits;
-            const uint2 e = hits[on ? h0 + (uint32_t)lane : 0u];
-            const uint32_t cell = e.x & kKeyCellMask;
-            const uint32_t code = code_from_bins_t<kPow2>(edge_x[cell / kGridCols] + (int)((e.x >> kKeyDxShift) & 3u),
-                                                          edge_y[cell % kGridCols] + (int)((e.x >> kKeyDyShift) & 3u), __uint_as_float(e.y), rp);
-            list_code(on ? code : kSkip);
-        }
-        n_hits = 0u;
-    };
-    const uint32_t strips_magic = small_div_magic(strips); /* t / strips for t < 1024 (t * (magic * strips - 2^20) < 2^20) */
-    auto resolve = [&](int gs0, const uint32_t (&key)[kHitSlots], const float (&z)[kHitSlots], int lo) { /* slices gs0 .. gs0 + kHitSlots - 1 */
-        uint32_t n_hits = 0u; /* (wave-uniform) */
-#pragma unroll
-        for (int j = 0; j < kHitSlots; ++j) {
-            const int n = slice_count(gs0 + j);
-            if (n == 0) continue; /* wave-uniform */
-            const uint32_t kk = key[j];
-            const bool have = lane < n;
-            const uint32_t cell = kk & kKeyCellMask;
-            const bool hit = have && (z[j] - minavg[cell >> 2]) >= 0.3f;
-            const bool wrong = have && hit != ((kk & kKeyPredBit) != 0u);
-            const bool coded = hit && !(kk & kKeyNoCodeBit);
-            const bool escapes = coded && candidate_key_escapes(kk); /* cell clamped or bins not next to the cell's edge: x, y from the point itself */
-            const unsigned long long lm = __ballot(coded && !escapes);
-            if (coded && !escapes)
-                hits[n_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u))] = make_uint2(kk, __float_as_uint(z[j]));
-            n_hits += (uint32_t)__popcll(lm);
-            if (__ballot(wrong || escapes)) { /* (wave-uniform) the flat slot index: the candidate's segment + its column inside the strip */
-                const uint32_t i = 64u * (uint32_t)(gs0 + j) + (uint32_t)lane;
-                const int t = seg_of(__builtin_amdgcn_readlane(lo, j), __builtin_amdgcn_readlane(lo, j + 1), have ? i : 0u);
-                const int rr = small_div(t, strips_magic), strip = t - rr * strips; /* segment t = (row lo_row - 1 + rr, strip) */
-                const uint32_t idx = (uint32_t)((rr + lo_row - 1) * H + strip * kStripCols) + ((kk >> kKeyColShift) & 0xffu);
-                if (escapes) {
-                    const float4 a = *reinterpret_cast<const float4 *>(fordered + idx);
-                    list_code(code_t<kPow2>(a.x, a.y, a.z, 1 /* not 0: no kKeyNoCodeBit */, rp));
-                }
-                /* the walk's provisional label differs.  Not un-grounded: label = 0, BatchMultiBevGen.cpp:245; un-grounded:
-                 * the point's own label back — which is -2: the walk guesses "stays ground" only for points that carry it */
-                if (wrong) flabel[16u * idx + 14u] = hit ? (uint16_t)(int16_t)-2 : (uint16_t)0;
-            }
-        }
-        flush(n_hits);
-    };
-    if (!gave_up) { /* (workgroup-uniform) the candidates once more: a wave takes kHitSlots consecutive slices at a time (no
-                     * order to keep here), the next ones' loads in flight while it tests these */
-        const std::integral_constant<int, kHitSlots> kHitN{};
-        uint32_t nk[kHitSlots];
-        float nzz[kHitSlots];
-        int nl;
-        request(kHitN, wv * kHitSlots, nk, nzz, nl);
-#pragma unroll 1
-        for (int gs0 = wv * kHitSlots; gs0 < G; gs0 += kGndWaves * kHitSlots) {
-            uint32_t key[kHitSlots];
-            float zz[kHitSlots];
-            const int lo = nl;
-#pragma unroll
-            for (int j = 0; j < kHitSlots; ++j) {
-                key[j] = nk[j];
-                zz[j] = nzz[j];
-            }
-            request(kHitN, gs0 + kGndWaves * kHitSlots, nk, nzz, nl);
-            resolve(gs0, key, zz, lo);
-        }
-    }
-    lds_barrier();
-    if (tid < bands) b.ncode[((size_t)f * g.emitters + g.strips + quarter) * bands + tid] = band_cursor[tid];
-    PH();
-    PH_PRINT("ground init parts meet phaseC", tid == 0 && blockIdx.x == 1500);
+    float *avg = b.avg + (size_t)f * kCells;
+    for (int c = tid; c < kCellsQ; c += kSumThreads)
+        if (c * kSumQ + quarter < kCells) avg[c * kSumQ + quarter] = sumv[c] / cntv[c]; /* :210 */
+    PH_PRINT("cell_sums all-parts", tid == 0 && blockIdx.x == 100);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1928,6 +1726,148 @@ __global__ __launch_bounds__(256) void k_cloud_codes(const bev_point_t *__restri
     const float4 a = *reinterpret_cast<const float4 *>(cloud + i);
     const int label = (int)reinterpret_cast<const int16_t *>(cloud + i)[14];
     codes[i] = bev_code(a.x, a.y, a.z, label, rp);
+}
+
+/* ------------------------------------------------------------------------- */
+/* markGroundPoints phase C for the candidates, BatchMultiBevGen.cpp:216-250.  A candidate that is higher than a
+ * neighbour cell's average + 0.30 stops being ground ("hit"): it keeps / gets back its own label, and its BEV code —
+ * rebuilt from key and height, bev_exact.h — is appended to a code list of the raster band it falls into, exactly like
+ * the walk's lists (an LDS cursor per band, no global atomics): k_bev_raster reads both kinds the same way.  The walk
+ * wrote each candidate's label for its guess (key bit kKeyPredBit); only wrong guesses are patched.
+ * kResolveParts code lists per frame, a contiguous quarter of the segments each; kResolveWgs workgroups per frame (one:
+ * the frame's tables — 3,750 averages, their neighbour minima, edge bins, band table — cost as much as a part's
+ * candidates) walk kResolveParts / kResolveWgs parts each; a wave requests kResolveBatch segments (x 4 slices of 64
+ * candidates) at a time. */
+constexpr int kResolveBatch = 4;
+/* (round 3: the raster constants in vector registers and stores through address-space-1 pointers, as in the walk — a
+ * quarter of this kernel's vector instructions were v_readlane restores of spilled 8-dword argument tuples) */
+template <bool kPow2>
+__global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b, Geometry g)
+{
+    /* Per cell, the LOWEST of its in-range 4-neighbours' averages: "any neighbour n with fl(z - avg[n]) >= 0.3f" is
+     * "fl(z - min_n avg[n]) >= 0.3f" — fl(z - a) does not increase with a, and the minimum passes over NaN averages exactly
+     * as the comparisons do (a difference with a NaN is never >= 0.3f).  One look-up and one subtraction per candidate
+     * instead of four of each with their range tests (bev_exact.h above_neighbour_ground, BatchMultiBevGen.cpp:227-241). */
+    __shared__ float minavg[kCells];
+    __shared__ float avg[kCells];                        /* the frame's 75 x 50 averages */
+    __shared__ int edge_x[kGridRows], edge_y[kGridCols]; /* BEV bin of every ground-grid row's / column's lower edge */
+    __shared__ uint32_t band_cursor[kMaxBands];
+    __shared__ uint8_t band_tab[512];                    /* x bin -> raster band */
+    __shared__ uint16_t cnt[kMaxSegs / kResolveParts + 8];
+    constexpr int kPartsPerWg = kResolveParts / kResolveWgs;
+    const int f = blockIdx.x / kResolveWgs, part0 = (blockIdx.x - f * kResolveWgs) * kPartsPerWg;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = g.segs;
+    for (int c = tid; c < kCells; c += kResolveThreads) avg[c] = b.avg[(size_t)f * kCells + c];
+    if (tid < kGridRows) edge_x[tid] = cell_edge_bin(tid, 75.0f, g.rp);
+    else if (tid < kGridRows + kGridCols) edge_y[tid - kGridRows] = cell_edge_bin(tid - kGridRows, 50.0f, g.rp);
+    if (tid < kMaxBands) band_cursor[tid] = 0u;
+    for (int x = tid; x < g.rp.mat_size; x += kResolveThreads) band_tab[x] = (uint8_t)raster_band_of_nodiv(x, g.rp);
+    lds_barrier();
+    for (int c = tid; c < kCells; c += kResolveThreads) {
+        const int sr = c / kGridCols, sc = c % kGridCols;
+        float m = __uint_as_float(0x7fc00000u); /* NaN: no neighbour yet (fminf returns the other operand) */
+        if (sr - 1 >= 0) m = fminf(m, avg[c - kGridCols]);
+        if (sc + 1 < kGridCols) m = fminf(m, avg[c + 1]);
+        if (sc - 1 >= 0) m = fminf(m, avg[c - 1]);
+        if (sr + 1 < kGridRows) m = fminf(m, avg[c + kGridCols]);
+        minavg[c] = m;
+    }
+    lds_barrier();
+
+    constexpr int kSl = kSeg / 64;
+    constexpr int kWaves = kResolveThreads / 64;
+    const int bands = g.raster_bands, lo_row = g.N - g.G, H = g.H, strips = g.strips;
+    const uint2 *fcand = b.cand + (size_t)f * T * kSeg; /* key | height */
+    const uint32_t code_cap = g.code_cap;
+    const gptr<uint16_t> flabel = (gptr<uint16_t>)(b.ordered + (size_t)f * g.S); /* label @28 of point i: [16 * i + 14] */
+    const bev_point_t *fordered = b.ordered + (size_t)f * g.S;
+    RasterParams rp = g.rp; /* the fields the BEV code needs, in vector registers */
+    rp.max_range_f = in_vgpr(rp.max_range_f);
+    rp.lidar_to_ground = in_vgpr(rp.lidar_to_ground);
+    rp.mat_size = in_vgpr(rp.mat_size);
+    rp.n_layers = in_vgpr(rp.n_layers);
+    if (kPow2) {
+        rp.inv_interval = in_vgpr(rp.inv_interval);
+        rp.inv_height_res = in_vgpr(rp.inv_height_res);
+    } else {
+        rp.interval = in_vgpr(rp.interval);
+        rp.height_res = in_vgpr(rp.height_res);
+        rp.inv_interval = 0.0f;
+        rp.inv_height_res = 0.0f;
+    }
+  for (int part = part0; part < part0 + kPartsPerWg; ++part) { /* one code list set per part */
+    const int t0 = (int)((long long)T * part / kResolveParts), t1 = (int)((long long)T * (part + 1) / kResolveParts);
+    const gptr<uint32_t> flist = (gptr<uint32_t>)(b.code_main + ((size_t)f * g.emitters + g.strips + part) * bands * (size_t)g.code_stride);
+    if (part != part0) lds_barrier(); /* the previous part's cursors have been written out, its counts read */
+    for (int i = tid; i < t1 - t0; i += kResolveThreads) {
+        const uint32_t w = b.ncand[(size_t)f * T + t0 + i]; /* four byte-wide counts: the segment's runs by cell quarter, back to back */
+        cnt[i] = (uint16_t)((w & 0xffu) + ((w >> 8) & 0xffu) + ((w >> 16) & 0xffu) + (w >> 24));
+    }
+    if (tid < kMaxBands) band_cursor[tid] = 0u;
+    lds_barrier();
+    for (int s0 = t0 + wv; s0 < t1; s0 += kWaves * kResolveBatch) {
+        uint32_t key[kResolveBatch][kSl];
+        float z[kResolveBatch][kSl];
+#pragma unroll
+        for (int j = 0; j < kResolveBatch; ++j) {
+            const int sg = s0 + j * kWaves;
+            const int n = sg < t1 ? (int)cnt[sg - t0] : 0; /* wave-uniform */
+#pragma unroll
+            for (int k = 0; k < kSl; ++k) { /* whole slices, nothing but the loads inside the uniform test (see k_cell_sums) */
+                const size_t at = (size_t)(sg < t1 ? sg : t0) * kSeg + lane + 64 * k;
+                key[j][k] = 0u;
+                z[j][k] = 0.f;
+                if (64 * k < __builtin_amdgcn_readfirstlane(n)) {
+                    const uint2 kz = fcand[at];
+                    key[j][k] = kz.x;
+                    z[j][k] = __uint_as_float(kz.y);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kResolveBatch; ++j) {
+            const int sg = s0 + j * kWaves;
+            const int n = sg < t1 ? (int)cnt[sg - t0] : 0;
+            const int rr = sg / strips, strip = sg - rr * strips;
+            const uint32_t slot0 = (uint32_t)((rr + lo_row - 1) * H + strip * kStripCols);
+#pragma unroll
+            for (int k = 0; k < kSl; ++k) {
+                if (64 * k >= n) break; /* wave-uniform */
+                const uint32_t kk = key[j][k];
+                const bool have = lane + 64 * k < n;
+                const int cell = (int)(kk & kKeyCellMask);
+                const bool hit = have && (z[j][k] - minavg[cell]) >= 0.3f;
+                const bool pred = (kk & kKeyPredBit) != 0u;
+                const bool wrong = have && hit != pred;
+                if (!__ballot(hit || wrong)) continue; /* wave-uniform */
+                const uint32_t idx = slot0 + ((kk >> kKeyColShift) & 0xffu);
+                if (hit && !(kk & kKeyNoCodeBit)) {
+                    uint32_t code;
+                    if (!candidate_key_escapes(kk)) {
+                        code = code_from_bins_t<kPow2>(edge_x[cell / kGridCols] + (int)((kk >> kKeyDxShift) & 3u),
+                                                       edge_y[cell % kGridCols] + (int)((kk >> kKeyDyShift) & 3u), z[j][k], rp);
+                    } else { /* cell clamped or bins not next to the cell's edge: x, y from the point itself */
+                        const float4 a = *reinterpret_cast<const float4 *>(fordered + idx);
+                        code = code_t<kPow2>(a.x, a.y, a.z, 1 /* not 0: no kKeyNoCodeBit */, rp);
+                    }
+                    if (code != kSkip) {
+                        const int band = band_tab[code_x(code)];
+                        const uint32_t pos = atomicAdd(&band_cursor[band], 1u);
+                        flist[(uint32_t)band * g.code_stride + (pos < code_cap ? pos : code_cap - 1u)] = code;
+                    }
+                }
+                if (wrong) { /* the walk's provisional label differs */
+                    /* not un-grounded: label = 0, BatchMultiBevGen.cpp:245; un-grounded: the point's own label back —
+                     * which is -2: the walk guesses "stays ground" only for points that carry it */
+                    flabel[16u * idx + 14u] = hit ? (uint16_t)(int16_t)-2 : (uint16_t)0;
+                }
+            }
+        }
+    }
+    lds_barrier();
+    if (tid < bands) b.ncode[((size_t)f * g.emitters + g.strips + part) * bands + tid] = band_cursor[tid];
+  }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -2309,11 +2249,8 @@ __global__ __launch_bounds__(256) void k_angle_debug(const float *dx, const floa
 /* launchers                                                                  */
 hipError_t configure_kernels(const Geometry &g)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ground<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)GndDims::lds_bytes(kMaxSegs));
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_ground<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)GndDims::lds_bytes(kMaxSegs));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_cell_sums),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SumDims::lds_bytes(kMaxSegs));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_bev_raster), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)raster_lds_bytes(g));
@@ -2367,13 +2304,17 @@ void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream
     if (nf == 0) return;
     hipLaunchKernelGGL(k_gather_only, dim3(xcd_grid(nf, g.tiles)), dim3(kGatherThreads), 0, st, b, g, nf);
 }
-void launch_ground(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
+void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
+{
+    if (nf == 0) return;
+    hipLaunchKernelGGL(k_cell_sums, dim3(xcd_grid(nf, kSumQ)), dim3(kSumThreads), SumDims::lds_bytes(g.segs), st, b, g, nf);
+}
+void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {
     if (nf == 0) return;
     const bool pow2 = g.rp.inv_interval != 0.0f && g.rp.inv_height_res != 0.0f;
-    const dim3 gr(xcd_grid(nf, kSumQ)), bl(kGndThreads);
-    if (pow2) hipLaunchKernelGGL(k_ground<true>, gr, bl, GndDims::lds_bytes(g.segs), st, b, g, nf);
-    else hipLaunchKernelGGL(k_ground<false>, gr, bl, GndDims::lds_bytes(g.segs), st, b, g, nf);
+    if (pow2) hipLaunchKernelGGL(k_ground_resolve<true>, dim3(nf * kResolveWgs), dim3(kResolveThreads), 0, st, b, g);
+    else hipLaunchKernelGGL(k_ground_resolve<false>, dim3(nf * kResolveWgs), dim3(kResolveThreads), 0, st, b, g);
 }
 void launch_bev_raster(const Geometry &g, const BatchPtrs &b, bool want_multi, bool want_single, int nf, hipStream_t st)
 {
