@@ -40,7 +40,7 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU (BASELINE config: 1000)")
     ap.add_argument("--sensor", default=None)
-    ap.add_argument("--workload", default="hdl64_sweep", choices=["hdl64_sweep", "os1_firing", "oxford_concat", "hdl64_structured"],
+    ap.add_argument("--workload", default="hdl64_sweep", choices=["hdl64_sweep", "os1_firing", "oxford_concat", "hdl64_structured", "os1_firing_real", "mixed"],
                     help="hdl64_sweep = BASELINE configs[1]/[3] (default, the graded metric); os1_firing = configs[2] "
                          "(MulRan-style unordered OS1_64); oxford_concat = configs[4] (HDL_32E, ~2M points per frame); "
                          "hdl64_structured = the same sweeps in the layout the reference's KITTI selector writes "
@@ -118,7 +118,7 @@ def main() -> int:
         raise SystemExit(f"{bev_amd.LIB_PATH} missing")
 
     default_sensor = {"hdl64_sweep": "HDL_64E", "os1_firing": "OS1_64", "oxford_concat": "HDL_32E",
-                      "hdl64_structured": "HDL_64E"}[args.workload]
+                      "hdl64_structured": "HDL_64E", "os1_firing_real": "OS1_64", "mixed": "HDL_64E"}[args.workload]
     args.sensor = args.sensor or default_sensor
     p = bev_amd.params_for_sensor(args.sensor)
     S, M, L = p.slots, p.mat_size, p.n_layers
@@ -132,7 +132,8 @@ def main() -> int:
     # ---- synthetic frames, generated on the host cores, then made resident in HBM
     n_dup = args.n_dup
     n_sweeps = 60
-    cap = {"hdl64_sweep": S + n_dup, "os1_firing": S, "oxford_concat": S * n_sweeps, "hdl64_structured": S}[args.workload]
+    cap = {"hdl64_sweep": S + n_dup, "os1_firing": S, "oxford_concat": S * n_sweeps, "hdl64_structured": S,
+           "os1_firing_real": S, "mixed": S + n_dup}[args.workload]
     t_gen = time.time()
     host = np.empty((count, cap), dtype=bev_amd.POINT_DTYPE)
     counts = np.zeros(count, dtype=np.int64)
@@ -147,6 +148,23 @@ def main() -> int:
         elif args.workload == "hdl64_structured":
             host[i] = synth.structured(p, first + i, keep=0.98)
             counts[i] = S
+        elif args.workload == "os1_firing_real":
+            # what mulran_point_cloud_select writes for real sweeps (MulranPointCloudSelect.cpp:112-130): 3 % no-return
+            # records (column 0 of their row), start azimuth and direction drawn per frame, staggered laser columns
+            host[i] = synth.firing_real(p, first + i, noret=0.03)
+            counts[i] = S
+        elif args.workload == "mixed":
+            # the layouts of the reference's producers alternating in groups of 32 frames (the CLI's batch): sorted sweeps
+            # with appended duplicates, structured clouds, firing order
+            kind = ((first + i) // 32) % 3
+            if kind == 0:
+                counts[i] = len(synth.sweep(p, first + i, keep=0.98, n_dup=n_dup, out=host[i]))
+            elif kind == 1:
+                host[i, :S] = synth.structured(p, first + i, keep=0.98)
+                counts[i] = S
+            else:
+                host[i, :S] = synth.firing_real(p, first + i, noret=0.03)
+                counts[i] = S
         else:
             pts = synth.concat(p, first + i, n_sweeps=n_sweeps)
             host[i, :len(pts)] = pts
@@ -229,6 +247,8 @@ def main() -> int:
         stats = ctx.profile_get()
         ctx.profile_enable(False)
 
+    n_last = count - ((count - 1) // args.sub_batch) * args.sub_batch
+    routes = {str(k): int(v) for k, v in zip(*np.unique(ctx.frame_info(0, n_last)[:, 1], return_counts=True))}
     # ---- per-kernel HIP-event durations of the roofline pass (this rank)
     mean_pts = total_pts / count
     b_frame = bev_amd.algorithmic_bytes_per_frame(p, mean_pts)  # 32P + 32S + L*M*M + M*M
@@ -241,6 +261,7 @@ def main() -> int:
     else:  # k_walk: frames read in place; k_walk_general: frames that go through the winner table (only one of the two moves a frame)
         own_bytes = {"k_walk": 32.0 * mean_pts + 32.0 * S, "k_walk_general": 32.0 * mean_pts + 32.0 * S,
                      "k_walk_structured": 32.0 * mean_pts + 32.0 * S, "k_walk_colmajor": 32.0 * mean_pts + 32.0 * S,
+                     "k_walk_colmajor_gen": 32.0 * mean_pts + 32.0 * S,
                      "k_bev_raster": float(L * M * M + M * M)}
     roofline = None
     kernels = []
@@ -268,9 +289,9 @@ def main() -> int:
         traffic, traffic_src, traffic_total = None, None, None
         # which instantiation of the walk a profile id is (rocprofv3 names kernels by their template arguments)
         pmc_prefix = {"k_walk": "k_walk<2,", "k_walk_general": "k_walk<0,", "k_walk_structured": "k_walk<3,",
-                      "k_walk_colmajor": "k_walk<4,"}.get(dom["name"], dom["name"])
+                      "k_walk_colmajor": "k_walk<4,", "k_walk_colmajor_gen": "k_walk<5,"}.get(dom["name"], dom["name"])
         tag = "" if args.workload == "hdl64_sweep" else args.workload + "_"
-        rounds = ("r04",) if args.workload != "hdl64_sweep" else ("r04", "r03", "r02")
+        rounds = ("r05", "r04") if args.workload != "hdl64_sweep" else ("r05", "r04", "r03", "r02")
         for name in (f"{r}_{tag}pmc_traffic.json" for r in rounds):
             pmc_file = REPO / "profiles" / name
             if not pmc_file.exists():
@@ -399,6 +420,10 @@ def main() -> int:
             "kernels": kernels,
             "kernels_pipelined": kernels_pipelined,
             "gen_seconds": t_gen,
+            # how the frames of the last sub-batch reached their slots (bev_debug_get_frame_info): 0 general, 1 sorted prefix read
+            # in place, 2 read in place, failed its checks and redone, 3 structured cloud, 4 firing order (the plain sweep), 5 firing order (any phase,
+            # direction, stagger, no-return records)
+            "routes_last_sub_batch": routes,
         }
         print(json.dumps(out))
     ctx.close()

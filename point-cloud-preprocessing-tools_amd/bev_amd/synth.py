@@ -22,6 +22,8 @@ def _load():
         lib.bev_synth_sweep.restype = C.c_size_t
         lib.bev_synth_firing_order.argtypes = [P, C.c_uint64, C.c_uint32, C.c_void_p, C.c_size_t]
         lib.bev_synth_firing_order.restype = C.c_size_t
+        lib.bev_synth_firing_real.argtypes = [P, C.c_uint64, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_size_t]
+        lib.bev_synth_firing_real.restype = C.c_size_t
         lib.bev_synth_concat.argtypes = [P, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double, C.c_void_p, C.c_size_t]
         lib.bev_synth_concat.restype = C.c_size_t
         lib.bev_synth_adversarial.argtypes = [P, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t]
@@ -59,6 +61,23 @@ def firing_order(params: BevParams, frame_id: int, seed: int = SEED_BASE) -> np.
     lib = _load()
     buf = np.empty(params.slots, dtype=POINT_DTYPE)
     n = lib.bev_synth_firing_order(C.byref(params), seed, frame_id, buf.ctypes.data, buf.shape[0])
+    return buf[:n]
+
+
+def firing_real(params: BevParams, frame_id: int, noret: float = 0.03, phase: int | None = None, direction: int | None = None,
+                stagger: float = 1.0, seed: int = SEED_BASE) -> np.ndarray:
+    """What mulran_point_cloud_select writes for a real Ouster sweep (MulranPointCloudSelect.cpp:112-130): firing order with
+    an arbitrary start azimuth (`phase`, columns; default: drawn from the frame id), either direction of rotation (default:
+    drawn), the four staggered laser columns (+9, +3, -3, -9 columns by beam mod 4, scaled by `stagger`) and a share `noret`
+    of no-return records (x = y = z = 0 -> atan2(0, 0) = 0 -> column 0 of their row)."""
+    lib = _load()
+    h = (frame_id * 2654435761 + 12345) & 0xFFFFFFFF
+    if phase is None:
+        phase = h % params.horizon_scan
+    if direction is None:
+        direction = 1 if (h >> 20) & 1 else -1
+    buf = np.empty(params.slots, dtype=POINT_DTYPE)
+    n = lib.bev_synth_firing_real(C.byref(params), seed, frame_id, noret, int(phase), int(direction), stagger, buf.ctypes.data, buf.shape[0])
     return buf[:n]
 
 

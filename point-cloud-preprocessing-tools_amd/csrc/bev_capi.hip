@@ -49,6 +49,8 @@ struct Lane {
     int mode_absent[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* looks at hint[1] since it last showed the mode (see run_pipeline) */
     uint32_t *est = nullptr;    /* stream frames: estimated input position of every (row, strip)'s first slot */
     uint32_t *tail_list = nullptr, *tail_cnt = nullptr; /* ... and their tail points per (row, strip) (stream mode only) */
+    int32_t *cm_par = nullptr;   /* firing-order frames: direction and row bases (k_probe) */
+    uint32_t *cm_sync = nullptr; /* ... and what their strips tell each other and k_verdict about column 0 */
     uint32_t *winner = nullptr;
     uint32_t win_gen = 0; /* generation tag of the last sub-batch that used this set's winner table */
     uint2 *cand = nullptr; /* candidate key | height */
@@ -452,6 +454,8 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.est = ln.est;
         b.tail_list = ln.tail_list;
         b.tail_cnt = ln.tail_cnt;
+        b.cm_par = ln.cm_par;
+        b.cm_sync = ln.cm_sync;
         b.winner = ln.winner;
         b.win_shift = c->win_shift;
         b.ordered = d_ordered + (size_t)f0 * S;
@@ -516,9 +520,13 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                 ProfScope ps(c, K_WALK_COLMAJOR, nb, st);
                 launch_gather_ground(g, b, nb, 4, kFrameColMajor, st);
             }
+            if (c->allow_stream && n_exact_s > 0 && ln.cm_par && (seen & (1u << kFrameColMajorGen))) { /* ... from any start azimuth, in either direction, with staggered beams and no-return records */
+                ProfScope ps(c, K_WALK_COLMAJOR_GEN, nb, st);
+                launch_gather_ground(g, b, nb, 5, kFrameColMajorGen, st);
+            }
             if (c->allow_stream) {
                 ProfScope ps(c, K_VERDICT, nb, st);
-                launch_verdict(b, nb, ln.hint, st);
+                launch_verdict(g, b, nb, ln.hint, st);
             }
             {   /* every other frame — general, or read in place and failed (normally none of a sorted sub-batch).  Thin
                  * launch while this workspace set's earlier sub-batches were read in place entirely (a hint that k_verdict
@@ -770,6 +778,10 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
             CK(hipMalloc((void **)&ln.tail_list, nb * (size_t)c->geo.N * c->geo.strips * kTailCap * sizeof(uint32_t))); /* (lanes past a list's count fetch its word 0) */
             CK(hipMalloc((void **)&ln.tail_cnt, nb * (size_t)c->geo.N * c->geo.strips * sizeof(uint32_t)));
         }
+        if (c->allow_stream && c->geo.N <= kCmMaxRows && c->geo.strips <= kCmMaxStrips) {
+            CK(hipMalloc((void **)&ln.cm_par, nb * (size_t)kCmParWords * sizeof(int32_t)));
+            CK(hipMalloc((void **)&ln.cm_sync, nb * (size_t)kCmSyncWords * sizeof(uint32_t)));
+        }
         CK(hipMalloc((void **)&ln.winner, nb * S * sizeof(uint32_t)));
         CK(hipMemset(ln.winner, 0, nb * S * sizeof(uint32_t)));
         /* (+ one segment of slack: whole 64-slices are read past a short segment's count) */
@@ -812,7 +824,7 @@ void bev_destroy(bev_ctx_t *c)
     for (int l = 0; l < kMaxLanes; ++l) {
         Lane &ln = c->lanes[l];
         if (ln.st) (void)hipStreamSynchronize(ln.st);
-        void *ws[] = {ln.info, ln.est, ln.tail_list, ln.tail_cnt, ln.winner, ln.cand, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
+        void *ws[] = {ln.info, ln.est, ln.tail_list, ln.tail_cnt, ln.cm_par, ln.cm_sync, ln.winner, ln.cand, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
         for (void *p : ws)
             if (p) (void)hipFree(p);
         if (ln.hint) (void)hipHostFree(ln.hint);

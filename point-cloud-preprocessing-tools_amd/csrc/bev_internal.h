@@ -74,8 +74,8 @@ struct FrameDesc {
  *                  firing's number plus 0 .. 8 (or out of range: dropped).  The walk fetches a strip's firings band by
  *                  band (two rows of a firing are one 64-byte sector), settles the last writer of every slot in an LDS
  *                  index row and checks every record it fetches. */
-enum : uint32_t { kFrameGeneral = 0, kFrameStream = 1, kFrameRedo = 2, kFrameStructured = 3, kFrameColMajor = 4 };
-__host__ __device__ inline bool frame_read_in_place(uint32_t mode) { return mode == kFrameStream || mode == kFrameStructured || mode == kFrameColMajor; }
+enum : uint32_t { kFrameGeneral = 0, kFrameStream = 1, kFrameRedo = 2, kFrameStructured = 3, kFrameColMajor = 4, kFrameColMajorGen = 5 };
+__host__ __device__ inline bool frame_read_in_place(uint32_t mode) { return mode == kFrameStream || mode == kFrameStructured || mode == kFrameColMajor || mode == kFrameColMajorGen; }
 struct FrameInfo {
     uint32_t T;        /* length of the prefix taken for sorted (structured: S) */
     uint32_t mode;
@@ -85,6 +85,8 @@ struct FrameInfo {
                         * all-zero record after the first, bit 2: k_probe guessed that there is one */
 };
 constexpr uint32_t kInfoFailed = 1u, kInfoZeroSeen = 2u, kInfoZeroGuess = 4u;
+constexpr uint32_t kInfoCmStray = 8u; /* firing-order frames whose strips do not talk: a strip other than 0 owns a no-return record: k_verdict checks that it would not have won column 0 */
+constexpr uint32_t kInfoCmUsed = 2u; /* firing-order frames: a wrap-around halo fell back on column 0 somewhere: k_verdict compares what it took with what strip 0 put there */
 #ifndef BEV_PROBE_STRIDE
 #define BEV_PROBE_STRIDE 63
 #endif
@@ -95,7 +97,21 @@ constexpr int kStreamMinPrefix = 2048;
 constexpr int kTailCap = 64;         /* tail points (those after the sorted prefix) a (row, strip) can list; more: general way */
 constexpr int kTailMax = 16384;     /* ... a frame can have */
 constexpr int kTailBuckets = 2048;  /* (row, strip) pairs of a frame that k_probe can count in LDS */
-constexpr int kColMaxDisp = 8;       /* kFrameColMajor: a return's column is its firing's number + 0 .. kColMaxDisp (or >= H: dropped) */
+/* kFrameColMajor (round 5: any start azimuth, either direction of rotation, staggered beams, no-return records): with
+ * u = +-firing mod H (the sweep's direction) a return of row r has column (u + B[r] + 0 .. kColMaxDisp) mod H, B[r] the
+ * row's base (start azimuth + the beam's azimuth offset), or is out of range (>= H: dropped), or sits in column 0 whatever
+ * its firing (a no-return record: x = y = 0 -> atan2(0, 0) = 0, MulranPointCloudSelect.cpp:123-125). */
+constexpr int kColMaxDisp = 12;      /* (a row's displacements may spread over 8 columns and still leave k_probe, which sees every 63rd record, two columns of slack on either side) */
+constexpr int kCmSpread = 18;        /* the rows' bases lie within this many columns of each other (an OS1-64's four laser columns: +-9) */
+constexpr int kCmProbeDisp = kColMaxDisp; /* spread of a row's SAMPLED displacements that k_probe accepts; what is left of kColMaxDisp is put half below, half above them, for the records it did not see */
+constexpr int kCmExt = 16;           /* firings behind the 256 threads' that a strip fetches as well: 272 >= 240 columns + kColMaxDisp + kCmSpread */
+constexpr int kCmMaxRows = 128;      /* sensors with more rows go the general way */
+constexpr int kCmMaxSamples = 4096;  /* k_probe keeps this many samples (and their successors) for the analysis: frames of up to 258 k records */
+constexpr int kCmParWords = 4 + kCmMaxRows; /* per frame: direction (+1 / -1 as int), the largest base (mod H), the rows' bases, how far apart the bases lie, whether a sample was a no-return record */
+constexpr uint32_t kCmUsedBit = 0x80000000u;
+constexpr int kCmMaxStrips = 16;     /* strips other than 0 tell strip 0 about their no-return records, two words per band of two rows each: frames of more strips go the general way */
+constexpr int kCmPubWords = (kCmMaxRows / 2) * kCmMaxStrips * 2; /* BatchPtrs::cm_sync per frame: [band][strip][2] reports, then [row] what strip 0 put into column 0, then [row] what a wrap-around halo took for it */
+constexpr int kCmSyncWords = kCmPubWords + 3 * kCmMaxRows; /* ... then [row] the last no-return firing + 1 that a strip other than 0 owns, for frames whose strips do not talk (k_verdict compares) */
 constexpr int kStreamMaxRows = 64;   /* sensors with more rows go the general way (the stream walk keeps per-row estimates in LDS) */
 
 /* Workspace streams between the kernels of one sub-batch (see bev_exact.h for the candidate key):
@@ -134,6 +150,10 @@ struct BatchPtrs {
     uint32_t *est;               /* [nf][strips][N]: stream frames: estimated input position of slot (r, first column of strip - 2) */
     uint32_t *tail_list;         /* [nf][N][strips][kTailCap]: stream frames: column offset | input index << 8 of the tail points (nullptr: no stream mode) */
     uint32_t *tail_cnt;          /* [nf][strips][N] */
+    int32_t *cm_par;             /* [nf][kCmParWords]: kFrameColMajor: the frame's direction and row bases (k_probe) */
+    uint32_t *cm_sync;           /* [nf][kCmSyncWords]: kFrameColMajor, zeroed by k_probe: per band of two rows and strip: kCmUsedBit | the last no-return firing + 1 of either row
+                                  * that the strip owns; per row: the firing + 1 whose record strip 0 put into column 0; per row: kCmUsedBit | the firing + 1 that the
+                                  * strip with the wrap-around halo took for column 0 when column H - 2 fell back on it */
     uint32_t *winner;            /* [nf][S]  (win_tag << win_shift) | index+1 of the last input point per slot */
     uint32_t win_tag;            /* generation of this sub-batch in its workspace set (0: table was cleared) */
     int win_shift;               /* bits of index+1 */
@@ -165,7 +185,8 @@ enum KernelId {
     K_PROBE,
     K_WALK_GENERAL, /* the walk through the winner table (K_GATHER_GROUND: the walk that reads in place, or the identity walk) */
     K_WALK_STRUCTURED, /* the walk over structured clouds (kFrameStructured) */
-    K_WALK_COLMAJOR,   /* the walk over clouds in firing order (kFrameColMajor) */
+    K_WALK_COLMAJOR,   /* the walk over clouds in firing order: the plain sweep (kFrameColMajor) */
+    K_WALK_COLMAJOR_GEN, /* ... any start azimuth, direction, staggered beams, no-return records (kFrameColMajorGen) */
     K_VERDICT,
     K_COUNT
 };
@@ -182,7 +203,7 @@ void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t m
  * order (kFrameColMajor) */
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int source, uint32_t mode, hipStream_t st);
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st);
-void launch_verdict(const BatchPtrs &b, int nf, uint32_t *host_hint, hipStream_t st);
+void launch_verdict(const Geometry &g, const BatchPtrs &b, int nf, uint32_t *host_hint, hipStream_t st);
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
 void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
 void launch_ground_resolve(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);

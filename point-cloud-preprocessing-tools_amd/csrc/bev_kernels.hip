@@ -63,7 +63,7 @@ namespace bevk {
 static const char *const kNames[K_COUNT] = {
     "k_order_scan", "k_walk", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project", "k_transform",
-    "k_probe", "k_walk_general", "k_walk_structured", "k_walk_colmajor", "k_verdict",
+    "k_probe", "k_walk_general", "k_walk_structured", "k_walk_colmajor", "k_walk_colmajor_gen", "k_verdict",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
 
@@ -158,13 +158,19 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
     /* a structured cloud (kFrameStructured): exactly S records, every sampled one its own slot's point or empty */
     const bool can_struct = allow_stream && n == (uint32_t)g.S;
     /* ... or S returns in firing order (kFrameColMajor): every sampled record is beam (position mod N) of firing
-     * (position / N), its column the firing's number + 0 .. 8 or out of range */
-    __shared__ uint32_t struct_bad, struct_zero, cm_bad;
+     * (position / N); its column follows the firing — in either direction, from any start azimuth, with a base of its own
+     * per row (staggered beams) — or is out of range, or is column 0 (a no-return record): see below */
+    __shared__ uint32_t struct_bad, struct_zero, cm_bad, cm_not_plain;
+    const bool can_cm = can_struct && g.N >= 2; /* (the plain sweep) */
+    const bool can_cm_gen = can_cm && g.N <= kCmMaxRows && g.strips <= kCmMaxStrips && ns <= (uint32_t)kCmMaxSamples && b.cm_par != nullptr;
+    __shared__ uint32_t cmrc[kCmMaxSamples], cmrc1[kCmMaxSamples]; /* row | col << 16 of every sample and of its successor */
+    __shared__ uint32_t cm_ref[kCmMaxRows], cm_lo[kCmMaxRows], cm_hi[kCmMaxRows], cm_base[kCmMaxRows], cm_misc[4];
     if (tid == 0) {
         first_bad = can ? ns : 0u;
         struct_bad = 0u;
         struct_zero = 0u;
         cm_bad = 0u;
+        cm_not_plain = 0u;
     }
     __syncthreads();
     if (can || can_struct) {
@@ -195,15 +201,19 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
                     if (can_struct) { /* the successor: position i + 1 >= 1 */
                         if (sl1 != (uint32_t)(i + 1) && rc1[u] != 0u) struct_bad = 1u;
                         if (rc1[u] == 0u) struct_zero = 1u;
-                        const uint32_t fire1 = (uint32_t)(i + 1) / (uint32_t)g.N, beam1 = (uint32_t)(i + 1) - fire1 * (uint32_t)g.N;
-                        if (row1 != beam1 || (col1 < (uint32_t)g.H && col1 - fire1 > (uint32_t)kColMaxDisp)) cm_bad = 1u;
+                        if (row1 != (uint32_t)(i + 1) % (uint32_t)g.N) cm_bad = 1u;
+                        if (col1 < (uint32_t)g.H && col1 - (uint32_t)(i + 1) / (uint32_t)g.N > 8u) cm_not_plain = 1u; /* (the plain sweep: column = firing + 0 .. 8) */
                     }
                 }
                 if (can_struct) {
                     if (sl0 != (uint32_t)i && rc[u] != 0u) struct_bad = 1u;
                     if (rc[u] == 0u && i >= 1) struct_zero = 1u;
-                    const uint32_t fire = (uint32_t)i / (uint32_t)g.N, beam = (uint32_t)i - fire * (uint32_t)g.N;
-                    if (row != beam || (col < (uint32_t)g.H && col - fire > (uint32_t)kColMaxDisp)) cm_bad = 1u;
+                    if (row != (uint32_t)i % (uint32_t)g.N) cm_bad = 1u;
+                    if (col < (uint32_t)g.H && col - (uint32_t)i / (uint32_t)g.N > 8u) cm_not_plain = 1u;
+                }
+                if (can_cm_gen) {
+                    cmrc[k] = rc[u];
+                    cmrc1[k] = i + 1 < n ? rc1[u] : 0xffffffffu; /* (col 0xffff: out of range, not looked at) */
                 }
                 if (can) samp[k] = sl;
             }
@@ -213,9 +223,119 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
             if (tid == 0) b.info[f] = FrameInfo{n, kFrameStructured, 0u, struct_zero ? kInfoZeroGuess : 0u};
             return;
         }
-        if (can_struct && !cm_bad && g.N >= 2) {
+        /* Firing order: which way does the sweep turn, and where does every row start?  With u = +-firing mod H the
+         * displacement d = (col - u) mod H of a row's returns is the row's base plus a few columns of jitter.  Both
+         * directions are tried; the one under which every row's SAMPLED displacements lie within kCmProbeDisp columns of
+         * each other (and the rows' bases within kCmSpread) is taken and the bases are put kColMaxDisp - spread halves below
+         * the smallest sample.  Column 0 is left out (no-return records sit there whatever their firing) and so are
+         * columns >= H.  Nothing of this is trusted: the walk checks every record against its row's base. */
+        if (can_cm && !cm_bad && !cm_not_plain) {
+            /* the plain sweep (BASELINE config 3): starts at azimuth 0, turns forward, every sampled return within 0 .. 8 columns
+             * of its firing, no no-return record among the samples: round 4's walk (which takes anything else for a defect) */
             if (tid == 0) b.info[f] = FrameInfo{n, kFrameColMajor, 0u, 0u};
             return;
+        }
+        if (can_cm_gen && !cm_bad) {
+            const uint32_t H = (uint32_t)g.H, N = (uint32_t)g.N;
+            constexpr uint32_t kBias = 1u << 20;
+            /* pos / N for pos < S <= 2^20 and N <= 128 as a multiplication: with m = ceil(2^32 / N), pos * m / 2^32 exceeds
+             * pos / N by less than 2^-12, and pos / N lies 1 / 128 or more below the next integer unless it is one */
+            const uint32_t n_magic = (uint32_t)((0x100000000ull + N - 1u) / N);
+            auto div_n = [&](uint32_t pos) -> uint32_t { return N == 1u ? pos : __umulhi(pos, n_magic); };
+            for (int pass = 0; pass < 2; ++pass) {
+                const bool fwd = pass == 0;
+                for (uint32_t r = tid; r < N; r += kProbeThreads) {
+                    cm_ref[r] = 0xffffffffu;
+                    cm_lo[r] = 0xffffffffu;
+                    cm_hi[r] = 0u;
+                }
+                if (tid < 4) cm_misc[tid] = tid == 1 ? 0xffffffffu : 0u; /* [0] failed, [1] smallest / [2] largest base offset (biased), [3] a row that has samples + 1 */
+                __syncthreads();
+                auto disp = [&](uint32_t pos, uint32_t rcw, uint32_t *row, uint32_t *d) -> bool { /* a sample that says something about its row's base */
+                    const uint32_t col = rcw >> 16;
+                    if (col == 0u || col >= H) return false;
+                    const uint32_t fire = div_n(pos); /* (< H: the frame has S = N * H records) */
+                    *row = pos - fire * N;
+                    const uint32_t u = fwd ? fire : (fire ? H - fire : 0u);
+                    *d = col >= u ? col - u : col + H - u;
+                    return true;
+                };
+                for (uint32_t k = tid; k < ns; k += kProbeThreads) {
+                    uint32_t row, d;
+                    if (disp(k * kProbeStride, cmrc[k], &row, &d)) cm_ref[row] = d; /* (any sample of the row will do as its reference) */
+                    if (disp(k * kProbeStride + 1u, cmrc1[k], &row, &d)) cm_ref[row] = d;
+                }
+                __syncthreads();
+                auto rel = [&](uint32_t d, uint32_t ref) -> uint32_t { /* d - ref as a signed offset around the circle, biased */
+                    const uint32_t t = d >= ref ? d - ref : d + H - ref;
+                    return t > H / 2u ? kBias + t - H : kBias + t;
+                };
+                for (uint32_t k = tid; k < ns; k += kProbeThreads) {
+                    uint32_t row, d;
+                    if (disp(k * kProbeStride, cmrc[k], &row, &d)) {
+                        atomicMin(&cm_lo[row], rel(d, cm_ref[row]));
+                        atomicMax(&cm_hi[row], rel(d, cm_ref[row]));
+                    }
+                    if (disp(k * kProbeStride + 1u, cmrc1[k], &row, &d)) {
+                        atomicMin(&cm_lo[row], rel(d, cm_ref[row]));
+                        atomicMax(&cm_hi[row], rel(d, cm_ref[row]));
+                    }
+                }
+                __syncthreads();
+                for (uint32_t r = tid; r < N; r += kProbeThreads) {
+                    if (cm_ref[r] == 0xffffffffu) continue; /* a row without a usable sample: takes another row's base below */
+                    const uint32_t spread = cm_hi[r] - cm_lo[r];
+                    if (spread > (uint32_t)kCmProbeDisp) cm_misc[0] = 1u;
+                    /* base = reference + smallest offset - half of the slack, mod H (offsets are small against H, or H is tiny and anything goes) */
+                    const uint32_t slack = ((uint32_t)kColMaxDisp - (spread < (uint32_t)kColMaxDisp ? spread : (uint32_t)kColMaxDisp) + 1u) / 2u;
+                    const uint32_t off = cm_lo[r] - slack; /* biased */
+                    cm_base[r] = (cm_ref[r] + (off % H) + (H - kBias % H)) % H;
+                    cm_misc[3] = r + 1u;
+                }
+                __syncthreads();
+                if (cm_misc[0] == 0u && cm_misc[3] != 0u) {
+                    const uint32_t r0 = cm_misc[3] - 1u, bc = cm_base[r0];
+                    for (uint32_t r = tid; r < N; r += kProbeThreads) {
+                        if (cm_ref[r] == 0xffffffffu) cm_base[r] = bc;
+                        atomicMin(&cm_misc[1], rel(cm_base[r], bc));
+                        atomicMax(&cm_misc[2], rel(cm_base[r], bc));
+                    }
+                    __syncthreads();
+                    const uint32_t max_spread = (uint32_t)kCmSpread;
+                    if (cm_misc[2] - cm_misc[1] <= max_spread) {
+                        /* does the frame hold no-return records (column 0, away from where the firing's returns lie)?  Then
+                         * its strips talk to each other about them (k_walk: listen_band); a frame whose samples show none is
+                         * walked without that — and redone if a record the samples missed turns out to matter */
+                        if (tid == 0) cm_misc[0] = 0u;
+                        __syncthreads();
+                        for (uint32_t k = tid; k < ns; k += kProbeThreads) {
+#pragma unroll
+                            for (int w = 0; w < 2; ++w) {
+                                const uint32_t rcw = w ? cmrc1[k] : cmrc[k], pos = k * kProbeStride + (uint32_t)w;
+                                if ((rcw >> 16) != 0u) continue;
+                                const uint32_t fire = div_n(pos), row = pos - fire * N;
+                                const uint32_t u = fwd ? fire : (fire ? H - fire : 0u);
+                                const uint32_t d = (2u * H - u - cm_base[row]) % H; /* (0 - u - base) mod H */
+                                if ((rcw & 0xffffu) == row && d > (uint32_t)kColMaxDisp) cm_misc[0] = 1u;
+                            }
+                        }
+                        __syncthreads();
+                        int32_t *par = b.cm_par + (size_t)f * kCmParWords;
+                        uint32_t *sync = b.cm_sync + (size_t)f * kCmSyncWords;
+                        for (uint32_t r = tid; r < N; r += kProbeThreads) par[2 + r] = (int32_t)cm_base[r];
+                        for (uint32_t i = tid; i < (uint32_t)kCmSyncWords; i += kProbeThreads) sync[i] = 0u;
+                        if (tid == 0) {
+                            par[0] = fwd ? 1 : -1;
+                            par[1] = (int32_t)((bc + (cm_misc[2] % H) + (H - kBias % H)) % H); /* the largest base */
+                            par[2 + kCmMaxRows] = (int32_t)(cm_misc[2] - cm_misc[1]);         /* how far apart the bases lie */
+                            par[3 + kCmMaxRows] = (int32_t)cm_misc[0];                         /* a sample was a no-return record */
+                            b.info[f] = FrameInfo{n, kFrameColMajorGen, 0u, 0u};
+                        }
+                        return;
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
     if (can) {
@@ -345,7 +465,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
 /* host_hint[1]: which modes k_probe gave the sub-batch's frames (bit = mode).  The host launches the walk of a mode only
  * while the workspace set's last sub-batches had frames of it — a frame whose walk was not launched fails the count
  * below and is redone the general way, so a stale hint costs time, never results. */
-__global__ __launch_bounds__(1024) void k_verdict(FrameInfo *info, int nf, uint32_t *host_hint)
+__global__ __launch_bounds__(1024) void k_verdict(FrameInfo *info, int nf, uint32_t *host_hint, const uint32_t *cm_sync, int N)
 {
     __shared__ uint32_t others, modes;
     if (threadIdx.x == 0) others = modes = 0u;
@@ -354,7 +474,20 @@ __global__ __launch_bounds__(1024) void k_verdict(FrameInfo *info, int nf, uint3
     for (int f = threadIdx.x; f < nf; f += 1024) {
         FrameInfo fi = info[f];
         mask |= 1u << (fi.mode & 31u);
-        const bool bad_stream = (fi.mode == kFrameStream || fi.mode == kFrameColMajor) && (fi.failed != 0u || fi.consumed != fi.T);
+        bool bad_stream = (fi.mode == kFrameStream || fi.mode == kFrameColMajor || fi.mode == kFrameColMajorGen) && ((fi.failed & kInfoFailed) != 0u || fi.consumed != fi.T);
+        /* firing order: where a strip's wrap-around halo fell back on column 0 (BatchMultiBevGen.cpp:146-149; rare: the upper
+         * point's intensity is -1) it must have taken the record that strip 0 — which hears of every no-return record of the
+         * row — put there */
+        if (fi.mode == kFrameColMajorGen && !bad_stream && (fi.failed & (kInfoCmUsed | kInfoCmStray)) != 0u && cm_sync) {
+            const uint32_t *win0 = cm_sync + (size_t)f * kCmSyncWords + kCmPubWords, *used0 = win0 + kCmMaxRows, *stray = used0 + kCmMaxRows;
+            for (int r = 0; r < N && r < kCmMaxRows; ++r) {
+                const uint32_t u = used0[r];
+                if ((u & kCmUsedBit) != 0u && (u & ~kCmUsedBit) != win0[r]) bad_stream = true;
+                /* ... and in a frame whose strips did not talk, no no-return record of another strip's may be later in the
+                 * input than what strip 0 put into column 0 */
+                if (stray[r] > win0[r]) bad_stream = true;
+            }
+        }
         /* structured: every record checked, none bad, and the guess about all-zero records (it decided slot 0) was right */
         const bool bad_struct = fi.mode == kFrameStructured &&
                                 ((fi.failed & kInfoFailed) != 0u || fi.consumed != fi.T ||
@@ -601,19 +734,33 @@ struct WalkRow {
 __device__ __forceinline__ int wr_status(uint32_t fl) { return (int)(fl & 3u) - 1; }
 __device__ __forceinline__ int wr_gflag(uint32_t fl) { return (int)((fl >> 2) & 3u) - 1; }
 
-enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcInPlace = 2, kSrcStructured = 3, kSrcColMajor = 4 };
+enum : int { kSrcGather = 0, kSrcIdentity = 1, kSrcInPlace = 2, kSrcStructured = 3, kSrcColMajor = 4, kSrcColMajorGen = 5 };
 /* Column-major source (kFrameColMajor): input position k holds the return of firing k / N, beam k % N — what the MulRan
- * selector writes (MulranPointCloudSelect.cpp:112-130: row = k % 64, col from the azimuth).  A strip's 256 threads take one
- * firing each, kColLead firings before the strip's first own column; the records of kBandRows consecutive rows of a
- * firing are 64 contiguous bytes of the input, fetched as one band. */
-constexpr int kColLead = 10;     /* 2 halo columns + kColMaxDisp */
+ * selector writes (MulranPointCloudSelect.cpp:112-130: row = k % 64, col from the azimuth).  With u = +-firing mod H (the
+ * sweep's direction) a return of row r sits in column (u + B[r] + 0 .. kColMaxDisp) mod H (k_probe found the direction and
+ * the rows' bases B).  A strip's threads take one u each, from kColMaxDisp + the largest base before the strip's first
+ * virtual column on (kCmExt more by wave 0: 272 firings cover 240 columns, the jitter and bases kCmSpread apart); the
+ * records of kBandRows consecutive rows of a firing are 64 contiguous bytes of the input, fetched as one band. */
 constexpr int kBandRows = 2;
-constexpr int kSideFirings = 16; /* the first / last firings: the last strip's wrap-around halo, strip 0's flat-index halo */
+/* the PLAIN sweep (kFrameColMajor: starts at azimuth 0, turns forward, column = firing + 0 .. 8, no no-return records; BASELINE
+ * config 3) keeps round 4's walk: a thread per firing from kColLead firings before the strip's first own column, side windows of
+ * the first / last kPlainSide firings, 50 KB of LDS.  Everything else in firing order takes the general form below (kFrameColMajorGen). */
+constexpr int kPlainDisp = 8, kColLead = 2 + kPlainDisp, kPlainSide = 16;
+constexpr int kPlainBuf = kStripThreads * 32 * kBandRows + 2 * kPlainSide * 32 * kBandRows; /* one band buffer: the band, the flat-rule window, the wrap-around window */
+static_assert(kPlainSide * 2 * kBandRows == 64 && kStripVirt + kPlainDisp <= kStripThreads && kPlainDisp + 2 <= kPlainSide, "the plain sweep's windows");
+constexpr int kSideFirings = 32; /* firings of the side area: the wrap-around halo's window or strip 0's flat-index halo's */
 constexpr int kBandBytes = kStripThreads * 32 * kBandRows;
-constexpr int kSideBytes = kSideFirings * 32 * kBandRows; /* one side window */
-constexpr int kColBuf = kBandBytes + 2 * kSideBytes;     /* one band buffer: the band, the flat-rule window, the wrap-around window */
-static_assert(kSideFirings * 2 * kBandRows == 64, "a side window of a band is one LDS-DMA instruction");
-static_assert(kStripVirt + kColMaxDisp <= kStripThreads && kColLead == 2 + kColMaxDisp && kColMaxDisp + 2 <= kSideFirings, "firings a strip's columns can come from");
+constexpr int kExtBytes = kCmExt * 32 * kBandRows;
+constexpr int kSideBytes = kSideFirings * 32 * kBandRows;
+constexpr int kSpecialBytes = 32 * kBandRows;            /* strip 0: the last no-return record of either row that another strip owns */
+constexpr int kColBuf = kBandBytes + kExtBytes + kSideBytes + kSpecialBytes; /* one band buffer */
+/* where a record sits in a band buffer, as the index row remembers it: 0 .. 255 a thread's, then kCmExt extra firings,
+ * kSideFirings side firings, the special record; all but the first 256 are 64-byte entries behind the band */
+constexpr uint32_t kLocExt = kStripThreads, kLocSide = kLocExt + kCmExt, kLocSpecial = kLocSide + kSideFirings, kLocBits = 9;
+static_assert(kLocSpecial < (1u << kLocBits) && kCmExt * 2 * kBandRows == 64, "location bits; the extra firings of a band are one LDS-DMA instruction");
+static_assert(kStripVirt + kColMaxDisp + kCmSpread <= kStripThreads + kCmExt && 2 + kColMaxDisp + kCmSpread <= kSideFirings,
+              "firings a strip's columns can come from");
+constexpr uint32_t kCmSpins = 1u << 20;
 constexpr int kWinPos = kStripThreads; /* in-place source: window positions of a (row, strip), one per thread: est - kWinLead ... */
 constexpr int kWinLead = 12;
 constexpr int kWrapPos = 16;       /* ... the last strip's wrap-around halo: positions around the row's start */
@@ -657,19 +804,24 @@ __device__ __forceinline__ uint32_t quarter_scan(bool c, uint32_t q, uint32_t *r
 constexpr int kFlRankShift = 8; /* WalkRow::fl bits 8..13: the lane's rank among its wave's candidates of its quarter */
 
 template <int kSrc, bool kPow2, bool kGm>
-__global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : 4) void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
+__global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSrcColMajorGen) ? 3 : 4) void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
     /* kStructured: the identity source over the caller's INPUT (record i = slot i's point or an all-zero record), every
      * record checked; kIdentity below covers both (no winner table, position = slot) */
     constexpr bool kStructured = kSrc == kSrcStructured, kIdentity = kSrc == kSrcIdentity || kStructured, kInPlace = kSrc == kSrcInPlace;
     /* kIndexed: the sources whose points reach their columns through an index row (LDS atomicMax), after the step's barrier */
-    constexpr bool kColMajor = kSrc == kSrcColMajor, kIndexed = kInPlace || kColMajor;
+    constexpr bool kCmGen = kSrc == kSrcColMajorGen, kColMajor = kSrc == kSrcColMajor || kCmGen, kIndexed = kInPlace || kColMajor;
+    constexpr int kCmBuf = kCmGen ? kColBuf : kPlainBuf; /* bytes of one band buffer */
     static_assert(kWinPos == 256 && kStripVirt + 16 <= kWinPos && kTailCap == 64 && kWrapPos == 16, "DMA pieces of the in-place source");
     int f, strip;
 #ifdef BEV_CS_CLOCK
     const long long tl_t0 = wall_clock64();
 #endif
     if (!map_block_xcd(blockIdx.x, nf, g.strips, f, strip)) return;
+    /* firing order: strip 0 listens to the other strips of its frame (no-return records, see listen_band): it is dispatched
+     * LAST of them, and finds them under way (dispatched first it waited a quarter of its life for them to start: the walk
+     * 5 % slower) */
+    if (kSrc == kSrcColMajorGen) strip = g.strips - 1 - strip;
     if (kSrc != kSrcIdentity && b.info) { /* the launch for its mode has the frame; the general launch has every frame that is not read in place */
         const uint32_t fmode = b.info[f].mode;
         if (frame_read_in_place(want_mode) ? fmode != want_mode : frame_read_in_place(fmode)) return;
@@ -695,7 +847,7 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : 4) void k
     /* the points of rows r, r+1, r+2.  Gather / identity: by thread, low halves in the first 4 KiB, high halves in the
      * second.  In place: by window position, 32 B each, then the wrap-around positions, then the tail points */
     /* column-major: two band buffers, then 8 KiB for the write-out's transposition */
-    __shared__ __attribute__((aligned(16))) char ring[kColMajor ? 2 * kColBuf + 8192 : 3 * kSlotBytes];
+    __shared__ __attribute__((aligned(16))) char ring[kColMajor ? 2 * kCmBuf + 8192 : 3 * kSlotBytes];
     __shared__ uint32_t wring[kSrc == kSrcGather ? 3 : 1][kStripThreads]; /* raw winner words of rows r+2, r+3, r+4 */
     __shared__ uint32_t idx[kIndexed ? 2 : 1][kIndexed ? kStripThreads + 1 : 1]; /* column offset -> position + 1 | tail key ([256]: nowhere) */
     __shared__ u32x4 zero16[kInPlace ? 1 : 1];                               /* what an empty slot reads */
@@ -883,68 +1035,301 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : 4) void k
     };
 
     /* ---- column-major ---- */
-    const int cm_firing = strip * kStripCols - kColLead + tid;     /* this thread's firing */
-    const bool cm_valid = (unsigned)cm_firing < (unsigned)H;
-    const bool cm_own = (unsigned)(cm_firing - strip * kStripCols) < (unsigned)own_cols; /* counted by this strip */
-    auto cm_buf = [&](int band) -> uint32_t { return (uint32_t)(band & 1) * (uint32_t)kColBuf; };
+    /* the frame's direction and row bases (k_probe), the window of this strip, who counts what */
+    __shared__ uint16_t cm_base_l[kCmGen ? kCmMaxRows : 2]; /* (LDS is what holds this source at three workgroups per CU: 53,248 bytes and not one 512-byte granule more) */
+    __shared__ uint32_t cm_nr_l[2];     /* no-return firings + 1 this strip owns, rows 2b, 2b + 1 of the band just arrived (LDS atomicMax) */
+    __shared__ uint32_t cm_spec_l[2][2]; /* strip 0: [band & 1][row & 1]: the last no-return firing + 1 of the row that another strip owns (0: none) */
+    __shared__ uint32_t cm_halo0_l[2];  /* [row & 1]: the index entry that the strip with the wrap-around halo found for virtual column H (= column 0) */
+    __shared__ uint16_t cm_win0_l[kCmGen ? kCmMaxRows : 2]; /* strip 0: per row, the firing + 1 whose record it put into column 0 (written out at the end) */
+    const bool cm_fwd = kCmGen ? b.cm_par[(size_t)f * kCmParWords] > 0 : true;
+    const int cm_bmax = kCmGen ? b.cm_par[(size_t)f * kCmParWords + 1] : 0;
+    if constexpr (kCmGen) {
+        for (int r = tid; r < N; r += kStripThreads) cm_base_l[r] = (uint16_t)b.cm_par[(size_t)f * kCmParWords + 2 + r];
+        if (tid < 2) {
+            cm_nr_l[tid] = 0u;
+            cm_halo0_l[tid] = 0u;
+            cm_spec_l[0][tid] = cm_spec_l[1][tid] = 0u;
+        }
+    }
+    auto mod_h = [&](int x) -> int { /* x mod H for x in (-2 H, 2 H) */
+        x = x < 0 ? x + H : x;
+        x = x < 0 ? x + H : x;
+        return x >= H ? x - H : x;
+    };
+    auto firing_of = [&](int u) -> int { return cm_fwd ? u : (u ? H - u : 0); }; /* u = +-firing mod H */
+    /* What of all this the row loop needs it gets as ONE scalar word of flags and a handful of per-lane values computed here
+     * (the first form kept a dozen scalars alive across the loop: 52 spilled scalar registers, the walk 8 % slower). */
+    enum : uint32_t { kCfExt = 2u, kCfReports = 4u, kCfListens = 8u, kCfQuiet = 16u, kCfFirst = 32u, kCfBoth = 64u, kCfFlat = 128u, kCfWrap = 256u };
+    uint32_t cm_f = 0u;            /* (wave-uniform) */
+    int cm_u = 0;                  /* this thread's u = +-firing mod H */
+    uint32_t cm_off = 0u, cm_key = 0u, cm_vf = 0u; /* byte offset of its firing's records in the frame; its index key; bit 0 valid, bit 1 counted by this strip */
+    uint32_t cm_ext_off = 0u, cm_ext_key = 0u;     /* wave 0: lane = extra firing * 4 + piece: that piece's offset (row 0 of a band); lane < kCmExt: the extra firing's key (0: none) */
+    uint32_t cm_side_off[2] = {0u, 0u}, cm_side_key = 0u; /* the side window's wave: the same for its firings (two instructions of 16); lane < 32: a side firing's key */
+    /* the plain sweep: this thread's firing */
+    const int pl_firing = strip * kStripCols - kColLead + tid;
+    const bool pl_valid = (unsigned)pl_firing < (unsigned)H;
+    const bool pl_own = (unsigned)(pl_firing - strip * kStripCols) < (unsigned)own_cols; /* counted by this strip */
+    if constexpr (kCmGen) {
+        const int kind = b.cm_par[(size_t)f * kCmParWords + 3 + kCmMaxRows]; /* 1 a sample was a no-return record, 0 none was */
+        const bool first = strip == 0, both = first && last_strip, talk = strips > 1 && kind > 0;
+        /* Do this frame's strips talk about no-return records (k_probe saw one)?  If not, a strip other than 0 that owns one
+         * after all leaves the row's last in cm_sync and raises kInfoCmStray: k_verdict redoes the frame if it would have won.
+         * The kCmExt firings behind the 256 threads' are needed only when the rows' bases lie far apart (staggered beams).
+         * (A strip that is the first AND the last of its rows — a sensor of up to 237 columns — holds every firing in its
+         * window: its threads enter columns 0, 1 a second time as the wrap-around halo, the side area is the flat-index halo's.) */
+        const bool ext = kStripVirt + kColMaxDisp + b.cm_par[(size_t)f * kCmParWords + 2 + kCmMaxRows] > kStripThreads;
+        cm_f = ((ext && wv == 0) ? kCfExt : 0u) | ((talk && !first) ? kCfReports : 0u) | ((talk && first && wv == 3) ? kCfListens : 0u) |
+               ((strips > 1 && !talk && !first) ? kCfQuiet : 0u) | (first ? kCfFirst : 0u) | (both ? kCfBoth : 0u) |
+               ((first && wv == 1) ? kCfFlat : 0u) | ((last_strip && !both && wv == 2) ? kCfWrap : 0u);
+        cm_f = __builtin_amdgcn_readfirstlane(cm_f);
+        /* this thread's u and firing; a window position past the circle's length repeats an earlier one */
+        const int u0 = mod_h((first_col - cm_bmax - kColMaxDisp) % H);
+        cm_u = mod_h(u0 + tid % H);
+        const int firing = firing_of(cm_u);
+        const bool valid = tid < H;
+        /* every firing is counted by ONE strip: its window positions own_at .. own_at + own_cols - 1 (the strips' windows start
+         * kStripCols apart, so these ranges tile the circle) */
+        const int own_at = H >= kStripCols + 16 ? 16 : (H > kStripCols ? H - kStripCols : 0);
+        cm_vf = (valid ? 1u : 0u) | (((unsigned)(tid - own_at) < (unsigned)own_cols) ? 2u : 0u);
+        cm_off = (uint32_t)(valid ? firing : 0) * (uint32_t)N * 32u;
+        cm_key = (((uint32_t)firing + 1u) << kLocBits) | (uint32_t)tid;
+        const int i = lane >> 2, piece = lane & 3;
+        if (cm_f & kCfExt) {
+            const int w = kStripThreads + i, fr = firing_of(mod_h(u0 + w % H));
+            cm_ext_off = (uint32_t)(w < H ? fr : 0) * (uint32_t)N * 32u + 16u * (uint32_t)(piece & 1);
+            const int wl = kStripThreads + lane, frl = firing_of(mod_h(u0 + wl % H));
+            cm_ext_key = (lane < kCmExt && wl < H) ? ((((uint32_t)frl + 1u) << kLocBits) | (kLocExt + (uint32_t)lane)) : 0u;
+        }
+        if (cm_f & (kCfFlat | kCfWrap)) {
+            const int su0 = (cm_f & kCfFlat) ? mod_h((H - 2 - cm_bmax - kColMaxDisp) % H) : mod_h((-cm_bmax - kColMaxDisp) % H);
+#pragma unroll
+            for (int k0 = 0; k0 < 2; ++k0) {
+                const int k = 16 * k0 + i;
+                cm_side_off[k0] = (uint32_t)(k < H ? firing_of(mod_h(su0 + k % H)) : 0) * (uint32_t)N * 32u + 16u * (uint32_t)(piece & 1);
+            }
+            const int kl = lane & (kSideFirings - 1);
+            cm_side_key = (lane < kSideFirings && kl < H) ? ((((uint32_t)firing_of(mod_h(su0 + kl % H)) + 1u) << kLocBits) | (kLocSide + (uint32_t)kl)) : 0u;
+        }
+    }
+    const int cm_words = (strips - 1) * 2; /* (<= 30: kCmMaxStrips) strip 0 listens to this many words per band */
+    auto cm_pub = [&]() -> gptr<uint32_t> { return (gptr<uint32_t>)(b.cm_sync + (size_t)f * kCmSyncWords); }; /* [band][strip][2], then the per-row words */
+    auto cm_buf = [&](int band) -> uint32_t { return (uint32_t)(band & 1) * (uint32_t)kCmBuf; };
     /* rows 2 * band, 2 * band + 1 of this thread's firing: four 16-byte pieces of one 64-byte sector -> piece j at
-     * buffer + j * 4 KiB + thread * 16; wave 1 of strip 0: the same rows LESS ONE of the last kSideFirings firings
-     * (slots (r - 1, H - 2), (r - 1, H - 1) are strip 0's virtual columns -2, -1 of row r); wave 2 of the last strip:
-     * the rows of the first kSideFirings firings (columns 0, 1 as H, H + 1); lane = firing * 4 + piece */
+     * buffer + j * 4 KiB + thread * 16; wave 0: the same of the kCmExt firings behind the window; wave 1 of strip 0: the
+     * rows LESS ONE of the firings whose returns can be columns H - 2, H - 1 (slots (r - 1, H - 2), (r - 1, H - 1) are
+     * strip 0's virtual columns -2, -1 of row r); wave 2 of a strip with a wrap-around halo: the firings whose returns can
+     * be columns 0, 1 (as H, H + 1); lane = firing * 4 + piece */
     auto issue_band = [&](int band) {
         const int r0 = band * kBandRows;
         if (r0 >= N) return; /* (uniform) */
         const uint32_t at = ring_l + cm_buf(band) + (uint32_t)wv * 1024u;
-        const char *src = fbytes + ((size_t)(cm_valid ? cm_firing : 0) * N + r0) * 32u;
+        if constexpr (!kCmGen) { /* the plain sweep: wave 1 of strip 0: the rows LESS ONE of the last kPlainSide firings; wave 2 of the last strip: the first kPlainSide firings */
+            const char *src = fbytes + ((size_t)(pl_valid ? pl_firing : 0) * N + r0) * 32u;
+            const bool two = r0 + 1 < N;
+            glds16x2(src, at, src + 16, at + 4096u);
+            glds16x2(src + (two ? 32 : 0), at + 8192u, src + (two ? 48 : 16), at + 12288u);
+            if ((strip == 0 && wv == 1) || (last_strip && wv == 2)) {
+                const bool flat = wv == 1;
+                const int i = lane >> 2, piece = lane & 3;
+                const int fr = flat ? H - kPlainSide + i : i;
+                int row = r0 + (piece >> 1) - (flat ? 1 : 0);
+                const bool ok = (unsigned)fr < (unsigned)H && (unsigned)row < (unsigned)N;
+                glds16(fbytes + ((size_t)(ok ? fr : 0) * N + (ok ? row : 0)) * 32u + 16 * (piece & 1),
+                       ring_l + cm_buf(band) + (uint32_t)kBandBytes + (flat ? 0u : (uint32_t)(kPlainSide * 32 * kBandRows)));
+            }
+            return;
+        }
+        const char *src = fbytes + cm_off + (uint32_t)r0 * 32u;
         /* (N odd or a last band of one row: the second row's pieces come from the next firing or past the frame's end —
          * never used; past the END of the input they would be out of bounds: clamp) */
         const bool two = r0 + 1 < N;
         glds16x2(src, at, src + 16, at + 4096u);
         glds16x2(src + (two ? 32 : 0), at + 8192u, src + (two ? 48 : 16), at + 12288u);
-        if ((strip == 0 && wv == 1) || (last_strip && wv == 2)) {
-            const bool flat = wv == 1;
-            const int i = lane >> 2, piece = lane & 3;
-            const int fr = flat ? H - kSideFirings + i : i;
-            int row = r0 + (piece >> 1) - (flat ? 1 : 0);
-            const bool ok = (unsigned)fr < (unsigned)H && (unsigned)row < (unsigned)N;
-            glds16(fbytes + ((size_t)(ok ? fr : 0) * N + (ok ? row : 0)) * 32u + 16 * (piece & 1),
-                   ring_l + cm_buf(band) + (uint32_t)kBandBytes + (flat ? 0u : (uint32_t)kSideBytes));
+        const uint32_t second = ((lane & 2) && two) ? 32u : 0u; /* (piece >> 1: the band's second row) */
+        if (cm_f & kCfExt) /* (uniform) the extra firings */
+            glds16(fbytes + cm_ext_off + (uint32_t)r0 * 32u + second, ring_l + cm_buf(band) + (uint32_t)kBandBytes);
+        if (cm_f & (kCfFlat | kCfWrap)) { /* (uniform) */
+            const bool flat = (cm_f & kCfFlat) != 0u;
+            /* the flat-index halo wants rows r0 - 1, r0: none before row 0 (that piece fetches row 0 and is not entered) */
+            const int row = flat ? r0 - 1 + ((lane & 2) ? 1 : 0) : r0 + (((lane & 2) && two) ? 1 : 0);
+            const uint32_t side_at = ring_l + cm_buf(band) + (uint32_t)(kBandBytes + kExtBytes);
+            glds16(fbytes + cm_side_off[0] + (uint32_t)(row < 0 ? 0 : row) * 32u, side_at);
+            glds16(fbytes + cm_side_off[1] + (uint32_t)(row < 0 ? 0 : row) * 32u, side_at + 16u * 64u);
         }
     };
-    /* Row rho's records -> idx[rho & 1]; every record this thread holds is CHECKED: beam = position mod N, column =
-     * firing + 0 .. kColMaxDisp or out of range (dropped by the scatter, BatchMultiBevGen.cpp:109-111).  Later firings
-     * are later in the input: the larger key wins, as the reference's last writer does (:112-115). */
+    /* Strip 0, wave 3: what the other strips have reported for band `band` — the last no-return firing of either row —
+     * and the two records themselves into the band buffer's special entry.  The others report when the band ARRIVES in
+     * their LDS; strip 0 asks three steps before it uses the band, without waiting (the words come by LDS-DMA and are
+     * looked at after the next step's memory wait): once it trails the others by that much it never stalls.  Only when
+     * a report is still missing then does it wait for it (bounded), a step before the band is used. */
+    __shared__ uint32_t cm_poll_l[2][kCmGen ? 32 : 1];
+    auto ask_band = [&](int band) { /* (wave 3) */
+        if (band * kBandRows >= N) return; /* (uniform) */
+        if (lane < cm_words) glds4_nt(b.cm_sync + (size_t)f * kCmSyncWords + ((size_t)band * kCmMaxStrips + 1) * 2 + lane, __builtin_amdgcn_readfirstlane(lds_addr(&cm_poll_l[band & 1][0])));
+    };
+    auto take_band = [&](int band, uint32_t w) { /* (wave 3) the reports are in: the larger firing per row, the records */
+        const int r0 = band * kBandRows;
+        /* even lanes: the band's first row, odd lanes: its second.  (The maxima by v_readlane and scalar compares: as lane
+         * shuffles — five LDS round trips on a busy LDS — this cost strip 0 0.7 us at every other step.) */
+        uint32_t v0 = 0u, v1 = 0u;
+        for (int k = 0; k < cm_words; k += 2) {
+            const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)w, k) & 0xffffu, c = (uint32_t)__builtin_amdgcn_readlane((int)w, k + 1) & 0xffffu;
+            v0 = a > v0 ? a : v0;
+            v1 = c > v1 ? c : v1;
+        }
+        if (lane < 2) cm_spec_l[band & 1][lane] = lane ? v1 : v0;
+        if ((v0 | v1) != 0u && lane < 4) { /* (uniform test) the records (firing v - 1, row r0 + lane / 2); none: the frame's first record, never entered */
+            const uint32_t vv = (lane >> 1) ? v1 : v0;
+            const int row = r0 + (lane >> 1);
+            const bool ok = vv != 0u && row < N;
+            glds16(fbytes + ((size_t)(ok ? vv - 1u : 0u) * N + (ok ? row : 0)) * 32u + 16 * (lane & 1),
+                   ring_l + cm_buf(band) + (uint32_t)(kBandBytes + kExtBytes + kSideBytes));
+        }
+    };
+    auto try_band = [&](int band) -> bool { /* (wave 3, after a memory wait) have all the others reported? */
+        if (band * kBandRows >= N) return true; /* (uniform) */
+        const uint32_t w = lane < cm_words ? cm_poll_l[band & 1][lane] : kCmUsedBit;
+        if (__ballot((w & kCmUsedBit) == 0u) != 0ull) return false;
+        take_band(band, w);
+        return true;
+    };
+    auto listen_band = [&](int band) { /* (wave 3) ... waiting for them — and for those of the band after the next (lanes 32 ..) as
+                                        * well: strip 0 then trails the others by the four steps that asking without waiting needs,
+                                        * and stays there */
+        if (band * kBandRows >= N) return; /* (uniform) */
+        const bool more = (band + 2) * kBandRows < N;
+        uint32_t w = 0u, spins = 0u;
+        for (;;) {
+            const int l = lane & 31;
+            w = (l < cm_words && (lane < 32 || more)) ? __hip_atomic_load(cm_pub() + ((size_t)(band + 2 * (lane >> 5)) * kCmMaxStrips + 1) * 2 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                      : kCmUsedBit;
+            if (__ballot((w & kCmUsedBit) == 0u) == 0ull) break;
+            if (++spins > kCmSpins) { /* (never seen; the frame is redone the general way) */
+                failed |= 1u;
+                w = 0u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        take_band(band, w);
+    };
+    int cm_waiting = -1; /* (wave 3 of strip 0) the band whose reports were not all in when asked */
+#ifdef BEV_CS_CLOCK
+    long long dbg_try_t = 0, dbg_block_t = 0;
+    int dbg_fail_n = 0;
+#endif
+    /* is column `col` of a return of row `row` where firing u's returns of that row lie? */
+    auto cm_regular = [&](uint32_t col, int u, int row) -> bool {
+        const int d = mod_h((int)col - u - (int)cm_base_l[row]); /* (col < H) */
+        return d <= kColMaxDisp;
+    };
+    /* A band has arrived: the no-return records among the firings this strip owns (column 0, and not where the firing's
+     * returns lie), both rows, for strip 0.  (Strip 0 finds its own in its window.) */
+    auto report_band = [&](int band) {
+        const int r0 = band * kBandRows;
+        const char *buf = &ring[cm_buf(band)];
+#pragma unroll
+        for (int k = 0; k < kBandRows; ++k) {
+            const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + (k * 2 + 1) * 4096 + tid * 16 + 4);
+            const bool zero = cm_vf == 3u && r0 + k < N && rcw == (uint32_t)(r0 + k); /* (valid and counted here) row r0 + k, column 0 */
+            if (__ballot(zero) == 0ull) continue; /* (wave-uniform: a sweep without no-return records pays two reads and a compare) */
+            if (zero && !cm_regular(0u, cm_u, r0 + k)) atomicMax(&cm_nr_l[k], cm_key >> kLocBits);
+        }
+    };
+    /* Row rho's records -> idx[rho & 1], keyed by (firing + 1) << kLocBits | where the record sits: later firings are
+     * later in the input, the larger key wins, as the reference's last writer does (BatchMultiBevGen.cpp:112-115).  Every
+     * record this strip OWNS is checked: beam = position mod N, and its column is where its firing's returns lie, or out
+     * of range (dropped by the scatter, :109-111), or 0 (a no-return record). */
     auto index_row_cm = [&](int rho) {
         if (rho >= N) return;
         uint32_t *irow = idx[rho & 1];
         const char *buf = &ring[cm_buf(rho / kBandRows)];
+        if constexpr (!kCmGen) { /* the plain sweep: column = firing + 0 .. kPlainDisp or out of range; keys are thread numbers (firings ascend with them) */
+            {
+                const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + ((rho & 1) * 2 + 1) * 4096 + tid * 16 + 4);
+                const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
+                const bool good = (row == (uint32_t)rho) & ((col >= (uint32_t)H) | ((col - (uint32_t)pl_firing) <= (uint32_t)kPlainDisp));
+                failed |= (pl_valid & !good) ? 1u : 0u;
+                consumed += (pl_valid & pl_own) ? 1u : 0u;
+                const uint32_t off = col - (uint32_t)first_col;
+                atomicMax(&irow[(pl_valid & (col < (uint32_t)H) & (off < (uint32_t)row_span)) ? off : (uint32_t)kStripThreads], (uint32_t)tid + 1u);
+            }
+            if ((strip == 0 && wv == 1) || (last_strip && wv == 2)) { /* wave-uniform */
+                const bool flat = wv == 1;
+                const int i = lane & (kPlainSide - 1);
+                const int fr = flat ? H - kPlainSide + i : i;
+                const int want_row = flat ? rho - 1 : rho;
+                const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + kBandBytes + (flat ? 0 : kPlainSide * 32 * kBandRows) + i * 64 + (rho & 1) * 32 + 20);
+                const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
+                /* flat: columns H - 2, H - 1 of row rho - 1 at offsets 0, 1; wrap: columns 0, 1 of row rho at H - first_col + 0, 1 */
+                const uint32_t off = flat ? col - (uint32_t)(H - 2) : (uint32_t)(H - first_col) + col;
+                const bool ok = (lane < kPlainSide) & ((unsigned)fr < (unsigned)H) & (want_row >= 0) & (row == (uint32_t)want_row) &
+                                (flat ? (col < (uint32_t)H) & (off < 2u) : (col < 2u) & (off < (uint32_t)kStripVirt));
+                atomicMax(&irow[ok ? off : (uint32_t)kStripThreads], (uint32_t)(kStripThreads + (flat ? 0 : kPlainSide) + i) + 1u);
+            }
+            return;
+        }
         {
+            const int base = (int)cm_base_l[rho]; /* (requested together with the record's word) */
             const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + ((rho & 1) * 2 + 1) * 4096 + tid * 16 + 4);
             const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
-            const bool good = (row == (uint32_t)rho) & ((col >= (uint32_t)H) | ((col - (uint32_t)cm_firing) <= (uint32_t)kColMaxDisp));
-            failed |= (cm_valid & !good) ? 1u : 0u;
-            consumed += (cm_valid & cm_own) ? 1u : 0u;
+            const bool good = (row == (uint32_t)rho) && (col >= (uint32_t)H || col == 0u || mod_h((int)col - cm_u - base) <= kColMaxDisp);
+            failed |= (cm_vf == 3u && !good) ? 1u : 0u;
+            consumed += cm_vf == 3u ? 1u : 0u;
             const uint32_t off = col - (uint32_t)first_col;
-            atomicMax(&irow[(cm_valid & (col < (uint32_t)H) & (off < (uint32_t)row_span)) ? off : (uint32_t)kStripThreads], (uint32_t)tid + 1u);
+            const bool here = (cm_vf & 1u) && row == (uint32_t)rho;
+            atomicMax(&irow[(here & (col < (uint32_t)H) & (off < (uint32_t)row_span)) ? off : (uint32_t)kStripThreads], cm_key);
+            if (cm_f & kCfBoth) { /* (uniform) columns 0, 1 once more, as the virtual columns H, H + 1 */
+                const uint32_t off2 = (uint32_t)(H - first_col) + col;
+                atomicMax(&irow[(here & (col < 2u) & (off2 < (uint32_t)kStripVirt)) ? off2 : (uint32_t)kStripThreads], cm_key);
+            }
+            if ((cm_f & kCfQuiet) && __ballot(cm_vf == 3u && rcw == (uint32_t)rho) != 0ull) { /* (wave-uniform, rare: a record of column 0)
+                                                                                             * a no-return record after all, in a frame whose strips do not talk? */
+                const bool stray = cm_vf == 3u && rcw == (uint32_t)rho && mod_h(-cm_u - base) > kColMaxDisp;
+                if (__ballot(stray) != 0ull) {
+                    if (stray) atomicMax(b.cm_sync + (size_t)f * kCmSyncWords + kCmPubWords + 2 * kCmMaxRows + rho, cm_key >> kLocBits);
+                    failed |= kInfoCmStray;
+                }
+            }
         }
-        if ((strip == 0 && wv == 1) || (last_strip && wv == 2)) { /* wave-uniform */
-            const bool flat = wv == 1;
-            const int i = lane & (kSideFirings - 1);
-            const int fr = flat ? H - kSideFirings + i : i;
+        if ((cm_f & kCfExt) && lane < kCmExt) { /* (uniform per wave) the extra firings: never counted here */
+            const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + kBandBytes + lane * 64 + (rho & 1) * 32 + 20);
+            const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
+            const uint32_t off = col - (uint32_t)first_col;
+            atomicMax(&irow[((cm_ext_key != 0u) & (row == (uint32_t)rho) & (col < (uint32_t)H) & (off < (uint32_t)row_span)) ? off : (uint32_t)kStripThreads], cm_ext_key);
+        }
+        if (cm_f & (kCfFlat | kCfWrap)) { /* wave-uniform */
+            const bool flat = (cm_f & kCfFlat) != 0u;
+            const int e = lane & (kSideFirings - 1); /* entry of the side area */
             const int want_row = flat ? rho - 1 : rho;
-            const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + kBandBytes + (flat ? 0 : kSideBytes) + i * 64 + (rho & 1) * 32 + 20);
+            const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + kBandBytes + kExtBytes + e * 64 + (rho & 1) * 32 + 20);
             const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
             /* flat: columns H - 2, H - 1 of row rho - 1 at offsets 0, 1; wrap: columns 0, 1 of row rho at H - first_col + 0, 1 */
             const uint32_t off = flat ? col - (uint32_t)(H - 2) : (uint32_t)(H - first_col) + col;
-            const bool ok = (lane < kSideFirings) & ((unsigned)fr < (unsigned)H) & (want_row >= 0) & (row == (uint32_t)want_row) &
+            const bool ok = (lane < kSideFirings) & (cm_side_key != 0u) & (want_row >= 0) & (row == (uint32_t)want_row) &
                             (flat ? (col < (uint32_t)H) & (off < 2u) : (col < 2u) & (off < (uint32_t)kStripVirt));
-            atomicMax(&irow[ok ? off : (uint32_t)kStripThreads], (uint32_t)(kStripThreads + (flat ? 0 : kSideFirings) + i) + 1u);
+            atomicMax(&irow[ok ? off : (uint32_t)kStripThreads], cm_side_key);
+        }
+        if ((cm_f & kCfListens) && lane == 0) { /* the last no-return record of the row that another strip owns: column 0 = offset 2 */
+            const uint32_t v = cm_spec_l[(rho / kBandRows) & 1][rho & 1];
+            const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + kBandBytes + kExtBytes + kSideBytes + (rho & 1) * 32 + 20);
+            if (v != 0u) {
+                if (rcw != (uint32_t)rho) failed |= 1u; /* (row rho, column 0: what its owner said it was) */
+                else atomicMax(&irow[2], (v << kLocBits) | kLocSpecial);
+            }
         }
     };
 
     /* ---- prologue: the queue the row loop expects ---- */
-    if constexpr (kColMajor) {
+    if constexpr (kColMajor && !kCmGen) {
         issue_band(0);
+    } else if constexpr (kCmGen) {
+        lds_barrier(); /* the rows' bases */
+        issue_band(0);
+        if (cm_f & kCfListens) {
+            listen_band(0);
+            ask_band(1); /* (looked at behind step 0's memory wait) */
+        }
     } else if constexpr (kInPlace) {
         if (wv == 3) {
             issue_tail_list(0, 0);
@@ -1043,7 +1428,10 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : 4) void k
         if constexpr (kColMajor) {
             /* a band's loads are the newest operations but the stores since: they have arrived when nothing is outstanding
              * (the stores of the step before are a step old, as for the other sources) */
-            if ((r % kBandRows) == 0) wait_vm<0>();
+            if ((r % kBandRows) == 0) {
+                wait_vm<0>();
+                if (kCmGen && (cm_f & kCfReports) && r < N) report_band(r / kBandRows);
+            }
             PHA(0);
             index_row_cm(r);
             PHA(1);
@@ -1100,17 +1488,60 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : 4) void k
         lds_barrier();
         PHA(2);
         if constexpr (kColMajor) {
-            /* the column's owner follows its index entry to a firing of the band, or of a side window */
+            /* the column's owner follows its index entry to a record of the band: a thread's, an extra firing's, a side
+             * window's, the special one */
             const uint32_t e = idx[par][tid];
             idx[par][tid] = 0u;
             const char *buf = &ring[cm_buf(r / kBandRows)];
-            const uint32_t k = e - 1u; /* thread of the window, or kStripThreads + side firing */
+            const uint32_t k = kCmGen ? e & ((1u << kLocBits) - 1u) : e - 1u; /* (the plain sweep: thread of the window, or kStripThreads + side firing) */
             const bool main = k < (uint32_t)kStripThreads;
             const uint32_t lo_at = main ? (uint32_t)((r & 1) * 2) * 4096u + k * 16u
                                         : (uint32_t)kBandBytes + (k - (uint32_t)kStripThreads) * 64u + (uint32_t)(r & 1) * 32u;
             const bool have = (e != 0u) & (r < N);
             cur_lo = *(have ? reinterpret_cast<const u32x4 *>(buf + lo_at) : &zero16[0]);
             cur_hi = *(have ? reinterpret_cast<const u32x4 *>(buf + lo_at + (main ? 4096u : 16u)) : &zero16[0]);
+            /* Column 0 can hold a no-return record of ANY firing.  Strip 0, which owns the column, hears of the other strips'
+             * (listen_band) and says which firing's record it took; a strip whose wrap-around halo shows column 0 as virtual
+             * column H sees only the firings of its side window: it remembers what it found there, and if column H - 2 falls
+             * back on it (BatchMultiBevGen.cpp:146-149: the upper point's intensity is -1) says so: k_verdict compares. */
+            if (kCmGen && r < N) {
+                if ((cm_f & kCfFirst) && tid == 2) cm_win0_l[r] = (uint16_t)(e >> kLocBits);
+                if (last_strip && v == H) cm_halo0_l[r & 1] = e >> kLocBits;
+            }
+            /* this strip's no-return records of the band that has just arrived, for strip 0: a word per row */
+            if (kCmGen && (cm_f & kCfReports) && (r % kBandRows) == 0 && r < N && tid < kBandRows) {
+                const uint32_t nr = cm_nr_l[tid];
+                cm_nr_l[tid] = 0u;
+                __hip_atomic_store(cm_pub() + ((size_t)(r / kBandRows) * kCmMaxStrips + strip) * 2 + tid, kCmUsedBit | nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (kCmGen && (cm_f & kCfListens)) { /* (uniform) */
+                if ((r % kBandRows) == 0) { /* after this step's memory wait: the reports asked for two steps ago, for the band two steps on;
+                                             * and the next band's are asked for (a load asked for at an odd step was waited for half a
+                                             * step later, by every wave at the barrier behind: strip 0 18 % slower) */
+                    const int band = r / kBandRows + 1;
+#ifdef BEV_CS_CLOCK
+                    const long long t0_ = wall_clock64();
+#endif
+                    cm_waiting = try_band(band) ? -1 : band;
+#ifdef BEV_CS_CLOCK
+                    const long long t1_ = wall_clock64();
+                    dbg_block_t += t1_ - t0_;
+#endif
+                    ask_band(band + 1);
+#ifdef BEV_CS_CLOCK
+                    dbg_try_t += wall_clock64() - t1_;
+                    dbg_fail_n += cm_waiting >= 0 ? 1 : 0;
+#endif
+                } else if (cm_waiting >= 0) {
+#ifdef BEV_CS_CLOCK
+                    const long long t0_ = wall_clock64();
+#endif
+                    listen_band(cm_waiting);
+#ifdef BEV_CS_CLOCK
+                    dbg_block_t += wall_clock64() - t0_;
+#endif
+                }
+            }
         } else if constexpr (kInPlace) {
             /* the column's owner follows its index entry: a window / wrap-around position, or a tail point; an entry
              * whose (row, col) is not the slot's own is an empty slot (value-initialised, BatchMultiBevGen.cpp:98) */
@@ -1189,7 +1620,7 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : 4) void k
                 u32x4 hi = p2.hi;
                 const bool as_ground = cand2 && !((p2.fl >> 4) & 1u);
                 if (as_ground) hi.w &= 0xffff0000u; /* label = 0, BatchMultiBevGen.cpp:245 (provisional) */
-                char *xb = &ring[kColMajor ? 2 * kColBuf : (kInPlace ? s2 : s0) * kSlotBytes];
+                char *xb = &ring[kColMajor ? 2 * kCmBuf : (kInPlace ? s2 : s0) * kSlotBytes];
                 *reinterpret_cast<u32x4 *>(xb + xp_wlo) = p2.lo;
                 *reinterpret_cast<u32x4 *>(xb + xp_whi) = hi;
                 const u32x4 pa = *reinterpret_cast<const u32x4 *>(xb + xp_r0);
@@ -1243,6 +1674,12 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : 4) void k
             }
             {   /* (every thread evaluates it: only output columns' statuses are ever used) */
                 XYZI up = prev;                                  /* (r-1, c)                  :143     */
+                if constexpr (kCmGen) { /* column H - 2 falls back on column 0 of row r - 1: which firing's record this strip took for it */
+                    if (last_strip && outcol && v == H - 2 && up.i == -1.0f) {
+                        cm_pub()[kCmPubWords + kCmMaxRows + (r - 1)] = kCmUsedBit | cm_halo0_l[(r - 1) & 1];
+                        failed |= kInfoCmUsed;
+                    }
+                }
                 if (up.i == -1.0f) up = right;                   /* (r-1, (c+2) % H)          :146-149 */
                 if (up.i == -1.0f) up = left;                    /* flat (r-1)*H + c - 2      :151-154 */
                 if ((up.i == -1.0f) & (r >= 2)) up = prevprev;   /* (r-2, c)                  :157-160 */
@@ -1309,8 +1746,13 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : 4) void k
     wait_vm<0>(); /* no LDS-DMA may outlive the workgroup's LDS */
     PHA_PRINT(kInPlace ? "walk_inplace vmwait index barrier acquire writeout issue status rest" : "walk_gather vmwait - barrier acquire writeout issue status rest",
               lane == 0 && blockIdx.x == 100);
+    PHA_PRINT("walk_cm_strip0 vmwait index barrier acquire writeout issue status rest", kColMajor && lane == 0 && strip == 0 && f == 12);
+#ifdef BEV_CS_CLOCK
+    if (kColMajor && lane == 0 && wv == 3 && strip == 0 && f == 12) printf("walk_cm_listen try_t %lld block_t %lld fails %d (x10 ns)\n", dbg_try_t, dbg_block_t, dbg_fail_n);
+#endif
+    PHA_PRINT("walk_cm_strip2 vmwait index barrier acquire writeout issue status rest", kColMajor && lane == 0 && strip == 2 && f == 12);
 #ifdef BEV_CS_CLOCK /* where and when the workgroup ran: HW_ID (wave, SIMD, CU, SH, SE), XCC_ID; start and end on the 100 MHz clock */
-    if (tid == 0 && kInPlace && blockIdx.x < kWalkTlCap) {
+    if (tid == 0 && (kInPlace || kColMajor) && blockIdx.x < kWalkTlCap) {
         long long *rec = g_walk_tl[blockIdx.x];
         rec[0] = tl_t0;
         rec[1] = wall_clock64();
@@ -1320,6 +1762,10 @@ __global__ __launch_bounds__(kStripThreads, kSrc == kSrcColMajor ? 3 : 4) void k
 #endif
     lds_barrier();
     if (tid < bands) b.ncode[((size_t)f * g.emitters + strip) * bands + tid] = band_cursor[tid];
+    if constexpr (kCmGen) {
+        if (cm_f & kCfFirst)
+            for (int r = tid; r < N; r += kStripThreads) cm_pub()[kCmPubWords + r] = (uint32_t)cm_win0_l[r];
+    }
     if constexpr (kIndexed || kStructured) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
@@ -2287,6 +2733,7 @@ void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int sou
     else if (source == kSrcInPlace) launch_walk<kSrcInPlace>(g, b, nf, mode, grid, st);
     else if (source == kSrcStructured) launch_walk<kSrcStructured>(g, b, nf, mode, grid, st);
     else if (source == kSrcColMajor) launch_walk<kSrcColMajor>(g, b, nf, mode, grid, st);
+    else if (source == kSrcColMajorGen) launch_walk<kSrcColMajorGen>(g, b, nf, mode, grid, st);
     else launch_walk<kSrcGather>(g, b, nf, mode, grid, st);
 }
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st)
@@ -2294,10 +2741,10 @@ void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stre
     if (nf == 0) return;
     hipLaunchKernelGGL(k_probe, dim3(nf), dim3(kProbeThreads), 0, st, b, g, allow_stream ? 1 : 0);
 }
-void launch_verdict(const BatchPtrs &b, int nf, uint32_t *host_hint, hipStream_t st)
+void launch_verdict(const Geometry &g, const BatchPtrs &b, int nf, uint32_t *host_hint, hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_verdict, dim3(1), dim3(1024), 0, st, b.info, nf, host_hint);
+    hipLaunchKernelGGL(k_verdict, dim3(1), dim3(1024), 0, st, b.info, nf, host_hint, b.cm_sync, g.N);
 }
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st)
 {

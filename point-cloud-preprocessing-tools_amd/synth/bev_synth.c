@@ -212,6 +212,51 @@ size_t bev_synth_firing_order(const bev_params_t *p, uint64_t seed, uint32_t fra
     return n;
 }
 
+/* kind 1b — what mulran_point_cloud_select writes for a REAL Ouster sweep (MulranPointCloudSelect.cpp:112-130), beyond
+ * the idealised kind 1: the sweep starts at an arbitrary azimuth (`phase`, in columns) and turns either way (`dir`),
+ * the 64 lasers sit in four staggered columns (beam b fires `stagger`-scaled +9, +3, -3, -9 columns off its firing's
+ * azimuth, b mod 4), and a share `noret` of the records are no-returns: x = y = z = 0, for which the selector computes
+ * atan2(0, 0) = 0 and hence column 0 of the record's row — every such record lands in slot (row, 0), the last one in
+ * input order wins.  `t` carries the record's position so that WHICH record won is visible in the output. */
+size_t bev_synth_firing_real(const bev_params_t *p, uint64_t seed, uint32_t frame_id, double noret, int phase, int dir,
+                             double stagger, bev_point_t *out, size_t cap)
+{
+    static const double beam_off[4] = { 9.0, 3.0, -3.0, -9.0 };
+    synth_geom_t g;
+    geom_for(p, &g);
+    const uint64_t S = (uint64_t)g.n_scan * (uint64_t)g.horizon_scan;
+    const uint64_t fseed = mix64(seed + 0x100000001b3ULL * (uint64_t)frame_id);
+    if (!out) return (size_t)S;
+    const double H = (double)g.horizon_scan;
+    size_t n = 0;
+    for (uint64_t k = 0; k < S && n < cap; ++k, ++n) {
+        int r = (int)(k % (uint64_t)g.n_scan);
+        uint64_t fire = k / (uint64_t)g.n_scan;
+        if (u01(hash3(fseed, k, 10)) < noret) { /* no return: the origin, column 0 */
+            memset(&out[n], 0, sizeof(out[n]));
+            out[n].label = -2;
+            out[n].row = (uint16_t)r;
+            out[n].col = 0;
+            out[n].t = (uint32_t)k;
+            continue;
+        }
+        double jitter = u01(hash3(fseed, k, 6)) - 0.5; /* +-half a column */
+        double colpos = (double)phase + (dir < 0 ? -(double)fire : (double)fire) + stagger * beam_off[r & 3] + 0.5 + jitter;
+        colpos -= H * (double)(int64_t)(colpos / H); /* into (-H, H) */
+        if (colpos < 0.0) colpos += H;
+        double az_deg = 360.0 * colpos / H;
+        double az = az_deg * (SYNTH_PI / 180.0);
+        make_return(&g, fseed, k, r, az, &out[n]);
+        if (out[n].intensity == -1.0f) out[n].intensity = 0.5f;
+        double colf = az_deg / 360.0 * H;
+        uint32_t col = (uint32_t)(colf + 0.5); /* round half away from zero of a non-negative value; may be == H */
+        out[n].row = (uint16_t)r;
+        out[n].col = (uint16_t)col;
+        out[n].t = (uint32_t)k;
+    }
+    return n;
+}
+
 /* kind 2 — Oxford-style concatenation (config 5): `n_sweeps` sweeps of the
  * same sensor with a small per-sweep pose jitter, every sweep row-major, so
  * P ~ n_sweeps * S * keep points land in S slots. */

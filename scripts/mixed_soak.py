@@ -27,6 +27,7 @@ def make(kind, fid):
     if kind == 0: return synth.sweep(p, fid, keep=0.97, n_dup=int(300 * S / 33792))
     if kind == 1: return synth.structured(p, fid, 0.95, kitti_intensity=bool(fid % 2))
     if kind == 2: return synth.firing_order(p, fid)
+    if kind == 6: return synth.firing_real(p, fid, noret=(0.0, 0.03, 0.3)[fid % 3])   # a real MulRan sweep: phase, direction, stagger, no-returns
     if kind == 3: return synth.adversarial(p, S // 2 + fid % 1000, fid, False)
     if kind == 4: return synth.sweep(p, fid, keep=1.0, n_dup=0)            # structured and sorted at once
     f = synth.structured(p, fid, 1.0)                                      # a structured cloud with ONE hidden empty record: wrong guess, redone
@@ -47,9 +48,9 @@ for rnd in range(rounds):
     kinds = []
     while len(kinds) < n:
         if rng.random() < 0.5:
-            kinds += [int(rng.integers(0, 6))] * int(rng.integers(1, 3 * sub))
+            kinds += [int(rng.integers(0, 7))] * int(rng.integers(1, 3 * sub))
         else:
-            kinds += [int(k) for k in rng.integers(0, 6, int(rng.integers(1, 2 * sub)))]
+            kinds += [int(k) for k in rng.integers(0, 7, int(rng.integers(1, 2 * sub)))]
     kinds = kinds[:n]
     with ThreadPoolExecutor(16) as ex:
         frames = list(ex.map(lambda a: make(a[1], 100000 * rnd + a[0]), enumerate(kinds)))

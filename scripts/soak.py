@@ -1,5 +1,5 @@
 """Soak: many different BASELINE-config frames through the pipelined device-resident path, EVERY frame compared with the
-oracle.  usage (GPU box): python scripts/soak.py [rounds] [frames_per_round] [hdl64_sweep | os1_firing | hdl32_sweep | hdl64_adversarial | hdl64_structured | hdl64_gappy] [sub_batch]
+oracle.  usage (GPU box): python scripts/soak.py [rounds] [frames_per_round] [hdl64_sweep | os1_firing | os1_firing_real | hdl64_firing_real | hdl32_sweep | hdl64_adversarial | hdl64_structured | hdl64_gappy] [sub_batch]
 (hdl64_gappy: sorted sweeps with BURSTS of dropped returns — runs of 1 to 400 slots at random places, next to row starts and strip
 boundaries too —, a tenth of the returns invalid, appended points: what shifts the in-place source's windows off their spans)
 (sub_batch defaults to 500, bench.py's launch size)"""
@@ -17,7 +17,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 workload = sys.argv[3] if len(sys.argv) > 3 else "hdl64_sweep"
 sub_batch = int(sys.argv[4]) if len(sys.argv) > 4 else 500
 p = bev_amd.params_for_sensor({"hdl64_sweep": "HDL_64E", "os1_firing": "OS1_64", "hdl32_sweep": "HDL_32E", "hdl64_adversarial": "HDL_64E",
-                               "hdl64_structured": "HDL_64E", "hdl64_gappy": "HDL_64E"}[workload])
+                               "hdl64_structured": "HDL_64E", "hdl64_gappy": "HDL_64E", "os1_firing_real": "OS1_64", "hdl64_firing_real": "HDL_64E"}[workload])
 sp = orc.sensor_from_params(p)
 
 
@@ -25,6 +25,15 @@ def make_frame(rnd, f):
     fid = 100000 + rnd * n + f
     if workload == "os1_firing":
         return synth.firing_order(p, fid)
+    if workload in ("os1_firing_real", "hdl64_firing_real"):
+        # real MulRan sweeps (round 5): no-return shares from none to a third, every start azimuth and direction, staggers from
+        # none to full; a tenth of the frames with invalid returns (intensity -1: phase A's fallbacks cross the row ends)
+        rng = np.random.default_rng(fid)
+        fr = synth.firing_real(p, fid, noret=float(rng.choice([0.0, 0.002, 0.03, 0.03, 0.1, 0.33])),
+                               stagger=float(rng.choice([0.0, 0.5, 1.0, 1.0])))
+        if f % 10 == 3:
+            fr["intensity"][rng.random(len(fr)) < float(rng.choice([0.02, 0.2]))] = -1.0
+        return fr
     if workload == "hdl64_gappy":
         rng = np.random.default_rng(fid)
         base = synth.sweep(p, fid, keep=1.0 - 0.01 * (f % 4), n_dup=(0, 200, 3000)[f % 3])

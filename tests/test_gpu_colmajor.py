@@ -12,7 +12,7 @@ import oracle_lib as orc
 from bev_amd import synth
 
 pytestmark = pytest.mark.gpu
-COLMAJOR, REDO, GENERAL = 4, 2, 0
+COLMAJOR, COLMAJOR_GEN, REDO, GENERAL = 4, 5, 2, 0   # 4: the plain sweep (round 4's walk), 5: any phase / direction / stagger / no-returns
 
 
 def _run(p, frames, max_batch=16):
@@ -59,7 +59,7 @@ def test_firing_order_is_read_in_place(sensor):
     modes, info = _run(p, frames)
     assert modes == [COLMAJOR] * 5, info
     for i in range(5):
-        assert int(info[i, 0]) == p.slots and int(info[i, 2]) == p.slots and int(info[i, 3]) == 0
+        assert int(info[i, 0]) == p.slots and int(info[i, 2]) == p.slots and (int(info[i, 3]) & 1) == 0   # (bit 1: a wrap-around halo fell back on column 0 — compared by k_verdict)
 
 
 def test_defects_hidden_from_the_samples_are_caught_and_redone():
@@ -73,11 +73,11 @@ def test_defects_hidden_from_the_samples_are_caught_and_redone():
 
     wrong_beam = base.copy()
     wrong_beam[at(30000)]["row"] = (int(base[at(30000)]["row"]) + 1) % 64
-    far_column = base.copy()              # nine columns past its firing: more than the walk's window allows for
-    far_column[at(20000)]["col"] = at(20000) // 64 + 9
-    behind = base.copy()                  # a column BEFORE its firing's number
+    far_column = base.copy()              # twenty columns past its firing: more than the walk's window (13 columns from the row's base) allows for
+    far_column[at(20000)]["col"] = at(20000) // 64 + 20
+    behind = base.copy()                  # a column well BEFORE its firing's number
     k = at(40000)
-    behind[k]["col"] = max(0, k // 64 - 3)
+    behind[k]["col"] = max(1, k // 64 - 9)
     swapped = base.copy()                 # two beams of one firing swapped
     a = at(50000)
     a -= a % 64
@@ -98,3 +98,43 @@ def test_odd_sensors_and_mixed_sub_batches():
         frames.append(synth.structured(p, 8, 0.9))
         modes, info = _run(p, frames)
         assert modes[:2] == [COLMAJOR, COLMAJOR] and modes[3] == 3, (n, h, g, info)
+
+
+# ---- round 5: what mulran_point_cloud_select writes for REAL sweeps (MulranPointCloudSelect.cpp:112-130): any start
+# azimuth, either direction of rotation, the four staggered laser columns, no-return records (x = y = 0 -> atan2(0, 0) = 0
+# -> column 0 of the record's row, the last one in input order winning the slot)
+@pytest.mark.parametrize("sensor", ["OS1_64", "HDL_32E", "HDL_64E"])
+def test_real_mulran_sweeps_are_read_in_place(sensor):
+    p = bev_amd.params_for_sensor(sensor)
+    frames = [synth.firing_real(p, 11), synth.firing_real(p, 12, noret=0.0), synth.firing_real(p, 13, noret=0.3),
+              synth.firing_real(p, 14, phase=0, direction=1, stagger=0.0), synth.firing_real(p, 15, phase=p.horizon_scan - 1, direction=-1),
+              synth.firing_real(p, 16, noret=0.002), synth.firing_real(p, 17, phase=5, direction=-1, stagger=0.5)]
+    modes, info = _run(p, frames)
+    # (frame 14: phase 0, forward, no stagger, but 3 % no-return records: not the plain sweep either)
+    assert modes == [COLMAJOR_GEN] * len(frames), info
+
+
+def test_real_sweeps_with_invalid_returns_match_whatever_the_route():
+    """intensity -1 in column H - 2 makes phase A fall back on column 0 of the row above (BatchMultiBevGen.cpp:146-149) —
+    where a no-return record of ANY firing may sit, which only strip 0 hears of: the strip with the wrap-around halo says
+    what it took, k_verdict compares, the frame is redone when they differ.  Equal to the oracle either way."""
+    p = bev_amd.params_for_sensor("OS1_64")
+    frames = [_with_invalid(synth.firing_real(p, 21 + i, noret=nr), 21 + i, share) for i, (nr, share) in
+              enumerate([(0.03, 0.15), (0.0, 0.3), (0.3, 0.05), (0.01, 0.5), (0.1, 0.02)])]
+    modes, info = _run(p, frames)
+    assert set(modes) <= {COLMAJOR_GEN, REDO}, info
+    assert modes[1] == COLMAJOR_GEN, info      # no no-return records: nothing to disagree about
+
+
+def test_real_sweep_defects_are_caught():
+    """a return far from where its firing's returns lie (and not in column 0), a wrong beam: the frame goes the general
+    way after the walk has seen it — the probe's samples do not"""
+    p = bev_amd.params_for_sensor("OS1_64")
+    good = synth.firing_real(p, 31)
+    a = good.copy()
+    k = 64 * 400 + 7            # firing 400, beam 7
+    a["col"][k] = (int(a["col"][k]) + 200) % p.horizon_scan or 1
+    b2 = good.copy()
+    b2["row"][64 * 500 + 9] = 10
+    modes, info = _run(p, [a, b2, good])
+    assert modes[2] == COLMAJOR_GEN and modes[0] in (REDO, GENERAL) and modes[1] in (REDO, GENERAL), info
