@@ -696,6 +696,14 @@ __device__ __forceinline__ void glds4_nt(const void *gsrc, uint32_t lds_dst)
 template <int N>
 __device__ __forceinline__ void wait_vm()
 { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+/* a per-lane value as the row loop's body should see it: NOT loop-invariant, so that the lane predicates made from it
+ * (lane < 4, lane & 2 ...) are compared afresh where they are used — hoisted out of the loop each of them is a pair of
+ * scalar registers that the loop then spills and restores (k_walk<firing order>: 58 spilled scalars, 60 restores per step) */
+__device__ __forceinline__ int fresh(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
 /* a wave-uniform value that only feeds vector instructions: keep it out of the scalar file */
 template <class T>
 __device__ __forceinline__ T in_vgpr(T v)
@@ -1111,8 +1119,11 @@ __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSr
             cm_side_key = (lane < kSideFirings && kl < H) ? ((((uint32_t)firing_of(mod_h(su0 + kl % H)) + 1u) << kLocBits) | (kLocSide + (uint32_t)kl)) : 0u;
         }
     }
-    const int cm_words = (strips - 1) * 2; /* (<= 30: kCmMaxStrips) strip 0 listens to this many words per band */
-    auto cm_pub = [&]() -> gptr<uint32_t> { return (gptr<uint32_t>)(b.cm_sync + (size_t)f * kCmSyncWords); }; /* [band][strip][2], then the per-row words */
+    const int cm_words_v = in_vgpr((strips - 1) * 2); /* (<= 30: kCmMaxStrips) strip 0 listens to this many words per band (kept in a vector register: see cm_pub_v) */
+    /* the frame's words of cm_sync: [band][strip][2], then the per-row words.  (The pointer lives in vector registers: these are
+     * rare accesses, and every scalar register kept across the row loop is one more that the loop spills.) */
+    const uint64_t cm_pub_v = kCmGen ? in_vgpr((uint64_t)(uintptr_t)(b.cm_sync + (size_t)f * kCmSyncWords)) : 0ull;
+    auto cm_pub = [&]() -> gptr<uint32_t> { return (gptr<uint32_t>)(uintptr_t)cm_pub_v; };
     auto cm_buf = [&](int band) -> uint32_t { return (uint32_t)(band & 1) * (uint32_t)kCmBuf; };
     /* rows 2 * band, 2 * band + 1 of this thread's firing: four 16-byte pieces of one 64-byte sector -> piece j at
      * buffer + j * 4 KiB + thread * 16; wave 0: the same of the kCmExt firings behind the window; wave 1 of strip 0: the
@@ -1145,13 +1156,14 @@ __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSr
         const bool two = r0 + 1 < N;
         glds16x2(src, at, src + 16, at + 4096u);
         glds16x2(src + (two ? 32 : 0), at + 8192u, src + (two ? 48 : 16), at + 12288u);
-        const uint32_t second = ((lane & 2) && two) ? 32u : 0u; /* (piece >> 1: the band's second row) */
+        const int ln = fresh(lane);
+        const uint32_t second = ((ln & 2) && two) ? 32u : 0u; /* (piece >> 1: the band's second row) */
         if (cm_f & kCfExt) /* (uniform) the extra firings */
             glds16(fbytes + cm_ext_off + (uint32_t)r0 * 32u + second, ring_l + cm_buf(band) + (uint32_t)kBandBytes);
         if (cm_f & (kCfFlat | kCfWrap)) { /* (uniform) */
             const bool flat = (cm_f & kCfFlat) != 0u;
             /* the flat-index halo wants rows r0 - 1, r0: none before row 0 (that piece fetches row 0 and is not entered) */
-            const int row = flat ? r0 - 1 + ((lane & 2) ? 1 : 0) : r0 + (((lane & 2) && two) ? 1 : 0);
+            const int row = flat ? r0 - 1 + ((ln & 2) ? 1 : 0) : r0 + (((ln & 2) && two) ? 1 : 0);
             const uint32_t side_at = ring_l + cm_buf(band) + (uint32_t)(kBandBytes + kExtBytes);
             glds16(fbytes + cm_side_off[0] + (uint32_t)(row < 0 ? 0 : row) * 32u, side_at);
             glds16(fbytes + cm_side_off[1] + (uint32_t)(row < 0 ? 0 : row) * 32u, side_at + 16u * 64u);
@@ -1165,30 +1177,33 @@ __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSr
     __shared__ uint32_t cm_poll_l[2][kCmGen ? 32 : 1];
     auto ask_band = [&](int band) { /* (wave 3) */
         if (band * kBandRows >= N) return; /* (uniform) */
-        if (lane < cm_words) glds4_nt(b.cm_sync + (size_t)f * kCmSyncWords + ((size_t)band * kCmMaxStrips + 1) * 2 + lane, __builtin_amdgcn_readfirstlane(lds_addr(&cm_poll_l[band & 1][0])));
+        const int words = __builtin_amdgcn_readfirstlane(cm_words_v);
+        if (fresh(lane) < words) glds4_nt((const uint32_t *)(uintptr_t)cm_pub_v + ((size_t)band * kCmMaxStrips + 1) * 2 + lane, __builtin_amdgcn_readfirstlane(lds_addr(&cm_poll_l[band & 1][0])));
     };
     auto take_band = [&](int band, uint32_t w) { /* (wave 3) the reports are in: the larger firing per row, the records */
-        const int r0 = band * kBandRows;
+        const int r0 = band * kBandRows, words = __builtin_amdgcn_readfirstlane(cm_words_v);
         /* even lanes: the band's first row, odd lanes: its second.  (The maxima by v_readlane and scalar compares: as lane
          * shuffles — five LDS round trips on a busy LDS — this cost strip 0 0.7 us at every other step.) */
         uint32_t v0 = 0u, v1 = 0u;
-        for (int k = 0; k < cm_words; k += 2) {
+        for (int k = 0; k < words; k += 2) {
             const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)w, k) & 0xffffu, c = (uint32_t)__builtin_amdgcn_readlane((int)w, k + 1) & 0xffffu;
             v0 = a > v0 ? a : v0;
             v1 = c > v1 ? c : v1;
         }
-        if (lane < 2) cm_spec_l[band & 1][lane] = lane ? v1 : v0;
-        if ((v0 | v1) != 0u && lane < 4) { /* (uniform test) the records (firing v - 1, row r0 + lane / 2); none: the frame's first record, never entered */
-            const uint32_t vv = (lane >> 1) ? v1 : v0;
-            const int row = r0 + (lane >> 1);
+        const int ln = fresh(lane);
+        if (ln < 2) cm_spec_l[band & 1][ln] = ln ? v1 : v0;
+        if ((v0 | v1) != 0u && ln < 4) { /* (uniform test) the records (firing v - 1, row r0 + lane / 2); none: the frame's first record, never entered */
+            const uint32_t vv = (ln >> 1) ? v1 : v0;
+            const int row = r0 + (ln >> 1);
             const bool ok = vv != 0u && row < N;
-            glds16(fbytes + ((size_t)(ok ? vv - 1u : 0u) * N + (ok ? row : 0)) * 32u + 16 * (lane & 1),
+            glds16(fbytes + ((size_t)(ok ? vv - 1u : 0u) * N + (ok ? row : 0)) * 32u + 16 * (ln & 1),
                    ring_l + cm_buf(band) + (uint32_t)(kBandBytes + kExtBytes + kSideBytes));
         }
     };
     auto try_band = [&](int band) -> bool { /* (wave 3, after a memory wait) have all the others reported? */
         if (band * kBandRows >= N) return true; /* (uniform) */
-        const uint32_t w = lane < cm_words ? cm_poll_l[band & 1][lane] : kCmUsedBit;
+        const int ln = fresh(lane), words = __builtin_amdgcn_readfirstlane(cm_words_v);
+        const uint32_t w = ln < words ? cm_poll_l[band & 1][ln & 31] : kCmUsedBit;
         if (__ballot((w & kCmUsedBit) == 0u) != 0ull) return false;
         take_band(band, w);
         return true;
@@ -1198,10 +1213,11 @@ __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSr
                                         * and stays there */
         if (band * kBandRows >= N) return; /* (uniform) */
         const bool more = (band + 2) * kBandRows < N;
+        const int words = __builtin_amdgcn_readfirstlane(cm_words_v);
         uint32_t w = 0u, spins = 0u;
         for (;;) {
             const int l = lane & 31;
-            w = (l < cm_words && (lane < 32 || more)) ? __hip_atomic_load(cm_pub() + ((size_t)(band + 2 * (lane >> 5)) * kCmMaxStrips + 1) * 2 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+            w = (l < words && (lane < 32 || more)) ? __hip_atomic_load(cm_pub() + ((size_t)(band + 2 * (lane >> 5)) * kCmMaxStrips + 1) * 2 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                                       : kCmUsedBit;
             if (__ballot((w & kCmUsedBit) == 0u) == 0ull) break;
             if (++spins > kCmSpins) { /* (never seen; the frame is redone the general way) */
@@ -1287,30 +1303,31 @@ __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSr
                                                                                              * a no-return record after all, in a frame whose strips do not talk? */
                 const bool stray = cm_vf == 3u && rcw == (uint32_t)rho && mod_h(-cm_u - base) > kColMaxDisp;
                 if (__ballot(stray) != 0ull) {
-                    if (stray) atomicMax(b.cm_sync + (size_t)f * kCmSyncWords + kCmPubWords + 2 * kCmMaxRows + rho, cm_key >> kLocBits);
+                    if (stray) atomicMax((uint32_t *)(uintptr_t)cm_pub_v + kCmPubWords + 2 * kCmMaxRows + rho, cm_key >> kLocBits);
                     failed |= kInfoCmStray;
                 }
             }
         }
-        if ((cm_f & kCfExt) && lane < kCmExt) { /* (uniform per wave) the extra firings: never counted here */
-            const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + kBandBytes + lane * 64 + (rho & 1) * 32 + 20);
+        const int ln = fresh(lane);
+        if ((cm_f & kCfExt) && ln < kCmExt) { /* (uniform per wave) the extra firings: never counted here */
+            const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + kBandBytes + ln * 64 + (rho & 1) * 32 + 20);
             const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
             const uint32_t off = col - (uint32_t)first_col;
             atomicMax(&irow[((cm_ext_key != 0u) & (row == (uint32_t)rho) & (col < (uint32_t)H) & (off < (uint32_t)row_span)) ? off : (uint32_t)kStripThreads], cm_ext_key);
         }
         if (cm_f & (kCfFlat | kCfWrap)) { /* wave-uniform */
             const bool flat = (cm_f & kCfFlat) != 0u;
-            const int e = lane & (kSideFirings - 1); /* entry of the side area */
+            const int e = ln & (kSideFirings - 1); /* entry of the side area */
             const int want_row = flat ? rho - 1 : rho;
             const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + kBandBytes + kExtBytes + e * 64 + (rho & 1) * 32 + 20);
             const uint32_t row = rcw & 0xffffu, col = rcw >> 16;
             /* flat: columns H - 2, H - 1 of row rho - 1 at offsets 0, 1; wrap: columns 0, 1 of row rho at H - first_col + 0, 1 */
             const uint32_t off = flat ? col - (uint32_t)(H - 2) : (uint32_t)(H - first_col) + col;
-            const bool ok = (lane < kSideFirings) & (cm_side_key != 0u) & (want_row >= 0) & (row == (uint32_t)want_row) &
+            const bool ok = (ln < kSideFirings) & (cm_side_key != 0u) & (want_row >= 0) & (row == (uint32_t)want_row) &
                             (flat ? (col < (uint32_t)H) & (off < 2u) : (col < 2u) & (off < (uint32_t)kStripVirt));
             atomicMax(&irow[ok ? off : (uint32_t)kStripThreads], cm_side_key);
         }
-        if ((cm_f & kCfListens) && lane == 0) { /* the last no-return record of the row that another strip owns: column 0 = offset 2 */
+        if ((cm_f & kCfListens) && ln == 0) { /* the last no-return record of the row that another strip owns: column 0 = offset 2 */
             const uint32_t v = cm_spec_l[(rho / kBandRows) & 1][rho & 1];
             const uint32_t rcw = *reinterpret_cast<const uint32_t *>(buf + kBandBytes + kExtBytes + kSideBytes + (rho & 1) * 32 + 20);
             if (v != 0u) {

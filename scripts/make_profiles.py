@@ -27,7 +27,7 @@ for name, out in (("bench_under_rocprof.log", "_bench_under_rocprof.json"), ("be
     if os.path.exists(p):
         json.dump(last_json_line(p), open(prefix + out, "w"), indent=1)
 
-for wl in ("os1_firing", "oxford_concat", "hdl64_structured"):
+for wl in ("os1_firing", "oxford_concat", "hdl64_structured", "os1_firing_real", "mixed"):
     st = glob.glob(os.path.join(src, "trace_" + wl, "**", "*kernel_stats.csv"), recursive=True)
     if st:
         shutil.copy(st[0], f"{prefix}_{wl}_kernel_stats.csv")
@@ -91,6 +91,10 @@ def pmc_summary(dir_glob, out_path, frames, what):
 pmc_summary("pmc[0-9]*", prefix + "_pmc_traffic.json", pmc_frames, "bench.py --steps 1 --warmup 1 (the 1000-frame workload, sub-batch 500)")
 pmc_summary("pmcgen[0-9]*", prefix + "_pmc_traffic_general.json", pmc_frames,
             "BEV_STREAM=0 bench.py --steps 1 --warmup 1 (the 1000-frame workload through the GENERAL path: order scan + gather walk)")
-for wl in ("os1_firing", "hdl64_structured"):
+for wl in ("os1_firing", "hdl64_structured", "os1_firing_real"):
     pmc_summary(f"pmc_{wl}[0-9]*", f"{prefix}_{wl}_pmc_traffic.json", pmc_frames, f"bench.py --steps 1 --warmup 1 --workload {wl}")
+pmc_summary("pmc_oxford_concat[0-9]*", prefix + "_oxford_concat_pmc_traffic.json", pmc_frames // 10, "bench.py --steps 1 --warmup 1 --workload oxford_concat --frames 100")
+rp = os.path.join(src, "repeat.txt")
+if os.path.exists(rp):
+    shutil.copy(rp, prefix + "_repeat.txt")
 print("files:", sorted(glob.glob(prefix + "_*")))

@@ -1,8 +1,9 @@
-# usage (on the GPU box): bash scripts/profile_round.sh <tag> [pmc] [pmcothers] [others]   -> gpurun_out/<tag>/...
+# usage (on the GPU box): bash scripts/profile_round.sh <tag> [pmc] [pmcothers] [others] [repeat]   -> gpurun_out/<tag>/...
 #   default : plain bench line (with CPU baseline) + rocprofv3 kernel trace/stats of the same command with one lane
 #   pmc     : + the PMC passes (one counter group per run) on the SAME 1000-frame workload
 #   pmcothers: + FETCH_SIZE / WRITE_SIZE passes of the general path (BEV_STREAM=0) and of os1_firing / hdl64_structured
-#   others  : + bench line and kernel stats of BASELINE configs 3 (os1_firing) and 5 (oxford_concat) and of hdl64_structured
+#   others  : + bench line and kernel stats of BASELINE configs 3 (os1_firing) and 5 (oxford_concat), of hdl64_structured, os1_firing_real and mixed
+#   repeat  : + the graded workload and hdl64_structured five times each, unprofiled, on the same box -> repeat.txt
 # The libraries are built ONCE up front; every profiled command is `rocprofv3 ... -- python3 bench.py --no-build`, so
 # nothing is spawned from a process the profiler has already attached to the GPU.
 export TMPDIR=/tmp
@@ -32,13 +33,20 @@ i=0
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   BEV_STREAM=0 BEV_LANES=1 timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcgen$i -- python3 bench.py --no-build --steps 1 --warmup 1 --no-cpu --no-profile > $OUT/pmcgen$i.log 2>&1 || exit 1
-  for wl in os1_firing hdl64_structured; do
-    BEV_LANES=1 timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_${wl}$i -- python3 bench.py --no-build --steps 1 --warmup 1 --no-cpu --no-profile --workload $wl > $OUT/pmc_${wl}$i.log 2>&1 || exit 1
+  for wl in os1_firing hdl64_structured os1_firing_real oxford_concat; do
+    F=1000; if [ $wl = oxford_concat ]; then F=100; fi
+    BEV_LANES=1 timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_${wl}$i -- python3 bench.py --no-build --steps 1 --warmup 1 --no-cpu --no-profile --workload $wl --frames $F > $OUT/pmc_${wl}$i.log 2>&1 || exit 1
   done
 done
 fi
+if [ "$w" = repeat ]; then
+# 3c. the graded workload and the structured layout five times each, unprofiled, interleaved: median and spread on ONE box
+for rep in 1 2 3 4 5; do for wl in hdl64_sweep hdl64_structured; do
+  timeout 300 python3 bench.py --no-build --steps 20 --warmup 5 --no-cpu --workload $wl 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$wl', round(d['value']), 'frames/s; fenced median', round(1e3*d['config']['frames_per_gpu']/d['ms_per_step_median_fenced']), '; dominant kernel frac', round(d['roofline']['frac'],3), 'pipeline frac', round(d['roofline']['pipeline']['frac'],3))" >> $OUT/repeat.txt || exit 1
+done; done
+fi
 if [ "$w" = others ]; then
-for wl in os1_firing oxford_concat hdl64_structured; do
+for wl in os1_firing oxford_concat hdl64_structured os1_firing_real mixed; do
   F=1000; if [ $wl = oxford_concat ]; then F=100; fi
   timeout 900 python3 bench.py --no-build --steps 20 --warmup 5 --workload $wl --frames $F --cpu-sample 50 > $OUT/bench_$wl.log 2>$OUT/bench_$wl.err || exit 1
   BEV_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -- python3 bench.py --no-build --steps 3 --warmup 1 --no-cpu --workload $wl --frames $F > $OUT/bench_under_rocprof_$wl.log 2>&1 || exit 1
