@@ -279,6 +279,11 @@ def main() -> int:
             })
         dom = max(stats, key=lambda s: s["total_ms"])
         per_launch_frames = dom["frames"] / dom["launches"]
+        if args.workload == "mixed":  # a walk moves only the frames of its route: their share of the last sub-batch stands for every launch
+            route_of = {"k_walk": ("1",), "k_walk_structured": ("3",), "k_walk_colmajor": ("4",), "k_walk_colmajor_gen": ("5",), "k_walk_general": ("0", "2")}
+            share = sum(routes.get(r, 0) for r in route_of.get(dom["name"], ())) / max(1, sum(routes.values()))
+            if dom["name"] in route_of:
+                per_launch_frames *= share
         avg_ms = dom["total_ms"] / dom["launches"]
         dom_bytes = own_bytes.get(dom["name"], 0.0) * per_launch_frames
         achieved = dom_bytes / (avg_ms * 1e-3) / 1e9

@@ -94,6 +94,33 @@ pmc_summary("pmcgen[0-9]*", prefix + "_pmc_traffic_general.json", pmc_frames,
 for wl in ("os1_firing", "hdl64_structured", "os1_firing_real"):
     pmc_summary(f"pmc_{wl}[0-9]*", f"{prefix}_{wl}_pmc_traffic.json", pmc_frames, f"bench.py --steps 1 --warmup 1 --workload {wl}")
 pmc_summary("pmc_oxford_concat[0-9]*", prefix + "_oxford_concat_pmc_traffic.json", pmc_frames // 10, "bench.py --steps 1 --warmup 1 --workload oxford_concat --frames 100")
+# the bench lines of THIS run carry the traffic of THIS run's PMC passes (bench.py itself can only look at what was committed
+# before it ran: the counters are collected after the bench line is printed)
+PREFIX = {"k_walk": "k_walk<2,", "k_walk_general": "k_walk<0,", "k_walk_structured": "k_walk<3,", "k_walk_colmajor": "k_walk<4,",
+          "k_walk_colmajor_gen": "k_walk<5,"}
+for tag in ("", "os1_firing_", "hdl64_structured_", "os1_firing_real_", "oxford_concat_"):
+    pmc_path = f"{prefix}_{tag}pmc_traffic.json"
+    if not os.path.exists(pmc_path):
+        continue
+    pmc = json.load(open(pmc_path))
+    for kind in ("bench", "bench_under_rocprof"):
+        bp = f"{prefix}_{tag}{kind}.json"
+        if not os.path.exists(bp):
+            continue
+        d = json.load(open(bp))
+        r = d.get("roofline")
+        if not r:
+            continue
+        pre = PREFIX.get(r["kernel"], r["kernel"])
+        for kname, kv in pmc["kernels"].items():
+            if kname.startswith(pre) and kv.get("hbm_bytes_per_frame", 0) > 1e5:
+                r["traffic"] = kv["hbm_bytes_per_frame"] * r["frames_per_launch"]
+                r["traffic_source"] = f"{os.path.basename(pmc_path)} (the PMC passes of the same profile_round.sh run; filled in by scripts/make_profiles.py): {pmc.get('source', '')}"
+        tot = pmc.get("hbm_bytes_per_frame_all_kernels")
+        if tot and "pipeline" in r:
+            r["pipeline"]["hbm_traffic_per_frame_all_kernels"] = tot
+            r["pipeline"]["real_traffic_gbps"] = tot * d["value"] / d["n_gpus"] / 1e9
+        json.dump(d, open(bp, "w"), indent=1)
 rp = os.path.join(src, "repeat.txt")
 if os.path.exists(rp):
     shutil.copy(rp, prefix + "_repeat.txt")
