@@ -1884,6 +1884,14 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
 
     int f, quarter;
     if (!map_block_xcd(blockIdx.x, nf, kSumQ, f, quarter)) return; /* the quarters of a frame on one XCD: they read the same lines */
+    /* ... in a different order from frame to frame.  Measured (scripts/cell_sums_timeline.py): with quarter = position in
+     * the frame, a quarter that runs long in every frame (OS1-64 firing order: quarter 3 holds the cells with the longest
+     * runs, 103 us per workgroup where the others take 41) ends up four to a CU on every fourth CU — a launch's workgroups go
+     * to an XCD's CUs in turn — and the launch's second round of workgroups did not start before THOSE had ended: 55 us
+     * with three quarters of the chip idle.  Rotated, every CU holds a mix and the second round starts as the short ones
+     * end: 0.43 -> 0.35 us per OS1 frame, config 3 +8 %. */
+    static_assert((kSumQ & (kSumQ - 1)) == 0, "the rotation below");
+    quarter = (quarter + (f >> 3)) & (kSumQ - 1);
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint2 *ccand = b.cand + (size_t)f * T * kSeg; /* key | height */
     const uint32_t *fn = b.ncand + (size_t)f * T;
@@ -2158,6 +2166,15 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
     for (int c = tid; c < kCellsQ; c += kSumThreads)
         if (c * kSumQ + quarter < kCells) avg[c * kSumQ + quarter] = sumv[c] / cntv[c]; /* :210 */
     PH_PRINT("cell_sums all-parts", tid == 0 && blockIdx.x == 100);
+#ifdef BEV_CS_TL /* developer build: start / end of every workgroup of this launch in the walk's timeline records */
+    if (tid == 0 && blockIdx.x < kWalkTlCap) {
+        long long *rec = g_walk_tl[blockIdx.x];
+        rec[0] = ph_clk[0];
+        rec[1] = wall_clock64();
+        rec[2] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        rec[3] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((long long)GC << 32) | ((long long)quarter << 8);
+    }
+#endif
 }
 
 /* ------------------------------------------------------------------------- */

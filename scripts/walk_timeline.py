@@ -43,3 +43,13 @@ print("distinct CUs", len(per), "workgroups per CU: min", min(per.values()), "ma
 T = int(en.max() // 10) + 1
 conc = [int(((st <= 10 * k + 5) & (en > 10 * k + 5)).sum()) for k in range(T)]
 print("resident workgroups every 10 us:", conc)
+life = en - st
+slots = 4 * 256
+print(f"sum of lifetimes {life.sum():.0f} us over {slots} slots = {life.sum() / slots:.1f} us of a {en.max():.1f} us launch: {life.sum() / slots / en.max():.3f} of the slot-time used")
+strips = (p.horizon_scan + 235) // 236
+blk = np.arange(len(hw)) if len(hw) == 8 * ((F + 7) // 8) * strips else None
+if blk is not None:
+    s_of = (blk >> 3) % strips
+    for s in range(strips):
+        m = s_of == s
+        print(f"strip {s}: lifetime median {np.median(life[m]):.1f} p90 {np.percentile(life[m], 90):.1f}")
