@@ -285,7 +285,7 @@ void fill_geometry(const bev_params_t *p, Geometry *g)
     {   /* raster bands: M / u rows each, the middle quarter of the image cut four times finer (bev_exact.h) */
         const int M = mat_size_of(p), u = raster_bands_for(M);
         const int coarse = u ? M / u : M;
-        const int fine = coarse % 4 == 0 ? coarse / 4 : coarse;
+        const int fine = coarse % BEV_RASTER_FINE_DIV == 0 ? coarse / BEV_RASTER_FINE_DIV : coarse;
         const int z0 = (3 * u / 8) * coarse, z1 = M - z0;
         g->rp.coarse = coarse;
         g->rp.fine = fine;

@@ -25,7 +25,10 @@ constexpr int kSeg = 256;                       /* capacity of one candidate seg
 constexpr int kMaxSegs = 1024;                  /* (G + 1) * strips must not exceed this (bev_create checks) */
 constexpr int kSumWaves = 4;      /* waves of the per-frame cell-sum workgroup: the size of a column-walk workgroup */
 constexpr int kSumThreads = kSumWaves * 64;
-constexpr int kResolveThreads = 512;
+#ifndef BEV_RESOLVE_THREADS
+#define BEV_RESOLVE_THREADS 512
+#endif
+constexpr int kResolveThreads = BEV_RESOLVE_THREADS;
 constexpr int kResolveParts = 4;  /* code lists per frame written by k_ground_resolve (a contiguous quarter of the segments each) */
 /* workgroups per frame in k_ground_resolve, kResolveParts / kResolveWgs consecutive parts each: a workgroup's tables
  * (3,750 averages, their neighbour minima, edge bins, band table) cost as much as a part's candidates */
@@ -35,6 +38,12 @@ static_assert(kResolveParts % kResolveWgs == 0, "whole parts per workgroup");
 #define BEV_RASTER_THREADS 512 /* (overridable for `make exp`: bev_kernels.hip is the only user) */
 #endif
 constexpr int kRasterThreads = BEV_RASTER_THREADS;
+#ifndef BEV_RASTER_LDS_CAP
+#define BEV_RASTER_LDS_CAP (100 * 1024)
+#endif
+#ifndef BEV_RASTER_FINE_DIV
+#define BEV_RASTER_FINE_DIV 4
+#endif
 constexpr int kRasterSplit = 8;   /* x-bands per frame in the raster kernel at the reference's 224 x 224 (see raster_bands_for) */
 constexpr int kMaxBands = 32;     /* coarse + fine raster bands (see RasterParams) */
 constexpr int kMaxStrips = 280;   /* ceil(65535 / kStripCols) rounded up */

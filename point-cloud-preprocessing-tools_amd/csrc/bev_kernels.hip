@@ -60,6 +60,32 @@ using namespace bevx;
 
 namespace bevk {
 
+/* developer aid (make tl): start, end and place of EVERY workgroup of the pipeline's kernels since the last reset — what
+ * shares the chip with what, and when (scripts/pipeline_timeline.py) */
+#ifdef BEV_TL_ALL
+constexpr unsigned kTlAllCap = 1u << 17;
+__device__ long long g_tl_all[kTlAllCap][4];
+__device__ unsigned g_tl_all_n;
+#define TL_BEGIN const long long tl_all_t0 = wall_clock64()
+#define TL_END(kid)                                                                                               \
+    do {                                                                                                          \
+        if (threadIdx.x == 0) {                                                                                   \
+            const unsigned i_ = atomicAdd(&g_tl_all_n, 1u);                                                       \
+            if (i_ < kTlAllCap) {                                                                                 \
+                g_tl_all[i_][0] = tl_all_t0;                                                                      \
+                g_tl_all[i_][1] = wall_clock64();                                                                 \
+                g_tl_all[i_][2] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                \
+                                  ((long long)((unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu) << 32) | \
+                                  ((long long)(kid) << 40);                                                       \
+                g_tl_all[i_][3] = (long long)blockIdx.x;                                                          \
+            }                                                                                                     \
+        }                                                                                                         \
+    } while (0)
+#else
+#define TL_BEGIN
+#define TL_END(kid)
+#endif
+
 static const char *const kNames[K_COUNT] = {
     "k_order_scan", "k_walk", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project", "k_transform",
@@ -143,6 +169,7 @@ __device__ __forceinline__ uint32_t winner_index(uint32_t w, uint32_t tag, int s
 constexpr int kProbeThreads = BEV_PROBE_THREADS; /* one workgroup per frame */
 __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g, int allow_stream)
 {
+    TL_BEGIN;
     __shared__ uint32_t samp[kMaxSamples]; /* slot of sample k (position k * kProbeStride) */
     __shared__ uint32_t first_bad, overflow;
     __shared__ uint32_t tcnt[kTailBuckets]; /* tail points listed per (row, strip) */
@@ -455,6 +482,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
      * scatter of the tail among all the others) */
     if (tid == 0) b.info[f] = overflow ? FrameInfo{0u, kFrameGeneral, 4u, 0u} : FrameInfo{T, kFrameStream, 0u, 0u};
     PH();
+    TL_END(K_PROBE);
     PH_PRINT("probe samples prefix-end estimates tail-lists counts", tid == 0 && f == 100);
 }
 
@@ -778,6 +806,24 @@ constexpr int kWrapLead = 6;
 constexpr int kInPlaceSlot = (kWinPos + kWrapPos + kTailCap) * 32;
 constexpr uint32_t kIdxTail = 1u << 30;
 
+#ifdef BEV_TL_ALL
+} // namespace bevk
+extern "C" int bev_tl_all(long long *out, int cap, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(bevk::g_tl_all_n), sizeof n) != hipSuccess) return -1;
+    if (n > bevk::kTlAllCap) n = bevk::kTlAllCap;
+    if ((int)n > cap) n = (unsigned)cap;
+    if (out && n && hipMemcpyFromSymbol(out, HIP_SYMBOL(bevk::g_tl_all), (size_t)n * 4 * sizeof(long long)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(bevk::g_tl_all_n), &z, sizeof z) != hipSuccess) return -1;
+    }
+    return (int)n;
+}
+namespace bevk {
+#endif
 #ifdef BEV_CS_CLOCK /* developer build: start, end, HW_ID, XCC_ID of every workgroup of the last in-place walk launch */
 constexpr int kWalkTlCap = 8192;
 __device__ long long g_walk_tl[kWalkTlCap][4];
@@ -814,6 +860,7 @@ constexpr int kFlRankShift = 8; /* WalkRow::fl bits 8..13: the lane's rank among
 template <int kSrc, bool kPow2, bool kGm>
 __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSrcColMajorGen) ? 3 : 4) void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
 {
+    TL_BEGIN;
     /* kStructured: the identity source over the caller's INPUT (record i = slot i's point or an all-zero record), every
      * record checked; kIdentity below covers both (no winner table, position = slot) */
     constexpr bool kStructured = kSrc == kSrcStructured, kIdentity = kSrc == kSrcIdentity || kStructured, kInPlace = kSrc == kSrcInPlace;
@@ -1794,6 +1841,7 @@ __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSr
             if (failed) atomicOr(&b.info[f].failed, failed);
         }
     }
+    TL_END(K_GATHER_GROUND);
 }
 
 /* getOrderedCloud alone (bev_order_cloud): no ground work. */
@@ -1866,6 +1914,7 @@ size_t cell_sums_lds_bytes() { return SumDims::lds_bytes(kMaxSegs); }
 
 __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geometry g, int nf)
 {
+    TL_BEGIN;
     using D = SumDims;
     constexpr int kCellsQ = D::cells, kHistStride = D::hist_stride, kTouchWords = D::touch_words;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -2003,6 +2052,10 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
             cell[j] = lane < nn[j] ? ((key_n[j] & kKeyCellMask) >> 2) : 0xfffu; /* 0xfff: no candidate */
             zz[j] = z_n[j];
         }
+#ifdef BEV_CS_TL /* (the wait for the part's data apart from the issue of the next part's loads) */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PHA(1);
+#endif
         request(p + 1);
         PHA(5);
 
@@ -2166,7 +2219,11 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
     for (int c = tid; c < kCellsQ; c += kSumThreads)
         if (c * kSumQ + quarter < kCells) avg[c * kSumQ + quarter] = sumv[c] / cntv[c]; /* :210 */
     PH_PRINT("cell_sums all-parts", tid == 0 && blockIdx.x == 100);
+    TL_END(K_CELL_SUMS);
 #ifdef BEV_CS_TL /* developer build: start / end of every workgroup of this launch in the walk's timeline records */
+    if (tid == 0 && f == 12)
+        printf("cell_sums frame 12 quarter %d: %d candidates, %d parts; x10 ns: list %lld scan %lld place %lld sum %lld data-wait %lld request %lld hist %lld top %lld\n",
+               quarter, GC, P, pha_[0], pha_[2], pha_[3], pha_[4], pha_[1], pha_[5], pha_[6], pha_[7]);
     if (tid == 0 && blockIdx.x < kWalkTlCap) {
         long long *rec = g_walk_tl[blockIdx.x];
         rec[0] = ph_clk[0];
@@ -2224,6 +2281,7 @@ constexpr int kResolveBatch = 4;
 template <bool kPow2>
 __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b, Geometry g)
 {
+    TL_BEGIN;
     /* Per cell, the LOWEST of its in-range 4-neighbours' averages: "any neighbour n with fl(z - avg[n]) >= 0.3f" is
      * "fl(z - min_n avg[n]) >= 0.3f" — fl(z - a) does not increase with a, and the minimum passes over NaN averages exactly
      * as the comparisons do (a difference with a NaN is never >= 0.3f).  One look-up and one subtraction per candidate
@@ -2348,6 +2406,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
     lds_barrier();
     if (tid < bands) b.ncode[((size_t)f * g.emitters + g.strips + part) * bands + tid] = band_cursor[tid];
   }
+    TL_END(K_GROUND_RESOLVE);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -2359,7 +2418,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
 int raster_bands_for(int M) /* uniform bands whose two LDS planes fit; the coarse band height is M / this */
 {
     for (int bands = kRasterSplit; bands <= 16; bands *= 2)
-        if (M % bands == 0 && (size_t)2 * (M / bands) * M * sizeof(uint32_t) <= (size_t)100 * 1024) return bands;
+        if (M % bands == 0 && (size_t)2 * (M / bands) * M * sizeof(uint32_t) <= (size_t)BEV_RASTER_LDS_CAP) return bands;
     return 0;
 }
 size_t raster_lds_bytes(const Geometry &g)
@@ -2435,6 +2494,7 @@ __device__ __forceinline__ void store_planes(const uint32_t *mask, const uint32_
 
 __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geometry g, int nf, int want_multi, int want_single)
 {
+    TL_BEGIN;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     __shared__ uint32_t list_end[kMaxStrips + kResolveParts + 1]; /* inclusive prefix of this band's code-list lengths */
     __shared__ uint32_t over_l;                                    /* a writer had more codes for this band than its list holds */
@@ -2522,6 +2582,7 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
     store_planes(mask, hmax, want_multi ? b.multi : nullptr, want_single ? b.single : nullptr, f, x0, band_rows, M, L, tid,
                  kRasterThreads);
     PH();
+    TL_END(K_BEV_RASTER);
     PH_PRINT(band == 7 ? "raster7 setup codes stores" : "raster1 setup codes stores", tid == 0 && f == 100 && (band == 7 || band == 1));
 }
 

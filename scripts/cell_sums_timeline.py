@@ -1,6 +1,11 @@
-import os, sys, ctypes as C
+#!/usr/bin/env python3
+"""When, where and for how long every workgroup of ONE k_cell_sums launch ran (500 frames, one lane), by quarter, XCD and
+number of candidates; the phase clocks of frame 12's four workgroups (developer build: make -C point-cloud-preprocessing-tools_amd cstl).
+   BEV_AMD_LIB=.../csrc/libbev_cstl.so python3 scripts/cell_sums_timeline.py [OS1_64|HDL_64E]
+This is the tool that found the second round of an OS1-64 launch waiting 55 us for the long quarter (round 5)."""
+import os, sys, collections, ctypes as C
 import numpy as np
-sys.path.insert(0, '/root/repo/point-cloud-preprocessing-tools_amd'); sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT","/root/repo"),'point-cloud-preprocessing-tools_amd'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'point-cloud-preprocessing-tools_amd'))
 os.environ.setdefault("BEV_LANES", "1")
 import torch, bev_amd
 from bev_amd import synth
@@ -38,7 +43,6 @@ for k in range(4):
 hw = rec[:, 2]; cu = (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)
 slow = fr & (life > 70)
 print("slow first-round wgs:", slow.sum(), "distinct (xcc, cu):", len(set(zip(xcc[slow].tolist(), cu[slow].tolist()))), "of", len(set(zip(xcc[fr].tolist(), cu[fr].tolist()))))
-import collections
 per = collections.Counter(zip(xcc[slow].tolist(), cu[slow].tolist()))
 print("slow wgs per CU histogram:", sorted(collections.Counter(per.values()).items()))
 print("slow wgs: block index deciles", [int(x) for x in np.percentile(blk[slow], range(0, 101, 20))], "frame-local order (blk>>3)%4:", collections.Counter(q[slow].tolist()))

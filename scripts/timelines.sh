@@ -1,0 +1,10 @@
+set -e
+L=$PWD/point-cloud-preprocessing-tools_amd/csrc
+mkdir -p gpurun_out/tl
+BEV_AMD_LIB=$L/libbev_tl_all.so timeout -k 10 300 python3 scripts/pipeline_timeline.py 1000 HDL_64E 50 1000 > gpurun_out/tl/hdl_serial.txt 2>&1
+BEV_AMD_LIB=$L/libbev_tl_all.so timeout -k 10 300 python3 scripts/pipeline_timeline.py 2000 HDL_64E 50 500 > gpurun_out/tl/hdl_pipelined.txt 2>&1
+BEV_AMD_LIB=$L/libbev_tl_all.so timeout -k 10 300 python3 scripts/pipeline_timeline.py 2000 OS1_64 50 500 > gpurun_out/tl/os1_pipelined.txt 2>&1
+BEV_AMD_LIB=$L/libbev_tl_all.so timeout -k 10 300 python3 scripts/pipeline_timeline.py 1000 OS1_64 50 1000 > gpurun_out/tl/os1_serial.txt 2>&1
+BEV_AMD_LIB=$L/libbev_cstl.so timeout -k 10 300 python3 scripts/cell_sums_timeline.py OS1_64 2>&1 | grep -v "^cell_sums barrier0\|^cell_sums all-parts\|^walk\|^raster\|^probe" > gpurun_out/tl/cs_os1.txt
+BEV_AMD_LIB=$L/libbev_cstl.so timeout -k 10 300 python3 scripts/cell_sums_timeline.py HDL_64E 2>&1 | grep -v "^cell_sums barrier0\|^cell_sums all-parts\|^walk\|^raster\|^probe" > gpurun_out/tl/cs_hdl.txt
+head -8 gpurun_out/tl/os1_pipelined.txt gpurun_out/tl/os1_serial.txt; grep -c . gpurun_out/tl/*.txt
