@@ -2072,16 +2072,24 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
             if (nn[j] == 0) break; /* wave-uniform */
             const uint32_t c = cell[j];
             const bool valid = c != 0xfffu;
-            unsigned long long peers = __ballot(valid);
+            const unsigned long long vb = __ballot(valid);
+            /* the lanes that DIFFER from this one in some bit of the cell number: per bit one signed bit-field extract
+             * (0 / -1), one compare (the ballot) and, per half of the wave, ONE v_bitop3_b32 (gfx950): d |= ballot ^ mine.
+             * 4 vector instructions per bit (rounds 3-4: selects between the ballot and its complement, 10 per bit as
+             * compiled — two thirds of the kernel's vector instructions, and the kernel is short of issue slots, not of
+             * latency hiding: 11.4 k vector instructions per wave x 4 waves per SIMD x 4 cycles = its 76 us lifetime) */
+            uint32_t dl = 0u, dh = 0u;
 #pragma unroll
             for (int bit = 0; bit < 10; ++bit) {
-                const bool one = (c >> bit) & 1u;
-                const unsigned long long bal = __ballot(one);
-                peers &= one ? bal : ~bal;
+                const int m = __builtin_amdgcn_sbfe((int)c, (uint32_t)bit, 1u);
+                const unsigned long long bal = __ballot(m != 0);
+                dl = __builtin_amdgcn_bitop3_b32(dl, (uint32_t)bal, (uint32_t)m, 0xF6); /* a | (b ^ c) */
+                dh = __builtin_amdgcn_bitop3_b32(dh, (uint32_t)(bal >> 32), (uint32_t)m, 0xF6);
             }
-            const unsigned long long lower = peers & ((1ull << lane) - 1ull);
-            const uint32_t size = (uint32_t)__popcll(peers), rank = (uint32_t)__popcll(lower);
-            const bool leader = valid && lower == 0ull;
+            const uint32_t pl = (uint32_t)vb & ~dl, ph = (uint32_t)(vb >> 32) & ~dh; /* this lane's group */
+            const uint32_t size = (uint32_t)__popc(pl) + (uint32_t)__popc(ph);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(ph, __builtin_amdgcn_mbcnt_lo(pl, 0u)); /* members in lower lanes */
+            const bool leader = valid && rank == 0u;
             if (leader) {
                 atomicAdd(&myhist[c >> 1], size << (16 * (c & 1u)));
                 atomicOr(&tbits[c >> 5], 1u << (c & 31u));
