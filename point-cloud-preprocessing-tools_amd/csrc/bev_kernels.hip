@@ -1906,7 +1906,7 @@ struct SumDims {
     static constexpr int start_words = (cells + 3) / 4 * 4; /* (padded: the height buffer behind it is read 16 bytes at a time) */
     static constexpr size_t fixed_words = (size_t)kSumWaves * hist_stride + start_words + (size_t)kPartSlices * 64 + 2 * (size_t)cells + touch_words +
                                           (cells + 1) / 2 + 16;
-    static constexpr size_t seg_words(int T) { return (size_t)(T + 1) + (size_t)(T + 3) / 4; }
+    static constexpr size_t seg_words(int T) { return (size_t)(T + 4) + (size_t)(T + 3) / 4; } /* cpre: T + 1 entries and three of UINT32_MAX behind them */
     static constexpr size_t lds_bytes(int T) { return sizeof(uint32_t) * (fixed_words + seg_words(T)); } /* HDL_64E (459 segments): 39.5 KB */
 };
 static_assert(kPartSlices * 64 <= 4096, "a part's run start (12 bits) and length (13 bits) share a word with room to spare");
@@ -1928,7 +1928,7 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
     uint32_t *misc = reinterpret_cast<uint32_t *>(tlist) + (kCellsQ + 1) / 2; /* [0..1] list lengths (by part parity), [4..7] wave sums, [8] carry */
     const int T = g.segs;
     uint32_t *cpre = misc + 16;                            /* [T + 1]: this quarter's candidates before segment t */
-    uint8_t *rs8 = reinterpret_cast<uint8_t *>(cpre + T + 1); /* [T]: where its run starts inside segment t */
+    uint8_t *rs8 = reinterpret_cast<uint8_t *>(cpre + T + 4); /* [T]: where its run starts inside segment t */
     uint16_t *hist16 = reinterpret_cast<uint16_t *>(hist); /* the same counters, cell c of wave w at [w * 2 * kHistStride + c] */
 
     int f, quarter;
@@ -1985,6 +1985,7 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
             base += cq[k];
         }
         if (tid == kSumThreads - 1 && 4 * kSumThreads <= T) cpre[T] = base; /* (T == 1024 exactly) */
+        if (tid < 3) cpre[T + 1 + tid] = 0xffffffffu; /* (request() looks three segment starts ahead without asking) */
         lds_barrier();
         if (tid == 0) misc[4] = misc[5] = misc[6] = misc[7] = 0u;
     }
@@ -2024,11 +2025,23 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
             if (on) {
                 const int t0 = __builtin_amdgcn_readlane(lo, j), t1 = __builtin_amdgcn_readlane(lo, j + 1);
                 const uint32_t i = 64u * (uint32_t)(g0 + j) + (uint32_t)lane; /* this lane's candidate (past the end in the last slice) */
-                int t = t0;
-                for (int u = t0 + 1; u <= t1; ++u) t += cpre[u] <= i ? 1 : 0; /* (wave-uniform trip count, broadcast reads) */
+                /* the lane's segment: t0 plus the segment starts up to its candidate.  A slice spans two or three
+                 * segments: the next three starts are looked at without asking how many there are — a segment past t1
+                 * starts after the NEXT slice's first candidate, so past every candidate of this one; more than three
+                 * (rare): the loop.  (Rounds 3-4 looped over t0 + 1 ..
+                 * t1: a scalar loop per slot with a dependent LDS round trip per turn, 55-60 instructions for a typical
+                 * slot; this kernel is short of issue slots.) */
+                const uint32_t c1 = cpre[t0 + 1], c2 = cpre[t0 + 2], c3 = cpre[t0 + 3]; /* (t0 < T; UINT32_MAX behind cpre[T]) */
+                int t = t0 + (c1 <= i ? 1 : 0) + (c2 <= i ? 1 : 0) + (c3 <= i ? 1 : 0);
+                if (t1 - t0 > 3) { /* (wave-uniform) */
+#pragma unroll 1
+                    for (int u = t0 + 4; u <= t1; ++u) t += cpre[u] <= i ? 1 : 0;
+                }
+                t = t < T ? t : T - 1; /* (lanes past the stream's end) */
                 /* lanes past the stream's end read the last run's stale tail (allocated memory) and are masked where
                  * the values are used */
-                const uint2 kz = ccand[(size_t)t * kSeg + rs8[t] + (i - cpre[t])];
+                const uint32_t at = (uint32_t)t * (uint32_t)kSeg + rs8[t] + (i - cpre[t]);
+                const uint2 kz = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(ccand) + 8u * at);
                 key_n[j] = kz.x;
                 z_n[j] = __uint_as_float(kz.y);
             }
@@ -2062,11 +2075,14 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
         /* hist.  Lanes of a 64-slice that hold the same cell find each other with one ballot per key bit (10 bits cover
          * the quarter's 938 cells; 0xfff is not a cell): constant work however many distinct cells the slice has, and
          * nothing but vector / scalar ALU (rounds 1-2 took six ballots, fetched the group leader's cell through the LDS
-         * pipe to verify and took the other bits only on a mismatch: a round trip per slice on the critical path).  Every
-         * lane keeps its rank inside its group, the group's size and whether it leads the group in the spare bits of its
-         * cell register (cell | rank << 12 | size << 18 | leader << 25), so the placement below needs no second look.
-         * Only leaders touch the histogram (64 LDS atomics on one address would serialise) and mark their cell touched —
-         * without waiting for an answer: the list of touched cells is made from the marks after the barrier. */
+         * pipe to verify and took the other bits only on a mismatch: a round trip per slice on the critical path; round 5
+         * tried a table of lane masks by cell in LDS — OR the lane bit in, read the group back —: 256 entries per wave is
+         * what fits, the benchmark's slices hold 64 cells from all over the grid, nearly every slice shared an entry
+         * and fell back on the ballots: 0.47 us per frame against 0.385).  Every lane keeps its rank inside its group,
+         * the group's size and whether it leads the group in the spare bits of its cell register (cell | rank << 12 |
+         * size << 18 | leader << 25), so the placement below needs no second look.  Only leaders touch the histogram (64
+         * LDS atomics on one address would serialise) and mark their cell touched — without waiting for an answer: the
+         * list of touched cells is made from the marks after the barrier. */
 #pragma unroll
         for (int j = 0; j < kSlots; ++j) {
             if (nn[j] == 0) break; /* wave-uniform */
@@ -2075,13 +2091,15 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
             const unsigned long long vb = __ballot(valid);
             /* the lanes that DIFFER from this one in some bit of the cell number: per bit one signed bit-field extract
              * (0 / -1), one compare (the ballot) and, per half of the wave, ONE v_bitop3_b32 (gfx950): d |= ballot ^ mine.
-             * 4 vector instructions per bit (rounds 3-4: selects between the ballot and its complement, 10 per bit as
-             * compiled — two thirds of the kernel's vector instructions, and the kernel is short of issue slots, not of
-             * latency hiding: 11.4 k vector instructions per wave x 4 waves per SIMD x 4 cycles = its 76 us lifetime) */
+             * 5 vector instructions per bit as compiled (rounds 3-4: selects between the ballot and its complement, 10
+             * per bit — two thirds of the kernel's vector instructions, and the kernel is short of VECTOR issue slots,
+             * not of latency hiding: 11.4 k vector instructions per wave x 4 waves per SIMD x 4 cycles = its 76 us
+             * lifetime; SQ_INSTS_VALU 183 k -> 145 k per frame, 0.44 -> 0.385 us) */
             uint32_t dl = 0u, dh = 0u;
 #pragma unroll
             for (int bit = 0; bit < 10; ++bit) {
-                const int m = __builtin_amdgcn_sbfe((int)c, (uint32_t)bit, 1u);
+                int m = __builtin_amdgcn_sbfe((int)c, (uint32_t)bit, 1u);
+                asm volatile("" : "+v"(m)); /* (the ballot compares THIS register: left alone the compiler shifts the bit to the sign again for it) */
                 const unsigned long long bal = __ballot(m != 0);
                 dl = __builtin_amdgcn_bitop3_b32(dl, (uint32_t)bal, (uint32_t)m, 0xF6); /* a | (b ^ c) */
                 dh = __builtin_amdgcn_bitop3_b32(dh, (uint32_t)(bal >> 32), (uint32_t)m, 0xF6);
