@@ -89,6 +89,21 @@ def test_host_buffer_call_through_the_two_stage_pipeline(ctxs):
     _check_batch(p, ctx, frames)
 
 
+def test_every_turn_of_the_cell_quarters(ctxs):
+    """k_cell_sums hands the four cell quarters of a frame to its four workgroups in an order that turns from frame to
+    frame of the launch ((f >> 3) mod 4: a quarter that runs long must not always land on the same CUs).  56 frames through a
+    max_batch = 128 context are one host-buffer chunk cut into two launches of 28: every turn is taken.  Firing-order frames:
+    their quarters differ most."""
+    p, ctx = ctxs("OS1_64", 128)
+    frames = [synth.firing_order(p, 300 + f) if f % 3 else synth.sweep(p, 300 + f, keep=0.9, n_dup=500) for f in range(56)]
+    ordered, multi, single, gm = ctx.process_batch(frames, want_ground_mat=True)
+    for i, pts in enumerate(frames):  # (labels and rasters hang on the averages; the debug hook shows the last launch's alone)
+        o_ord, o_gm, o_multi, o_single, _ = _oracle(p, pts)
+        assert ordered[i].tobytes() == o_ord.tobytes(), f"frame {i}: ordered cloud / labels differ"
+        assert np.array_equal(gm[i], o_gm), i
+        assert np.array_equal(multi[i], o_multi) and np.array_equal(single[i], o_single), i
+
+
 def test_degenerate_clouds(ctxs):
     p, ctx = ctxs("HDL_32E")
     base = synth.sweep(p, 5)
