@@ -1940,7 +1940,9 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
      * with three quarters of the chip idle.  Rotated, every CU holds a mix and the second round starts as the short ones
      * end: 0.43 -> 0.35 us per OS1 frame, config 3 +8 %. */
     static_assert((kSumQ & (kSumQ - 1)) == 0, "the rotation below");
+#ifndef BEV_EXP_NO_QROT /* (developer build `make cstl0`: the launch as it was, for scripts/cell_sums_timeline.py) */
     quarter = (quarter + (f >> 3)) & (kSumQ - 1);
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint2 *ccand = b.cand + (size_t)f * T * kSeg; /* key | height */
     const uint32_t *fn = b.ncand + (size_t)f * T;
