@@ -32,7 +32,10 @@ constexpr int kResolveThreads = BEV_RESOLVE_THREADS;
 constexpr int kResolveParts = 4;  /* code lists per frame written by k_ground_resolve (a contiguous quarter of the segments each) */
 /* workgroups per frame in k_ground_resolve, kResolveParts / kResolveWgs consecutive parts each: a workgroup's tables
  * (3,750 averages, their neighbour minima, edge bins, band table) cost as much as a part's candidates */
-constexpr int kResolveWgs = 1;
+#ifndef BEV_RESOLVE_WGS
+#define BEV_RESOLVE_WGS 1
+#endif
+constexpr int kResolveWgs = BEV_RESOLVE_WGS;
 static_assert(kResolveParts % kResolveWgs == 0, "whole parts per workgroup");
 #ifndef BEV_RASTER_THREADS
 #define BEV_RASTER_THREADS 512 /* (overridable for `make exp`: bev_kernels.hip is the only user) */
