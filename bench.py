@@ -151,7 +151,11 @@ def main() -> int:
         elif args.workload == "os1_firing_real":
             # what mulran_point_cloud_select writes for real sweeps (MulranPointCloudSelect.cpp:112-130): 3 % no-return
             # records (column 0 of their row), start azimuth and direction drawn per frame, staggered laser columns
-            host[i] = synth.firing_real(p, first + i, noret=0.03)
+            # (developer knobs for traffic diagnosis: BEV_FR_NORET / BEV_FR_STAGGER / BEV_FR_PHASE / BEV_FR_DIR override the draw)
+            host[i] = synth.firing_real(p, first + i, noret=float(os.environ.get("BEV_FR_NORET", "0.03")),
+                                        stagger=float(os.environ.get("BEV_FR_STAGGER", "1.0")),
+                                        phase=int(os.environ["BEV_FR_PHASE"]) if "BEV_FR_PHASE" in os.environ else None,
+                                        direction=int(os.environ["BEV_FR_DIR"]) if "BEV_FR_DIR" in os.environ else None)
             counts[i] = S
         elif args.workload == "mixed":
             # the layouts of the reference's producers alternating in groups of 32 frames (the CLI's batch): sorted sweeps
