@@ -2556,42 +2556,47 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
     const uint32_t over = over_l;
     PH();
 
-    /* this band's lists as ONE index space, so that every load of the workgroup is requested at once */
+    /* this band's lists as ONE index space, so that every load of the workgroup is requested at once.  Which list an index
+     * falls in is settled per WAVE: its 64 consecutive indices start in one list (a cursor that only moves forward: the wave's
+     * indices ascend from load to load) and cross a list end once in a while (then, and only then, the lanes compare).  Round
+     * 4 compared every index with every list end — 15 compare-select pairs per code, four fifths of the kernel's vector
+     * instructions. */
     if (!over) {
         constexpr int kU = 8;
         const uint32_t total = list_end[E];
         const uint32_t *fmain = b.code_main + (size_t)f * E * bands * g.code_stride;
-        uint32_t ends[16]; /* ends[j] = first index of list j (j >= 1) */
-#pragma unroll
-        for (int j = 0; j < 16; ++j) ends[j] = __builtin_amdgcn_readfirstlane(j <= E ? list_end[j] : 0u);
+        const uint32_t wave0 = (uint32_t)(tid & ~63), lane = (uint32_t)(tid & 63);
+        int ue = 0; /* (wave-uniform) the list that holds the wave's first index of the current load, [ulo, uhi) */
+        uint32_t ulo = 0u, uhi = __builtin_amdgcn_readfirstlane(list_end[1]);
         for (uint32_t i0 = 0; i0 < total; i0 += kU * kRasterThreads) {
             uint32_t c[kU];
 #pragma unroll
             for (int k = 0; k < kU; ++k) {
-                const uint32_t i = i0 + (uint32_t)k * kRasterThreads + tid;
+                const uint32_t iw = i0 + (uint32_t)k * kRasterThreads + wave0; /* (wave-uniform) */
                 c[k] = kSkip;
-                if (i < total) {
-                    int e = 0;
-                    uint32_t e0 = 0u;
-                    if (E <= 16) { /* the list ends are wave-uniform: scalar compares, no dependent LDS reads */
-#pragma unroll
-                        for (int j = 1; j < 16; ++j) {
-                            const bool past = j < E && i >= ends[j];
-                            e += past ? 1 : 0;
-                            e0 = past ? ends[j] : e0;
-                        }
-                    } else {
-                        int lo = 0, hi = E - 1; /* first e with list_end[e + 1] > i */
-                        while (lo < hi) {
-                            const int mid = (lo + hi) >> 1;
-                            if (list_end[mid + 1] > i) hi = mid; else lo = mid + 1;
-                        }
-                        e = lo;
-                        e0 = list_end[e];
-                    }
-                    c[k] = fmain[((size_t)e * bands + band) * g.code_stride + (i - e0)];
+                if (iw >= total) continue;
+                while (iw >= uhi && ue + 1 < E) { /* (also past empty lists) */
+                    ++ue;
+                    ulo = uhi;
+                    uhi = __builtin_amdgcn_readfirstlane(list_end[ue + 1]);
                 }
+                const uint32_t i = iw + lane;
+                int e = ue;
+                uint32_t e0 = ulo;
+                {   /* list ends inside the wave's 64 indices */
+                    int ee = ue;
+                    uint32_t nx = uhi;
+                    while (ee + 1 < E && nx <= iw + 63u) {
+                        ++ee;
+                        const bool past = i >= nx;
+                        e = past ? ee : e;
+                        e0 = past ? nx : e0;
+                        nx = __builtin_amdgcn_readfirstlane(list_end[ee + 1]);
+                    }
+                }
+                if (i < total) c[k] = fmain[((size_t)e * bands + band) * g.code_stride + (i - e0)];
             }
+            /* (the next turn's loads in flight while these codes are entered: measured, no faster) */
 #pragma unroll
             for (int k = 0; k < kU; ++k)
                 if (c[k] != kSkip) splat_code(c[k], x0, M, mask, hmax);
