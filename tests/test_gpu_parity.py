@@ -104,6 +104,34 @@ def test_every_turn_of_the_cell_quarters(ctxs):
         assert np.array_equal(multi[i], o_multi) and np.array_equal(single[i], o_single), i
 
 
+def test_zero_heights_in_the_origins_cell(ctxs):
+    """Records without a return (x = y = z = 0) are ground candidates of the cell that holds the origin; k_cell_sums counts
+    the cell's zero heights instead of sorting and adding them (s + 0 = s: the running sum is never -0).  Frames where that
+    cell also holds -0.0 heights, heights that cancel to zero and ordinary ones, in every order the slots give, must leave
+    the same averages — bit for bit, the sign of a zero included — labels and rasters as the oracle's chain."""
+    p, ctx = ctxs("OS1_64", 16)
+    rng = np.random.default_rng(77)
+    frames = []
+    for k in range(6):
+        f = synth.firing_order(p, 400 + k).copy()
+        n = len(f)
+        # a share of the records dropped (all-zero), another share moved INTO the origin's cell (x in [-1, 1), y in [0, 2))
+        # with heights from a small pool: +-0, values that cancel, an ordinary one
+        drop = rng.random(n) < (0.0, 0.02, 0.2, 0.5, 0.2, 0.2)[k]
+        f[drop] = np.zeros(1, f.dtype)[0]
+        f["row"][drop] = (np.arange(n) % p.n_scan)[drop]                      # (firing order: beam = position mod N)
+        f["col"][drop] = np.minimum(np.arange(n) // p.n_scan, p.horizon_scan - 1)[drop]
+        near = rng.random(n) < (0.0, 0.01, 0.05, 0.05, 0.3, 0.05)[k]
+        f["x"][near] = rng.uniform(-0.9, 0.9, near.sum()).astype(np.float32)
+        f["y"][near] = rng.uniform(0.1, 1.9, near.sum()).astype(np.float32)
+        pool = np.array([0.0, -0.0, 1.5, -1.5, 0.25, -0.25, 3e-39, -1.7], np.float32) if k != 4 else np.array([-0.0, 0.0], np.float32)
+        f["z"][near] = pool[rng.integers(0, len(pool), near.sum())]
+        if k == 5:
+            f["z"][drop] = np.float32(-0.0)                                      # dropped records with a NEGATIVE zero height
+        frames.append(f)
+    _check_batch(p, ctx, frames)
+
+
 def test_degenerate_clouds(ctxs):
     p, ctx = ctxs("HDL_32E")
     base = synth.sweep(p, 5)
