@@ -130,8 +130,15 @@ int bev_process_batch(bev_ctx_t *ctx, int n_frames,
  * d_multi      : n_frames * bev_multi_bytes.
  * d_single     : n_frames * bev_single_bytes.
  * d_ground_mat : NULL or n_frames * S int8.
- * Asynchronous on the context's stream; call bev_synchronize() (or
- * hipDeviceSynchronize) before reading results. */
+ * Asynchronous: call bev_synchronize() before reading results.  The stages of a
+ * sub-batch ride in consecutive launches beside the stages of its neighbours
+ * (see bev_set_lanes); the last stages of a call's last sub-batches are
+ * launched by the NEXT call to this function — calls that follow each other
+ * without a synchronisation keep the device busy across the call boundary —
+ * or by bev_synchronize() (and by every other entry point of the context).
+ * A bare hipDeviceSynchronize() is therefore NOT enough: bev_synchronize()
+ * launches what is pending, then waits.  The buffers of a call must stay
+ * valid until then. */
 int bev_process_device_resident(bev_ctx_t *ctx, int n_frames,
                                 const bev_point_t *d_pts,
                                 const uint64_t *h_offsets,
@@ -209,10 +216,16 @@ int bev_project_xyzi(bev_ctx_t *ctx, int kind, const float *xyzi, uint32_t n, be
 size_t bev_project_out_points(int kind, uint32_t n); /* 0 for an unknown kind */
 
 /* ---- measurement ------------------------------------------------------- */
-/* Sub-batches of bev_process_device_resident run as a two-stage pipeline over BEV_LANES (default 2, max 4)
- * workspace sets, so that the streaming kernels of sub-batch k + 1 overlap the per-frame kernels of sub-batch k
- * (env BEV_STAGED=0: each lane runs whole sub-batches instead).  bev_set_lanes(ctx, 1) makes everything run back
- * to back (clean per-kernel durations for profiling); returns the number of lanes now in use, or a negative status. */
+/* Sub-batches (max_batch frames) run as FUSED launches: one launch holds the column walk of sub-batch t and, as further
+ * workgroups of the same grid, phase B of sub-batch t - 1, phase C of t - 2 and the rasters of t - 3, over four
+ * workspace sets; every kernel has one workgroup shape (256 threads, a quarter of a CU's LDS and registers).
+ * bev_set_lanes(ctx, 1) makes every kernel a launch of its own, back to back (clean per-kernel durations for
+ * profiling; the same device code); bev_set_lanes(ctx, n > 1) switches back.  Returns the number of workspace sets now
+ * in rotation (1 or 4), or a negative status.  Environment of bev_create: BEV_LANES=1 starts serial; BEV_STREAM=0
+ * sends every frame through the general path (order scan + gather walk); BEV_MODE_TTL=n: sub-batches for which a
+ * layout's walk stays launched after the workspace set last saw the layout (default 8); BEV_CODE_CAP=n: entries of a
+ * raster-band code list (tests); BEV_STAGE_LEAD=n: group slots by which a fused launch's walk workgroups precede its
+ * other stages' (default 12; placement only).  These are all the knobs the library reads. */
 int bev_set_lanes(bev_ctx_t *ctx, int n);
 
 #define BEV_MAX_KERNELS 16

@@ -35,18 +35,12 @@ struct ProfSlot {
     int frames;
 };
 
-/* Sub-batches are dealt round-robin to a few "lanes": each lane has its own
- * stream and its own sub-batch workspace, so the latency-bound per-frame
- * cell-sum kernel of one sub-batch overlaps the bandwidth-bound kernels of the
- * next.  Lane 0 doubles as the workspace of the single-cloud entry points. */
+/* A sub-batch's workspace lives from its column walk to its rasters: four launches (k_stage, see run_pipeline), so
+ * four workspace sets ("lanes", the name rounds 2-5 gave them when each also had a stream) go round.  Lane 0 doubles as
+ * the workspace of the single-cloud entry points. */
 constexpr int kMaxLanes = 4;
 struct Lane {
-    hipStream_t st = nullptr;
-    hipEvent_t done = nullptr;
-    hipEvent_t front_done = nullptr, back_done = nullptr; /* staged mode: workspace hand-over between the two stages */
     FrameInfo *info = nullptr;  /* per frame: how its points reach their slots (k_probe / k_verdict) */
-    uint32_t *hint = nullptr;   /* mapped host words (k_verdict): [0] frames of the set's last sub-batch that were NOT read in place, [1] the modes k_probe gave its frames (bit = mode) */
-    int mode_absent[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* looks at hint[1] since it last showed the mode (see run_pipeline) */
     uint32_t *est = nullptr;    /* stream frames: estimated input position of every (row, strip)'s first slot */
     uint32_t *tail_list = nullptr, *tail_cnt = nullptr; /* ... and their tail points per (row, strip) (stream mode only) */
     int32_t *cm_par = nullptr;   /* firing-order frames: direction and row bases (k_probe) */
@@ -134,17 +128,27 @@ struct bev_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;
 
-    /* per-lane sub-batch workspace; the aliases below are lane 0's */
+    /* sub-batch workspace sets; the aliases below are lane 0's */
     Lane lanes[kMaxLanes];
-    int n_lanes = 1;
-    int n_lanes_active = 1; /* <= n_lanes; bev_set_lanes */
-    bool staged = true;     /* two-stage pipeline, see run_pipeline; BEV_STAGED=0 falls back to free-running lanes */
-    int back_chunk = 1 << 30;  /* frames per launch of the back-stage kernels (BEV_BACK_CHUNK: experiment knob; default: the whole sub-batch) */
-    int mode_ttl = 8;          /* a mode's in-place walk stays launched for this many sub-batches of a workspace set after the set last saw the mode (BEV_MODE_TTL) */
+    int n_lanes = kMaxLanes;
+    int next_lane = 0;
+    /* fused: a sub-batch's stages ride in consecutive k_stage launches beside the stages of its neighbours (run_pipeline);
+     * serial (BEV_LANES=1, bev_set_lanes(ctx, 1)): every kernel a launch of its own, back to back — per-kernel durations */
+    bool fused = true;
+    int stage_lead = 12;       /* BEV_STAGE_LEAD: group slots by which a launch's walk workgroups precede its other stages' */
+    uint32_t *hint = nullptr;  /* mapped host words (k_verdict): [0] frames of the last verdict's sub-batch that were NOT read in place, [1] the modes k_probe gave its frames (bit = mode) */
+    int mode_absent[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* looks at hint[1] since it last showed the mode (see run_pipeline) */
+    int mode_ttl = 8;          /* a mode's in-place walk stays launched for this many sub-batches after a verdict last showed the mode (BEV_MODE_TTL) */
     bool allow_stream = true;  /* sorted-prefix frames are read in place (k_probe); BEV_STREAM=0 turns it off, see bev_create */
-    hipEvent_t fork_ev = nullptr;
-    hipEvent_t stagger_ev = nullptr; /* recorded on a lane after its bandwidth-bound kernels */
-    bool staggered[kMaxLanes] = {false, false, false, false};
+    /* sub-batches whose later stages have not been launched yet, oldest first (see run_pipeline / flush_pending) */
+    struct Pending {
+        BatchPtrs b;
+        int nf;
+        bool want_multi, want_single;
+        int8_t *gm_out; /* final ground_mat wanted (device), or nullptr */
+        int next;       /* 1 phase B, 2 phase C, 3 rasters */
+    };
+    std::deque<Pending> pending;
     uint32_t *winner = nullptr;
     uint32_t *codes = nullptr;
     size_t codes_elems = 0;
@@ -285,8 +289,9 @@ void fill_geometry(const bev_params_t *p, Geometry *g)
     {   /* raster bands: M / u rows each, the middle quarter of the image cut four times finer (bev_exact.h) */
         const int M = mat_size_of(p), u = raster_bands_for(M);
         const int coarse = u ? M / u : M;
-        const int fine = coarse % BEV_RASTER_FINE_DIV == 0 ? coarse / BEV_RASTER_FINE_DIV : coarse;
+        int fine = coarse % kRasterFineDiv == 0 ? coarse / kRasterFineDiv : coarse;
         const int z0 = (3 * u / 8) * coarse, z1 = M - z0;
+        if (2 * (z0 / coarse) + (z1 - z0) / fine > kMaxBands) fine = coarse; /* (large images: uniform bands) */
         g->rp.coarse = coarse;
         g->rp.fine = fine;
         g->rp.z0 = z0;
@@ -386,18 +391,84 @@ int ensure_gm(bev_ctx *c)
     return BEV_OK;
 }
 
-/* The whole pipeline on device pointers.  `identity`: d_pts already holds
- * ordered clouds (n_frames * S points) and the order stage is skipped.       */
+/* ---- the stages of earlier sub-batches that have not been launched yet ------------------------------------------- */
+/* Fills the later-stage parts of a fused launch from the pending sub-batches: each is advanced by ONE stage.  With every
+ * launch advancing every pending sub-batch there is at most one per stage. */
+void take_pending(bev_ctx *c, StageArgs *a)
+{
+    a->sums = StagePart{};
+    a->resolve = StagePart{};
+    a->raster = StagePart{};
+    a->want_multi = a->want_single = 0;
+    for (const bev_ctx::Pending &p : c->pending) {
+        StagePart &part = p.next == 1 ? a->sums : (p.next == 2 ? a->resolve : a->raster);
+        part.b = p.b;
+        part.nf = p.nf;
+        if (p.next == 3) {
+            a->want_multi = p.want_multi ? 1 : 0;
+            a->want_single = p.want_single ? 1 : 0;
+            if (!p.want_multi && !p.want_single) part.nf = 0;
+        }
+    }
+}
+/* ... after that launch: the optional final ground_mat of the sub-batch whose averages are now final (a plain launch:
+ * rarely asked for), sub-batches through their rasters leave the queue */
+int advance_pending(bev_ctx *c)
+{
+    for (bev_ctx::Pending &p : c->pending) {
+        if (p.next == 1 && p.gm_out) {
+            ProfScope ps(c, K_GROUND_MAT, p.nf);
+            launch_ground_mat(c->geo, p.b, p.gm_out, p.nf, c->stream);
+        }
+        ++p.next;
+    }
+    while (!c->pending.empty() && c->pending.front().next > 3) c->pending.pop_front();
+    HIPCK(c, hipGetLastError());
+    return BEV_OK;
+}
+/* launches what is left of every pending sub-batch: up to three launches without a walk */
+int flush_pending(bev_ctx *c)
+{
+    while (!c->pending.empty()) {
+        StageArgs a{};
+        a.g = c->geo;
+        a.lead = 0;
+        take_pending(c, &a);
+        {
+            ProfScope ps(c, K_STAGE, 0);
+            launch_stage(a, -1, c->stream);
+        }
+        int rc = advance_pending(c);
+        if (rc != BEV_OK) return rc;
+    }
+    return BEV_OK;
+}
+
+/* The whole pipeline on device pointers, everything on the context's stream.  `identity`: d_pts already holds ordered
+ * clouds (n_frames * S points) and the order stage is skipped.
+ *
+ * Fused (the default): per sub-batch t ONE launch of k_stage holds its column walk and, as further workgroups of the
+ * same grid, phase B of sub-batch t - 1, phase C of t - 2 and the rasters of t - 3 (bev_kernels.hip).  The stages of a
+ * sub-batch that have not been launched when the call returns stay PENDING: the next call's launches carry them, or
+ * bev_synchronize() (and every other entry point) launches them — calls that follow each other without a
+ * synchronisation keep the pipeline full across the call boundary.  `flush`: launch them before returning.
+ * Serial (bev_set_lanes(ctx, 1)): every kernel a launch of its own, back to back. */
 int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint64_t *h_offsets, bool identity,
-                 bev_point_t *d_ordered, uint8_t *d_multi, uint8_t *d_single, int8_t *d_gm, bool fork = true,
+                 bev_point_t *d_ordered, uint8_t *d_multi, uint8_t *d_single, int8_t *d_gm, bool flush = true,
                  int sub_frames = 0 /* frames per sub-batch; 0: max_batch */)
 {
     if (n_frames == 0) return BEV_OK;
     const Geometry &g = c->geo;
     const size_t S = (size_t)g.S;
+    hipStream_t st = c->stream;
     HIPCK(c, hipSetDevice(c->device));
     if (d_gm) {
         int rc = ensure_gm(c);
+        if (rc != BEV_OK) return rc;
+    }
+    const bool fused = c->fused && !identity;
+    if (!fused) { /* (the serial launches use the same workspace sets) */
+        int rc = flush_pending(c);
         if (rc != BEV_OK) return rc;
     }
 
@@ -415,38 +486,15 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             c->h_desc[ds][f].n_pts = (uint32_t)(b - a);
             c->h_desc[ds][f]._pad = 0;
         }
-        HIPCK(c, hipMemcpyAsync(c->d_desc[ds], c->h_desc[ds], (size_t)n_frames * sizeof(FrameDesc),
-                                hipMemcpyHostToDevice, c->copy_stream));
-        HIPCK(c, hipEventRecord(c->desc_copied[ds], c->copy_stream));
-        HIPCK(c, hipStreamWaitEvent(c->stream, c->desc_copied[ds], 0));
+        HIPCK(c, hipMemcpyAsync(c->d_desc[ds], c->h_desc[ds], (size_t)n_frames * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
     }
 
-    /* fork: every lane starts after whatever the caller already queued on the main stream (the staged
-     * host->device copies of the host-buffer entry points).  The device-resident entry point has nothing
-     * on the main stream to wait for, so its lanes free-run from call to call and stay staggered. */
     const int sub_size = sub_frames > 0 ? std::min(sub_frames, c->max_batch) : c->max_batch;
-    const int n_sub = (n_frames + sub_size - 1) / sub_size;
-    const int lanes_used = std::min(c->n_lanes_active, n_sub);
-    if (fork) {
-        HIPCK(c, hipEventRecord(c->fork_ev, c->stream));
-        for (int l = 0; l < lanes_used; ++l) HIPCK(c, hipStreamWaitEvent(c->lanes[l].st, c->fork_ev, 0));
-    } else if (!identity) {
-        for (int l = 0; l < lanes_used; ++l) HIPCK(c, hipStreamWaitEvent(c->lanes[l].st, c->desc_copied[ds], 0));
-    }
-
-    int sub = 0;
-    for (int f0 = 0; f0 < n_frames; f0 += sub_size, ++sub) {
+    for (int f0 = 0; f0 < n_frames; f0 += sub_size) {
         const int nb = std::min(sub_size, n_frames - f0);
-        Lane &ln = c->lanes[sub % lanes_used];
-        /* staged mode: lanes are only workspace sets; the bandwidth-bound front (order scan + column walk) of
-         * every sub-batch runs on one stream, the latency-bound back (cell sums, resolve, rasters) on another,
-         * higher-priority one, so that exactly one of each kind is in flight */
-        const bool staged = c->staged && lanes_used >= 2 && !identity;
-        hipStream_t st = staged ? c->lanes[1].st : ln.st;
-        /* The workspace set's previous tenant has left.  Recorded by EVERY sub-batch on the stream that ran its back
-         * stage (staged or not, identity or not) and waited on by every front: a call that runs wholly on one lane may
-         * be followed, without a synchronisation, by a staged call whose front uses the same set from another stream. */
-        HIPCK(c, hipStreamWaitEvent(st, ln.back_done, 0));
+        /* the set's previous tenant is through its rasters: they rode in a launch three before this one at the latest */
+        Lane &ln = c->lanes[c->next_lane];
+        c->next_lane = (c->next_lane + 1) % c->n_lanes;
         BatchPtrs b{};
         b.pts = identity ? d_pts + (size_t)f0 * S : d_pts;
         b.frames = identity ? nullptr : c->d_desc[ds] + f0;
@@ -469,12 +517,36 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         b.multi = d_multi ? d_multi + (size_t)f0 * c->multi_bytes : nullptr;
         b.single = d_single ? d_single + (size_t)f0 * c->single_bytes : nullptr;
 
+        /* the walk of `source` over the frames of `mode`: the sub-batch's FIRST walk launch carries the pending stages of
+         * the sub-batches before it (fused), every other one is a plain launch */
+        bool carried = !fused;
+        auto walk = [&](int kid, int source, uint32_t mode) -> int {
+            if (!carried) {
+                carried = true;
+                StageArgs a{};
+                a.g = g;
+                a.walk.b = b;
+                a.walk.nf = nb;
+                a.want_mode = mode;
+                a.lead = c->stage_lead;
+                take_pending(c, &a);
+                {
+                    ProfScope ps(c, K_STAGE, nb, st);
+                    launch_stage(a, source, st);
+                }
+                return advance_pending(c);
+            }
+            ProfScope ps(c, kid, nb, st);
+            launch_gather_ground(g, b, nb, source, mode, st);
+            return BEV_OK;
+        };
+
         if (identity) {
             RoctxRange rr("bev:front (identity walk)");
-            ProfScope ps(c, K_GATHER_GROUND, nb, st);
-            launch_gather_ground(g, b, nb, 1, kFrameGeneral, st);
+            int rc = walk(K_GATHER_GROUND, 1, kFrameGeneral);
+            if (rc != BEV_OK) return rc;
         } else {
-            RoctxRange rr("bev:front (probe, order scan, column walk)");
+            RoctxRange rr("bev:front (probe, column walk beside the later stages of earlier sub-batches, verdict, order scan)");
             uint32_t max_pts = 0;
             int n_exact_s = 0; /* frames that can be structured clouds */
             for (int f = 0; f < nb; ++f) {
@@ -494,120 +566,77 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                 launch_probe(g, b, nb, c->allow_stream, st);
             }
             /* The walks of the modes that read in place.  A mode's walk is launched unless the last mode_ttl looks at the
-             * word k_verdict leaves in mapped host memory (the modes k_probe gave the frames of this workspace set's last
-             * finished sub-batch; read without waiting; all ones while nothing is known) did not show the mode: an empty
+             * word k_verdict leaves in mapped host memory (the modes k_probe gave the frames of the last sub-batch whose
+             * verdict has run; read without waiting; all ones while nothing is known) did not show the mode: an empty
              * launch costs 5-8 us of a 1 ms sub-batch, a frame whose walk was NOT launched fails k_verdict's count and is
              * redone the general way — the hint decides speed, not results.  Sticky since round 5 (round 4 followed the
              * last word alone: a directory that alternates layouts, or batches that cross a layout change, had every
              * frame of such a sub-batch redone; BEV_MODE_TTL=1 is that rule). */
             uint32_t seen = 0u;
-            if (c->allow_stream && ln.hint) {
-                const uint32_t word = reinterpret_cast<volatile uint32_t *>(ln.hint)[1];
+            if (c->allow_stream && c->hint) {
+                const uint32_t word = reinterpret_cast<volatile uint32_t *>(c->hint)[1];
                 for (int m = 0; m < 8; ++m) {
-                    ln.mode_absent[m] = (word >> m) & 1u ? 0 : std::min(ln.mode_absent[m] + 1, 1 << 20);
-                    if (ln.mode_absent[m] < c->mode_ttl) seen |= 1u << m;
+                    c->mode_absent[m] = (word >> m) & 1u ? 0 : std::min(c->mode_absent[m] + 1, 1 << 20);
+                    if (c->mode_absent[m] < c->mode_ttl) seen |= 1u << m;
                 }
             }
-            if (c->allow_stream && ln.tail_list && (seen & (1u << kFrameStream))) { /* frames k_probe found sorted up to a tail: read in place, verified */
-                ProfScope ps(c, K_GATHER_GROUND, nb, st);
-                launch_gather_ground(g, b, nb, 2, kFrameStream, st);
-            }
-            if (c->allow_stream && n_exact_s > 0 && (seen & (1u << kFrameStructured))) { /* structured clouds (only a frame of exactly S records can be one) */
-                ProfScope ps(c, K_WALK_STRUCTURED, nb, st);
-                launch_gather_ground(g, b, nb, 3, kFrameStructured, st);
-            }
-            if (c->allow_stream && n_exact_s > 0 && (seen & (1u << kFrameColMajor))) { /* ... or S returns in firing order */
-                ProfScope ps(c, K_WALK_COLMAJOR, nb, st);
-                launch_gather_ground(g, b, nb, 4, kFrameColMajor, st);
-            }
-            if (c->allow_stream && n_exact_s > 0 && ln.cm_par && (seen & (1u << kFrameColMajorGen))) { /* ... from any start azimuth, in either direction, with staggered beams and no-return records */
-                ProfScope ps(c, K_WALK_COLMAJOR_GEN, nb, st);
-                launch_gather_ground(g, b, nb, 5, kFrameColMajorGen, st);
-            }
+            int rc = BEV_OK;
+            if (c->allow_stream && ln.tail_list && (seen & (1u << kFrameStream))) /* frames k_probe found sorted up to a tail: read in place, verified */
+                rc = walk(K_GATHER_GROUND, 2, kFrameStream);
+            if (rc == BEV_OK && c->allow_stream && n_exact_s > 0 && (seen & (1u << kFrameStructured))) /* structured clouds (only a frame of exactly S records can be one) */
+                rc = walk(K_WALK_STRUCTURED, 3, kFrameStructured);
+            if (rc == BEV_OK && c->allow_stream && n_exact_s > 0 && (seen & (1u << kFrameColMajor))) /* ... or S returns in firing order */
+                rc = walk(K_WALK_COLMAJOR, 4, kFrameColMajor);
+            if (rc == BEV_OK && c->allow_stream && n_exact_s > 0 && ln.cm_par && (seen & (1u << kFrameColMajorGen))) /* ... from any start azimuth, in either direction, with staggered beams and no-return records */
+                rc = walk(K_WALK_COLMAJOR_GEN, 5, kFrameColMajorGen);
+            if (rc != BEV_OK) return rc;
             if (c->allow_stream) {
                 ProfScope ps(c, K_VERDICT, nb, st);
-                launch_verdict(g, b, nb, ln.hint, st);
+                launch_verdict(g, b, nb, c->hint, st);
             }
             {   /* every other frame — general, or read in place and failed (normally none of a sorted sub-batch).  Thin
-                 * launch while this workspace set's earlier sub-batches were read in place entirely (a hint that k_verdict
+                 * launch while the sub-batch of the last verdict was read in place entirely (a hint that k_verdict
                  * leaves in mapped host memory — UINT32_MAX until the set's first verdict: wide —, read without waiting:
                  * it only chooses the launch shape) */
-                const bool thin = c->allow_stream && ln.hint && *reinterpret_cast<volatile uint32_t *>(ln.hint) == 0u;
+                const bool thin = c->allow_stream && c->hint && *reinterpret_cast<volatile uint32_t *>(c->hint) == 0u;
                 ProfScope ps(c, K_ORDER_SCAN, nb, st);
                 launch_order_scan(g, b, nb, max_pts, thin, st);
             }
+            rc = walk(K_WALK_GENERAL, 0, kFrameGeneral);
+            if (rc != BEV_OK) return rc;
+        }
+        if (fused) {
+            c->pending.push_back(bev_ctx::Pending{b, nb, d_multi != nullptr, d_single != nullptr, d_gm ? d_gm + (size_t)f0 * S : nullptr, 1});
+        } else {
+            RoctxRange rb("bev:back (cell sums, resolve, rasters)");
             {
-                ProfScope ps(c, K_WALK_GENERAL, nb, st);
-                launch_gather_ground(g, b, nb, 0, kFrameGeneral, st);
-            }
-        }
-        /* One-time stagger: a lane's FIRST sub-batch starts only after the previous lane has issued its
-         * bandwidth-bound kernels (order scan + column walk), so that from then on one lane's latency-bound
-         * per-frame kernels run beside the other lane's streaming kernels instead of in lock-step. */
-        if (staged) {
-            HIPCK(c, hipEventRecord(ln.front_done, st));
-            st = c->lanes[0].st;
-            HIPCK(c, hipStreamWaitEvent(st, ln.front_done, 0));
-        }
-        if (lanes_used > 1 && !fork && !staged) {
-            const int li = sub % lanes_used;
-            HIPCK(c, hipEventRecord(c->stagger_ev, st));
-            const int nxt = (li + 1) % lanes_used;
-            if (nxt != li && !c->staggered[nxt]) {
-                HIPCK(c, hipStreamWaitEvent(c->lanes[nxt].st, c->stagger_ev, 0));
-                c->staggered[nxt] = true;
-            }
-        }
-        RoctxRange rb("bev:back (cell sums, resolve, rasters)");
-        /* (BEV_BACK_CHUNK cuts the back stage into pieces of that many frames: measured with 512-frame sub-batches and
-         * pieces of 256 — one k_cell_sums workgroup per CU and piece — the serialised pieces cost more than the second
-         * round of workgroups they avoid: 270 k against 287 k frames/s) */
-        for (int c0 = 0; c0 < nb; c0 += c->back_chunk) {
-            const int cn = std::min(c->back_chunk, nb - c0);
-            BatchPtrs bc = b;
-            bc.cand = b.cand + (size_t)c0 * g.segs * kSeg;
-            bc.ncand = b.ncand + (size_t)c0 * g.segs;
-            bc.avg = b.avg + (size_t)c0 * bevx::kGridCells;
-            bc.code_main = b.code_main + (size_t)c0 * g.emitters * g.raster_bands * g.code_stride;
-            bc.ncode = b.ncode + (size_t)c0 * g.emitters * g.raster_bands;
-            bc.ordered = b.ordered + (size_t)c0 * S;
-            bc.gm = b.gm ? b.gm + (size_t)c0 * S : nullptr;
-            bc.multi = b.multi ? b.multi + (size_t)c0 * c->multi_bytes : nullptr;
-            bc.single = b.single ? b.single + (size_t)c0 * c->single_bytes : nullptr;
-            {
-                ProfScope ps(c, K_CELL_SUMS, cn, st);
-                launch_cell_sums(g, bc, cn, st);
+                ProfScope ps(c, K_CELL_SUMS, nb, st);
+                launch_cell_sums(g, b, nb, st);
             }
             if (d_gm) {
-                ProfScope ps(c, K_GROUND_MAT, cn, st);
-                launch_ground_mat(g, bc, d_gm + (size_t)(f0 + c0) * S, cn, st);
+                ProfScope ps(c, K_GROUND_MAT, nb, st);
+                launch_ground_mat(g, b, d_gm + (size_t)f0 * S, nb, st);
             }
             {   /* phase C for the candidates: labels, codes of the un-grounded ones */
-                ProfScope ps(c, K_GROUND_RESOLVE, cn, st);
-                launch_ground_resolve(g, bc, cn, st);
+                ProfScope ps(c, K_GROUND_RESOLVE, nb, st);
+                launch_ground_resolve(g, b, nb, st);
             }
             if (d_multi || d_single) {
-                ProfScope ps(c, K_BEV_RASTER, cn, st);
-                launch_bev_raster(g, bc, d_multi != nullptr, d_single != nullptr, cn, st);
+                ProfScope ps(c, K_BEV_RASTER, nb, st);
+                launch_bev_raster(g, b, d_multi != nullptr, d_single != nullptr, nb, st);
             }
         }
-        HIPCK(c, hipEventRecord(ln.back_done, st));
         c->last_sub_frames = nb;
         c->last_avg = ln.avg;
         c->last_ncode = ln.ncode;
         c->last_info = identity ? nullptr : ln.info;
         HIPCK(c, hipGetLastError());
     }
-    /* join: the main stream continues after every lane */
-    for (int l = 0; l < lanes_used; ++l) {
-        HIPCK(c, hipEventRecord(c->lanes[l].done, c->lanes[l].st));
-        HIPCK(c, hipStreamWaitEvent(c->stream, c->lanes[l].done, 0));
-    }
     if (!identity) {
-        HIPCK(c, hipEventRecord(c->desc_done[ds], c->stream));
+        HIPCK(c, hipEventRecord(c->desc_done[ds], st));
         c->desc_used[ds] = true;
     }
-    return BEV_OK;
+    return flush ? flush_pending(c) : BEV_OK;
 }
 
 int ensure_staging(bev_ctx *c)
@@ -733,44 +762,25 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
     const size_t S = (size_t)c->geo.S, nb = (size_t)max_batch;
     c->codes_elems = std::max(std::max(max_points, S), (size_t)1024 * 1024); /* dense codes of one cloud, or the float BEV grid */
     {
+        /* BEV_LANES=1: serial launches from the start (what bev_set_lanes(ctx, 1) switches to) */
         const char *e = getenv("BEV_LANES");
-        int nl = e ? atoi(e) : 2;
-        c->n_lanes = std::max(1, std::min(kMaxLanes, nl));
-        c->n_lanes_active = c->n_lanes;
+        c->fused = !(e && atoi(e) == 1);
+        if (const char *ld = getenv("BEV_STAGE_LEAD")) c->stage_lead = std::max(0, atoi(ld));
         /* Frames whose points are in slot order up to a tail (a sweep written row by row with dropped returns ABSENT — none
          * of the reference's three selectors writes exactly that: KITTI's structured clouds and MulRan's firing order have
          * routes of their own, kFrameStructured / kFrameColMajor, Oxford's file order goes the general way) are read in place: no order
          * scan, no winner table, 5.6 MB less HBM traffic per HDL_64E frame.  k_probe decides per frame, the walk
          * verifies every point it consumes, a frame that fails is redone the general way: results never depend on the
-         * mode.  Since round 3 (LDS-DMA windows, four workgroups per CU) ahead of the general path on every box measured
-         * (+3 ... +7 % frames/s, same-box A/B); BEV_STREAM=0 forces the general path for every frame. */
+         * mode.  BEV_STREAM=0 forces the general path for every frame. */
         const char *sm = getenv("BEV_STREAM");
         c->allow_stream = !(sm && atoi(sm) == 0);
-        if (const char *bk = getenv("BEV_BACK_CHUNK")) c->back_chunk = std::max(1, atoi(bk));
         if (const char *mt = getenv("BEV_MODE_TTL")) c->mode_ttl = std::max(1, atoi(mt));
-        const char *sg = getenv("BEV_STAGED");
-        c->staged = (!sg || atoi(sg) != 0) && c->n_lanes >= 2;
     }
-    CK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
-    CK(hipEventCreateWithFlags(&c->stagger_ev, hipEventDisableTiming));
-    c->staggered[0] = true;
-    /* Streams of equal priority may be multiplexed onto ONE hardware queue (observed:
-     * two such lanes never overlapped); streams of different priority get different
-     * queues, so each lane takes its own priority level where the device has enough. */
-    int prio_least = 0, prio_greatest = 0;
-    CK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    CK(hipHostMalloc((void **)&c->hint, 2 * sizeof(uint32_t), hipHostMallocMapped));
+    c->hint[0] = 0xffffffffu; /* nothing known yet: the first order scan is launched wide, */
+    c->hint[1] = 0xffffffffu; /* ... every walk is launched */
     for (int l = 0; l < c->n_lanes; ++l) {
         Lane &ln = c->lanes[l];
-        int prio = prio_greatest + l;
-        if (prio > prio_least) prio = prio_least;
-        if (getenv("BEV_PRIO_SWAP") && atoi(getenv("BEV_PRIO_SWAP")) != 0) prio = l == 0 ? prio_least : prio_greatest; /* experiment: the back stage below the front */
-        CK(hipStreamCreateWithPriority(&ln.st, hipStreamNonBlocking, prio));
-        CK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
-        CK(hipEventCreateWithFlags(&ln.front_done, hipEventDisableTiming));
-        CK(hipEventCreateWithFlags(&ln.back_done, hipEventDisableTiming));
-        CK(hipHostMalloc((void **)&ln.hint, 2 * sizeof(uint32_t), hipHostMallocMapped));
-        ln.hint[0] = 0xffffffffu; /* nothing known yet: the set's first order scan is launched wide, */
-        ln.hint[1] = 0xffffffffu; /* ... every walk is launched */
         CK(hipMalloc((void **)&ln.info, nb * sizeof(FrameInfo)));
         CK(hipMemset(ln.info, 0, nb * sizeof(FrameInfo)));
         CK(hipMalloc((void **)&ln.est, nb * (size_t)c->geo.N * c->geo.strips * sizeof(uint32_t)));
@@ -819,22 +829,16 @@ void bev_destroy(bev_ctx_t *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    c->pending.clear(); /* (stages never launched: their outputs were never waited for) */
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (int l = 0; l < kMaxLanes; ++l) {
         Lane &ln = c->lanes[l];
-        if (ln.st) (void)hipStreamSynchronize(ln.st);
         void *ws[] = {ln.info, ln.est, ln.tail_list, ln.tail_cnt, ln.cm_par, ln.cm_sync, ln.winner, ln.cand, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
         for (void *p : ws)
             if (p) (void)hipFree(p);
-        if (ln.hint) (void)hipHostFree(ln.hint);
-        if (ln.done) (void)hipEventDestroy(ln.done);
-        if (ln.front_done) (void)hipEventDestroy(ln.front_done);
-        if (ln.back_done) (void)hipEventDestroy(ln.back_done);
-        if (ln.st) (void)hipStreamDestroy(ln.st);
     }
-    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
-    if (c->stagger_ev) (void)hipEventDestroy(c->stagger_ev);
+    if (c->hint) (void)hipHostFree(c->hint);
     if (c->downloader) {
         c->downloader->close();
         delete c->downloader;
@@ -864,6 +868,9 @@ void bev_destroy(bev_ctx_t *c)
 int bev_synchronize(bev_ctx_t *c)
 {
     if (!c) return BEV_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->device));
+    int rc = flush_pending(c); /* the later stages of the last sub-batches */
+    if (rc != BEV_OK) return rc;
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BEV_OK;
 }
@@ -874,7 +881,7 @@ int bev_process_device_resident(bev_ctx_t *c, int n_frames, const bev_point_t *d
     if (!c || n_frames < 0 || !h_offsets || !d_ordered) return BEV_ERR_INVALID_ARG;
     if (n_frames > 0 && !d_pts && h_offsets[n_frames] != h_offsets[0]) return BEV_ERR_INVALID_ARG;
     return run_pipeline(c, n_frames, d_pts, h_offsets, false, d_ordered, d_multi, d_single, d_ground_mat,
-                        /*fork=*/false);
+                        /*flush=*/false);
 }
 
 int bev_process_batch(bev_ctx_t *c, int n_frames, const bev_point_t *const *pts, const uint32_t *n_pts,
@@ -888,6 +895,10 @@ int bev_process_batch(bev_ctx_t *c, int n_frames, const bev_point_t *const *pts,
     }
     if (n_frames == 0) return BEV_OK;
     HIPCK(c, hipSetDevice(c->device));
+    { /* the later stages of sub-batches still in flight use the workspace this call is about to use */
+        const int rc_ = flush_pending(c);
+        if (rc_ != BEV_OK) return rc_;
+    }
     int rc = ensure_staging(c);
     if (rc != BEV_OK) return rc;
     const size_t S = (size_t)c->geo.S;
@@ -927,7 +938,7 @@ int bev_process_batch(bev_ctx_t *c, int n_frames, const bev_point_t *const *pts,
         rc = run_pipeline(c, nb, c->st_in, off.data(), false, c->st_ordered + base * S,
                           multi_out ? c->st_multi + base * c->multi_bytes : nullptr,
                           single_out ? c->st_single + base * c->single_bytes : nullptr, any_gm ? c->st_gm + base * S : nullptr,
-                          /*fork=*/true, /*sub_frames: two sub-batches, so that the two-stage pipeline engages*/ nb >= 8 ? (nb + 1) / 2 : 0);
+                          /*flush=*/true, /*sub_frames: two sub-batches, so that a chunk's stages overlap*/ nb >= 8 ? (nb + 1) / 2 : 0);
         if (rc != BEV_OK) break;
         e = hipEventRecord(c->out_ready[half], c->stream);
         if (e != hipSuccess) {
@@ -967,6 +978,10 @@ int bev_order_cloud(bev_ctx_t *c, const bev_point_t *pts, uint32_t n_pts, bev_po
     if (!c || !ordered_out || (n_pts && !pts)) return BEV_ERR_INVALID_ARG;
     if (n_pts > c->max_points) return BEV_ERR_TOO_LARGE;
     HIPCK(c, hipSetDevice(c->device));
+    { /* the later stages of sub-batches still in flight use the workspace this call is about to use */
+        const int rc_ = flush_pending(c);
+        if (rc_ != BEV_OK) return rc_;
+    }
     int rc = ensure_staging(c);
     if (rc != BEV_OK) return rc;
     const Geometry &g = c->geo;
@@ -1005,6 +1020,10 @@ int bev_mark_ground(bev_ctx_t *c, bev_point_t *ordered, int8_t *ground_mat_out)
 {
     if (!c || !ordered) return BEV_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->device));
+    { /* the later stages of sub-batches still in flight use the workspace this call is about to use */
+        const int rc_ = flush_pending(c);
+        if (rc_ != BEV_OK) return rc_;
+    }
     int rc = ensure_staging(c);
     if (rc != BEV_OK) return rc;
     const size_t S = (size_t)c->geo.S;
@@ -1023,6 +1042,10 @@ static int raster_cloud(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, uint
     if (!c || (n && !cloud)) return BEV_ERR_INVALID_ARG;
     if ((size_t)n > std::max(c->max_points, (size_t)c->geo.S)) return BEV_ERR_TOO_LARGE;
     HIPCK(c, hipSetDevice(c->device));
+    { /* the later stages of sub-batches still in flight use the workspace this call is about to use */
+        const int rc_ = flush_pending(c);
+        if (rc_ != BEV_OK) return rc_;
+    }
     int rc = ensure_staging(c);
     if (rc != BEV_OK) return rc;
     if (n) HIPCK(c, hipMemcpyAsync(c->st_in, cloud, (size_t)n * sizeof(bev_point_t), hipMemcpyHostToDevice, c->stream));
@@ -1105,6 +1128,10 @@ int bev_project_xyzi(bev_ctx_t *c, int kind, const float *xyzi, uint32_t n, bev_
     if ((size_t)n > std::max(c->max_points, (size_t)c->geo.S)) return BEV_ERR_TOO_LARGE;
     if (n_out == 0) return BEV_OK;
     HIPCK(c, hipSetDevice(c->device));
+    { /* the later stages of sub-batches still in flight use the workspace this call is about to use */
+        const int rc_ = flush_pending(c);
+        if (rc_ != BEV_OK) return rc_;
+    }
     int rc = ensure_staging(c);
     if (rc != BEV_OK) return rc;
     /* raw floats are staged in the ordered-cloud staging buffer (16 B per point fit its 32 B per slot) */
@@ -1149,6 +1176,10 @@ int bev_float_bev(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, float inte
     if ((size_t)n > std::max(c->max_points, (size_t)c->geo.S)) return BEV_ERR_TOO_LARGE;
     if (M * M > c->codes_elems) return BEV_ERR_UNSUPPORTED; /* the grid borrows the single-cloud code buffer */
     HIPCK(c, hipSetDevice(c->device));
+    { /* the later stages of sub-batches still in flight use the workspace this call is about to use */
+        const int rc_ = flush_pending(c);
+        if (rc_ != BEV_OK) return rc_;
+    }
     int rc = ensure_staging(c);
     if (rc != BEV_OK) return rc;
     float *grid = reinterpret_cast<float *>(c->codes);
@@ -1170,6 +1201,10 @@ int bev_transform_cloud(bev_ctx_t *c, const bev_point_t *cloud, uint32_t n, cons
     if ((size_t)n > std::max(c->max_points, (size_t)c->geo.S)) return BEV_ERR_TOO_LARGE;
     if (n == 0) return BEV_OK;
     HIPCK(c, hipSetDevice(c->device));
+    { /* the later stages of sub-batches still in flight use the workspace this call is about to use */
+        const int rc_ = flush_pending(c);
+        if (rc_ != BEV_OK) return rc_;
+    }
     int rc = ensure_staging(c);
     if (rc != BEV_OK) return rc;
     /* in place in the input staging (every thread reads and writes its own point) */
@@ -1201,11 +1236,10 @@ void bev_yaw_translate_matrix(float tx, float ty, float tz, float yaw_deg, float
 int bev_set_lanes(bev_ctx_t *c, int n)
 {
     if (!c || n < 1) return BEV_ERR_INVALID_ARG;
-    HIPCK(c, hipSetDevice(c->device));
-    for (int l = 0; l < c->n_lanes; ++l) HIPCK(c, hipStreamSynchronize(c->lanes[l].st));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    c->n_lanes_active = std::min(n, c->n_lanes);
-    return c->n_lanes_active;
+    int rc = bev_synchronize(c);
+    if (rc != BEV_OK) return rc;
+    c->fused = n > 1;
+    return c->fused ? c->n_lanes : 1;
 }
 
 int bev_profile_enable(bev_ctx_t *c, int on)
@@ -1254,6 +1288,10 @@ int bev_debug_get_cell_avg(bev_ctx_t *c, int first_frame, int n_frames, float *o
     if (!c || !out || first_frame < 0 || n_frames < 0 || first_frame + n_frames > c->last_sub_frames)
         return BEV_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->device));
+    { /* the later stages of sub-batches still in flight use the workspace this call is about to use */
+        const int rc_ = flush_pending(c);
+        if (rc_ != BEV_OK) return rc_;
+    }
     HIPCK(c, hipStreamSynchronize(c->stream));
     if (!c->last_avg) return BEV_ERR_INVALID_ARG;
     HIPCK(c, hipMemcpy(out, c->last_avg + (size_t)first_frame * bevx::kGridCells,
@@ -1266,6 +1304,10 @@ int bev_debug_get_frame_info(bev_ctx_t *c, int first_frame, int n_frames, uint32
     if (!c || !out || first_frame < 0 || n_frames < 0 || first_frame + n_frames > c->last_sub_frames || !c->last_info)
         return BEV_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->device));
+    { /* the later stages of sub-batches still in flight use the workspace this call is about to use */
+        const int rc_ = flush_pending(c);
+        if (rc_ != BEV_OK) return rc_;
+    }
     HIPCK(c, hipStreamSynchronize(c->stream));
     HIPCK(c, hipMemcpy(out, c->last_info + first_frame, (size_t)n_frames * sizeof(FrameInfo), hipMemcpyDeviceToHost));
     return BEV_OK;
@@ -1276,6 +1318,10 @@ int bev_debug_get_code_overflow(bev_ctx_t *c, int first_frame, int n_frames, uin
     if (!c || !out || first_frame < 0 || n_frames < 0 || first_frame + n_frames > c->last_sub_frames || !c->last_ncode)
         return BEV_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->device));
+    { /* the later stages of sub-batches still in flight use the workspace this call is about to use */
+        const int rc_ = flush_pending(c);
+        if (rc_ != BEV_OK) return rc_;
+    }
     HIPCK(c, hipStreamSynchronize(c->stream));
     const size_t per = (size_t)c->geo.emitters * c->geo.raster_bands;
     std::vector<uint32_t> counts((size_t)n_frames * per);

@@ -55,12 +55,12 @@ struct SumDims {
 static_assert(kPartSlices * 64 <= 4096, "a part's run start (12 bits) and length (13 bits) share a word with room to spare");
 size_t cell_sums_lds_bytes() { return SumDims::lds_bytes(kMaxSegs); }
 
-__global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geometry g, int nf)
+/* quarter `quarter` (position in the frame's launch slots; turned below) of frame f; lds: SumDims::lds_bytes(g.segs) bytes */
+__device__ __forceinline__ void cell_sums_body(uint32_t *lds, const BatchPtrs &b, const Geometry &g, const int f, int quarter, int bid /* developer builds */)
 {
     TL_BEGIN;
     using D = SumDims;
     constexpr int kCellsQ = D::cells, kHistStride = D::hist_stride, kTouchWords = D::touch_words;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *hist = lds;                                 /* [kSumWaves][kHistStride]: 16-bit counts, cells 2i | 2i+1 << 16 */
     uint32_t *start = hist + kSumWaves * kHistStride;     /* [kCellsQ]: the part's runs, start | length << 16 */
     float *zbuf = reinterpret_cast<float *>(start + D::start_words); /* [kPartSlices * 64]: the part's heights by cell (16-byte aligned) */
@@ -74,8 +74,7 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
     uint8_t *rs8 = reinterpret_cast<uint8_t *>(cpre + T + 4); /* [T]: where its run starts inside segment t */
     uint16_t *hist16 = reinterpret_cast<uint16_t *>(hist); /* the same counters, cell c of wave w at [w * 2 * kHistStride + c] */
 
-    int f, quarter;
-    if (!map_block_xcd(blockIdx.x, nf, kSumQ, f, quarter)) return; /* the quarters of a frame on one XCD: they read the same lines */
+    (void)bid; /* (the quarters of a frame on one XCD: they read the same lines) */
     /* ... in a different order from frame to frame.  Measured (scripts/cell_sums_timeline.py): with quarter = position in
      * the frame, a quarter that runs long in every frame (OS1-64 firing order: quarter 3 holds the cells with the longest
      * runs, 103 us per workgroup where the others take 41) ends up four to a CU on every fourth CU — a launch's workgroups go
@@ -419,25 +418,33 @@ __global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geome
         if (tid == 0) cntv[kOriginIdx] = count_advance(cntv[kOriginIdx], misc[12]);
         lds_barrier();
     }
-    PHA_PRINT("cell_sums barrier0 - scan place sum request histloop looptop", tid == 0 && blockIdx.x == 100);
+    PHA_PRINT("cell_sums barrier0 - scan place sum request histloop looptop", tid == 0 && bid == 100);
     PH();
     float *avg = b.avg + (size_t)f * kCells;
     for (int c = tid; c < kCellsQ; c += kSumThreads)
         if (c * kSumQ + quarter < kCells) avg[c * kSumQ + quarter] = sumv[c] / cntv[c]; /* :210 */
-    PH_PRINT("cell_sums all-parts", tid == 0 && blockIdx.x == 100);
+    PH_PRINT("cell_sums all-parts", tid == 0 && bid == 100);
     TL_END(K_CELL_SUMS);
 #ifdef BEV_CS_TL /* developer build: start / end of every workgroup of this launch in the walk's timeline records */
     if (tid == 0 && f == 12)
         printf("cell_sums frame 12 quarter %d: %d candidates, %d parts; x10 ns: list %lld scan %lld place %lld sum %lld data-wait %lld request %lld hist %lld top %lld\n",
                quarter, GC, P, pha_[0], pha_[2], pha_[3], pha_[4], pha_[1], pha_[5], pha_[6], pha_[7]);
-    if (tid == 0 && blockIdx.x < kWalkTlCap) {
-        long long *rec = g_walk_tl[blockIdx.x];
+    if (tid == 0 && bid < kWalkTlCap) {
+        long long *rec = g_walk_tl[bid];
         rec[0] = ph_clk[0];
         rec[1] = wall_clock64();
         rec[2] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
         rec[3] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) | ((long long)GC << 32) | ((long long)quarter << 8);
     }
 #endif
+}
+
+__global__ __launch_bounds__(kSumThreads, 4) void k_cell_sums(BatchPtrs b, Geometry g, int nf)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+    int f, quarter;
+    if (!map_block_xcd((int)blockIdx.x, nf, kSumQ, f, quarter)) return;
+    cell_sums_body(lds_dyn, b, g, f, quarter, (int)blockIdx.x);
 }
 
 } /* namespace bevk */

@@ -25,30 +25,27 @@ constexpr int kSeg = 256;                       /* capacity of one candidate seg
 constexpr int kMaxSegs = 1024;                  /* (G + 1) * strips must not exceed this (bev_create checks) */
 constexpr int kSumWaves = 4;      /* waves of the per-frame cell-sum workgroup: the size of a column-walk workgroup */
 constexpr int kSumThreads = kSumWaves * 64;
-#ifndef BEV_RESOLVE_THREADS
-#define BEV_RESOLVE_THREADS 512
-#endif
-constexpr int kResolveThreads = BEV_RESOLVE_THREADS;
+/* ONE workgroup shape for every kernel of the hot path — 256 threads, at most a quarter of a CU's LDS (32 of its 128
+ * allocation granules of 1,280 bytes) and of its registers (128 per lane) — so that the stages of different sub-batches can
+ * be workgroups of ONE launch (k_stage) and any of them fits wherever another has retired.  (Rounds 3-5 ran the resolve and
+ * the rasters as 512-thread workgroups, the rasters with 50 KB of LDS: beside the column walk they started only where two
+ * walk workgroups of one CU had retired together.) */
+constexpr int kStageThreads = 256;
+constexpr int kSlotLdsBytes = 32 * 1280;
+constexpr int kResolveThreads = kStageThreads;
 constexpr int kResolveParts = 4;  /* code lists per frame written by k_ground_resolve (a contiguous quarter of the segments each) */
 /* workgroups per frame in k_ground_resolve, kResolveParts / kResolveWgs consecutive parts each: a workgroup's tables
  * (3,750 averages, their neighbour minima, edge bins, band table) cost as much as a part's candidates */
 #ifndef BEV_RESOLVE_WGS
-#define BEV_RESOLVE_WGS 1
+#define BEV_RESOLVE_WGS 2
 #endif
 constexpr int kResolveWgs = BEV_RESOLVE_WGS;
 static_assert(kResolveParts % kResolveWgs == 0, "whole parts per workgroup");
-#ifndef BEV_RASTER_THREADS
-#define BEV_RASTER_THREADS 512 /* (overridable for `make exp`: bev_kernels.hip is the only user) */
-#endif
-constexpr int kRasterThreads = BEV_RASTER_THREADS;
-#ifndef BEV_RASTER_LDS_CAP
-#define BEV_RASTER_LDS_CAP (100 * 1024)
-#endif
-#ifndef BEV_RASTER_FINE_DIV
-#define BEV_RASTER_FINE_DIV 4
-#endif
-constexpr int kRasterSplit = 8;   /* x-bands per frame in the raster kernel at the reference's 224 x 224 (see raster_bands_for) */
-constexpr int kMaxBands = 32;     /* coarse + fine raster bands (see RasterParams) */
+constexpr int kRasterThreads = kStageThreads;
+constexpr int kRasterLdsCap = kSlotLdsBytes; /* a raster band's two planes (+ its list prefix) */
+constexpr int kRasterFineDiv = 2;  /* the middle bands of the image are cut this many times finer (see fill_geometry) */
+constexpr int kRasterSplit = 8;   /* fewest x-bands per frame in the raster kernel (see raster_bands_for) */
+constexpr int kMaxBands = 64;     /* coarse + fine raster bands (see RasterParams) */
 constexpr int kMaxStrips = 280;   /* ceil(65535 / kStripCols) rounded up */
 /* Entries of one (emitter, band) code list.  Measured fill (scripts/list_fill.py: which capacities overflow on the
  * synthetic layouts): HDL_64E sweeps stay under 2,048 codes per list, OS1_64 frames under 3,072 — of the 15,104 slots a
@@ -200,11 +197,31 @@ enum KernelId {
     K_WALK_COLMAJOR,   /* the walk over clouds in firing order: the plain sweep (kFrameColMajor) */
     K_WALK_COLMAJOR_GEN, /* ... any start azimuth, direction, staggered beams, no-return records (kFrameColMajorGen) */
     K_VERDICT,
+    K_STAGE, /* the fused launch: a sub-batch's walk beside the later stages of the sub-batches before it (k_stage) */
     K_COUNT
 };
 const char *kernel_name(int id);
 /* smallest of 4, 8, 16 bands whose LDS planes (2 * (M / bands) * M * 4 B) fit; 0 if none does */
 int raster_bands_for(int mat_size);
+
+/* One fused launch (k_stage): the column walk of one sub-batch and, as further workgroups of the same grid, phase B of the
+ * sub-batch before it, phase C of the one before that and the rasters of the one before that — every dependency between
+ * stages of one sub-batch is the order of launches on one stream; nothing inside a launch waits for anything.  nf == 0: the
+ * stage is absent from this launch. */
+struct StagePart {
+    BatchPtrs b;
+    int nf;
+};
+struct StageArgs {
+    Geometry g;
+    StagePart walk, sums, resolve, raster;
+    uint32_t want_mode;           /* of the walk part (see launch_gather_ground) */
+    int want_multi, want_single;  /* of the raster part */
+    int lead;                     /* group slots (8 frames each) by which the walk's workgroups precede the other stages' in the grid */
+};
+/* source: the walk part's (see launch_gather_ground; ignored when a.walk.nf == 0) */
+void launch_stage(const StageArgs &a, int source, hipStream_t st);
+size_t stage_lds_bytes(const Geometry &g, int source);
 
 /* launchers (bev_kernels.hip) — all asynchronous on `st` */
 /* the frames that are not read in place: general ones and (after k_verdict) those whose verification failed */

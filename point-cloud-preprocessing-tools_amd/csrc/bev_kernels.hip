@@ -22,6 +22,7 @@
  *     slot order, sorted STABLY by cell, and each cell is summed by one lane
  *     sequentially (a tree or atomic float reduction would change low bits).
  */
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -43,9 +44,102 @@ namespace bevk {
 static const char *const kNames[K_COUNT] = {
     "k_order_scan", "k_walk", "k_cell_sums", "k_ground_resolve", "k_bev_raster",
     "k_gather_only", "k_ground_mat", "k_cloud_codes", "k_angle_debug", "k_float_bev", "k_project", "k_transform",
-    "k_probe", "k_walk_general", "k_walk_structured", "k_walk_colmajor", "k_walk_colmajor_gen", "k_verdict",
+    "k_probe", "k_walk_general", "k_walk_structured", "k_walk_colmajor", "k_walk_colmajor_gen", "k_verdict", "k_stage",
 };
 const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] : "?"; }
+
+/* ------------------------------------------------------------------------- */
+/* k_stage: the stages of FOUR consecutive sub-batches as workgroups of one grid.
+ *
+ * Rounds 2-5 ran the front (probe, walk) and the back (cell sums, resolve, rasters) of neighbouring sub-batches on two
+ * streams of different priority.  The time lines of round 5 (profiles/r05_timeline_hdl_pipelined.txt) showed what that buys
+ * and what it cannot: the back stage's kernels were not the walk's shape (512 threads, 50 KB of LDS) and started only
+ * where two walk workgroups of one CU retired together; every hand-over between the streams and every kernel boundary left
+ * the chip to a launch's tail.  Here every stage has the walk's shape (bev_internal.h: kStageThreads, kSlotLdsBytes), a
+ * launch holds
+ *     the walk of sub-batch t  |  phase B of t - 1  |  phase C of t - 2  |  the rasters of t - 3
+ * and a workgroup's number says which it is: group slot i (8 frames, one per XCD: blocks b and b + 8 share an L2) holds
+ * the walk's strips of frame group i and the later stages' workgroups of frame group i - lead, so that a CU holds a mix of
+ * long memory-bound and short latency-bound workgroups at any time, the launch starts with walks alone and ends with the
+ * short workgroups of the later stages (a launch's tail is as long as its last workgroups live).  The stages of ONE
+ * sub-batch meet only through the order of launches on the stream. */
+template <int kSrc, bool kPow2, bool kGm>
+__global__ __launch_bounds__(kStageThreads, (kSrc == kSrcColMajor || kSrc == kSrcColMajorGen) ? 3 : 4) void k_stage(StageArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char stage_arena[];
+    static_assert(kStripThreads == kStageThreads && kSumThreads == kStageThreads && kResolveThreads == kStageThreads && kRasterThreads == kStageThreads, "one workgroup shape");
+    const int bid = (int)blockIdx.x, x = bid & 7, j = bid >> 3;
+    const int strips = a.g.strips;
+    const int per_slot = strips + kSumQ + kResolveWgs + a.g.raster_bands;
+    const int i = j / per_slot;
+    int k = j - i * per_slot;
+    if (k < strips) {
+        const int f = i * 8 + x;
+        if (f < a.walk.nf) walk_body<kSrc, kPow2, kGm>(stage_arena, a.walk.b, a.g, f, k, a.want_mode, bid);
+        return;
+    }
+    const int f = (i - a.lead) * 8 + x;
+    if (i < a.lead) return;
+    k -= strips;
+    if (k < kSumQ) {
+        if (f < a.sums.nf) cell_sums_body(reinterpret_cast<uint32_t *>(stage_arena), a.sums.b, a.g, f, k, bid);
+        return;
+    }
+    k -= kSumQ;
+    if (k < kResolveWgs) {
+        if (f < a.resolve.nf) resolve_body<kPow2>(stage_arena, a.resolve.b, a.g, f, k);
+        return;
+    }
+    k -= kResolveWgs;
+    if (f < a.raster.nf) raster_body(reinterpret_cast<uint32_t *>(stage_arena), a.raster.b, a.g, f, k, a.want_multi, a.want_single);
+}
+
+template <int kSrc>
+static size_t walk_lds_bytes() { return sizeof(WalkLds<kSrc>); }
+size_t stage_lds_bytes(const Geometry &g, int source)
+{
+    size_t w = 0;
+    switch (source) {
+    case kSrcIdentity: w = walk_lds_bytes<kSrcIdentity>(); break;
+    case kSrcInPlace: w = walk_lds_bytes<kSrcInPlace>(); break;
+    case kSrcStructured: w = walk_lds_bytes<kSrcStructured>(); break;
+    case kSrcColMajor: w = walk_lds_bytes<kSrcColMajor>(); break;
+    case kSrcColMajorGen: w = walk_lds_bytes<kSrcColMajorGen>(); break;
+    default: w = walk_lds_bytes<kSrcGather>(); break;
+    }
+    const size_t others = std::max(std::max(SumDims::lds_bytes(g.segs), sizeof(ResolveLds)), raster_lds_bytes(g));
+    return std::max(w, others);
+}
+template <int kSrc>
+static void launch_stage_src(const StageArgs &a, hipStream_t st)
+{
+    const Geometry &g = a.g;
+    const bool pow2 = g.rp.inv_interval != 0.0f && g.rp.inv_height_res != 0.0f; /* every configuration of the reference */
+    const bool gm = a.walk.nf > 0 && a.walk.b.gm != nullptr;
+    const int back = std::max(a.sums.nf, std::max(a.resolve.nf, a.raster.nf));
+    const int lead = back > 0 ? a.lead : 0;
+    const int slots = std::max((a.walk.nf + 7) / 8, back > 0 ? (back + 7) / 8 + lead : 0);
+    if (slots == 0) return;
+    const int per_slot = g.strips + kSumQ + kResolveWgs + g.raster_bands;
+    const dim3 gr((unsigned)(8 * slots * per_slot)), bl(kStageThreads);
+    const size_t lds = stage_lds_bytes(g, kSrc);
+    StageArgs args = a;
+    args.lead = lead;
+    if (pow2 && !gm) hipLaunchKernelGGL((k_stage<kSrc, true, false>), gr, bl, lds, st, args);
+    else if (pow2) hipLaunchKernelGGL((k_stage<kSrc, true, true>), gr, bl, lds, st, args);
+    else if (!gm) hipLaunchKernelGGL((k_stage<kSrc, false, false>), gr, bl, lds, st, args);
+    else hipLaunchKernelGGL((k_stage<kSrc, false, true>), gr, bl, lds, st, args);
+}
+void launch_stage(const StageArgs &a, int source, hipStream_t st)
+{
+    if (a.walk.nf == 0) source = kSrcInPlace; /* (any instantiation will do for a launch without a walk) */
+    if (source == kSrcIdentity) launch_stage_src<kSrcIdentity>(a, st);
+    else if (source == kSrcInPlace) launch_stage_src<kSrcInPlace>(a, st);
+    else if (source == kSrcStructured) launch_stage_src<kSrcStructured>(a, st);
+    else if (source == kSrcColMajor) launch_stage_src<kSrcColMajor>(a, st);
+    else if (source == kSrcColMajorGen) launch_stage_src<kSrcColMajorGen>(a, st);
+    else launch_stage_src<kSrcGather>(a, st);
+}
 
 /* ------------------------------------------------------------------------- */
 /* launchers                                                                  */

@@ -16,15 +16,16 @@ using namespace bevx;
  * words); its input are this band's code lists: one per strip from the walk (slots that are not candidates) and one
  * per part from k_ground_resolve (un-grounded candidates).  Finished planes leave with 16-byte stores, 1 KiB
  * contiguous per wave-instruction. */
+constexpr int kRasterTailWords = kMaxStrips + kResolveParts + 2; /* behind the planes: list_end, over_l */
 int raster_bands_for(int M) /* uniform bands whose two LDS planes fit; the coarse band height is M / this */
 {
-    for (int bands = kRasterSplit; bands <= 16; bands *= 2)
-        if (M % bands == 0 && (size_t)2 * (M / bands) * M * sizeof(uint32_t) <= (size_t)BEV_RASTER_LDS_CAP) return bands;
+    for (int bands = kRasterSplit; bands <= kMaxBands; bands *= 2)
+        if (M % bands == 0 && ((size_t)2 * (M / bands) * M + kRasterTailWords) * sizeof(uint32_t) <= (size_t)kRasterLdsCap) return bands;
     return 0;
 }
-size_t raster_lds_bytes(const Geometry &g)
+size_t raster_lds_bytes(const Geometry &g) /* the band's two planes + the list prefix behind them */
 {
-    return (size_t)2 * g.rp.coarse * g.rp.mat_size * sizeof(uint32_t);
+    return ((size_t)2 * g.rp.coarse * g.rp.mat_size + kRasterTailWords) * sizeof(uint32_t);
 }
 
 /* both 16-bit halves of v shifted left by the halves of sh (v_pk_lshlrev_b16) */
@@ -93,17 +94,13 @@ __device__ __forceinline__ void store_planes(const uint32_t *mask, const uint32_
     }
 }
 
-__global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geometry g, int nf, int want_multi, int want_single)
+/* x-band `band` of frame f; lds: raster_lds_bytes(g) bytes — the band's two planes, then kRasterTailWords words */
+__device__ __forceinline__ void raster_body(uint32_t *lds, const BatchPtrs &b, const Geometry &g, const int f, const int band, int want_multi, int want_single)
 {
     TL_BEGIN;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    __shared__ uint32_t list_end[kMaxStrips + kResolveParts + 1]; /* inclusive prefix of this band's code-list lengths */
-    __shared__ uint32_t over_l;                                    /* a writer had more codes for this band than its list holds */
+    uint32_t *list_end = lds + 2 * g.rp.coarse * g.rp.mat_size;   /* [kMaxStrips + kResolveParts + 1] inclusive prefix of this band's code-list lengths */
+    uint32_t &over_l = list_end[kMaxStrips + kResolveParts + 1];   /* a writer had more codes for this band than its list holds */
     const int M = g.rp.mat_size, L = g.rp.n_layers, bands = g.raster_bands, E = g.emitters;
-    /* the bands of a frame on ONE XCD (blocks b and b+8 share an L2), adjacent launch slots */
-    const int xl = blockIdx.x & 7, jj = blockIdx.x >> 3;
-    const int f = (jj / bands) * 8 + xl, band = jj % bands;
-    if (f >= nf) return;
     const int x0 = raster_band_x0(band, g.rp), band_rows = raster_band_rows(band, g.rp);
     const int cells = band_rows * M;
     uint32_t *mask = lds;
@@ -190,6 +187,16 @@ __global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geom
     PH();
     TL_END(K_BEV_RASTER);
     PH_PRINT(band == 7 ? "raster7 setup codes stores" : "raster1 setup codes stores", tid == 0 && f == 100 && (band == 7 || band == 1));
+}
+
+__global__ __launch_bounds__(kRasterThreads) void k_bev_raster(BatchPtrs b, Geometry g, int nf, int want_multi, int want_single)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+    /* the bands of a frame on ONE XCD (blocks b and b+8 share an L2), adjacent launch slots */
+    const int xl = (int)blockIdx.x & 7, jj = (int)blockIdx.x >> 3;
+    const int f = (jj / g.raster_bands) * 8 + xl, band = jj % g.raster_bands;
+    if (f >= nf) return;
+    raster_body(lds_dyn, b, g, f, band, want_multi, want_single);
 }
 
 /* rasters of ONE arbitrary cloud from a dense code array (bev_multi_bev / bev_single_bev): every band scans all codes */

@@ -23,22 +23,36 @@ using namespace bevx;
 constexpr int kResolveBatch = 4;
 /* (round 3: the raster constants in vector registers and stores through address-space-1 pointers, as in the walk — a
  * quarter of this kernel's vector instructions were v_readlane restores of spilled 8-dword argument tuples) */
+struct ResolveLds {
+    /* Per cell, the LOWEST of its in-range 4-neighbours' averages (see resolve_body) */
+    float minavg[kGridCells];
+    float avg[kGridCells];                               /* the frame's 75 x 50 averages */
+    int edge_x[kGridRows], edge_y[kGridCols];            /* BEV bin of every ground-grid row's / column's lower edge */
+    uint32_t band_cursor[kMaxBands];
+    uint16_t cnt[kMaxSegs / kResolveParts + 8];
+    uint8_t band_tab[512];                               /* x bin -> raster band */
+};
+static_assert(sizeof(ResolveLds) <= 32 * 1280, "a quarter of a CU's LDS");
+
+/* workgroup `wg` (0 .. kResolveWgs - 1) of frame f */
 template <bool kPow2>
-__global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b, Geometry g)
+__device__ __forceinline__ void resolve_body(char *arena, const BatchPtrs &b, const Geometry &g, const int f, const int wg)
 {
     TL_BEGIN;
     /* Per cell, the LOWEST of its in-range 4-neighbours' averages: "any neighbour n with fl(z - avg[n]) >= 0.3f" is
      * "fl(z - min_n avg[n]) >= 0.3f" — fl(z - a) does not increase with a, and the minimum passes over NaN averages exactly
      * as the comparisons do (a difference with a NaN is never >= 0.3f).  One look-up and one subtraction per candidate
      * instead of four of each with their range tests (bev_exact.h above_neighbour_ground, BatchMultiBevGen.cpp:227-241). */
-    __shared__ float minavg[kCells];
-    __shared__ float avg[kCells];                        /* the frame's 75 x 50 averages */
-    __shared__ int edge_x[kGridRows], edge_y[kGridCols]; /* BEV bin of every ground-grid row's / column's lower edge */
-    __shared__ uint32_t band_cursor[kMaxBands];
-    __shared__ uint8_t band_tab[512];                    /* x bin -> raster band */
-    __shared__ uint16_t cnt[kMaxSegs / kResolveParts + 8];
+    ResolveLds &lds_r = *reinterpret_cast<ResolveLds *>(arena);
+    auto &minavg = lds_r.minavg;
+    auto &avg = lds_r.avg;
+    auto &edge_x = lds_r.edge_x;
+    auto &edge_y = lds_r.edge_y;
+    auto &band_cursor = lds_r.band_cursor;
+    auto &band_tab = lds_r.band_tab;
+    auto &cnt = lds_r.cnt;
     constexpr int kPartsPerWg = kResolveParts / kResolveWgs;
-    const int f = blockIdx.x / kResolveWgs, part0 = (blockIdx.x - f * kResolveWgs) * kPartsPerWg;
+    const int part0 = wg * kPartsPerWg;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = g.segs;
     for (int c = tid; c < kCells; c += kResolveThreads) avg[c] = b.avg[(size_t)f * kCells + c];
@@ -152,6 +166,14 @@ __global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b,
     if (tid < bands) b.ncode[((size_t)f * g.emitters + g.strips + part) * bands + tid] = band_cursor[tid];
   }
     TL_END(K_GROUND_RESOLVE);
+}
+
+template <bool kPow2>
+__global__ __launch_bounds__(kResolveThreads) void k_ground_resolve(BatchPtrs b, Geometry g)
+{
+    __shared__ __attribute__((aligned(16))) char arena[sizeof(ResolveLds)];
+    const int f = (int)blockIdx.x / kResolveWgs;
+    resolve_body<kPow2>(arena, b, g, f, (int)blockIdx.x - f * kResolveWgs);
 }
 
 } /* namespace bevk */

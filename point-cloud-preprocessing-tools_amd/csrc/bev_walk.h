@@ -129,8 +129,49 @@ __device__ __forceinline__ uint32_t quarter_scan(bool c, uint32_t q, uint32_t *r
 }
 constexpr int kFlRankShift = 8; /* WalkRow::fl bits 8..13: the lane's rank among its wave's candidates of its quarter */
 
+/* The walk's LDS, one struct per source so that the same bytes can be another kernel body's in a fused launch (k_stage):
+ * every body carves its arrays out of ONE arena; a workgroup runs one body.  Members a source does not use are one element. */
+template <int kSrc>
+struct WalkLds {
+    static constexpr bool kInPlace = kSrc == kSrcInPlace, kCmGen = kSrc == kSrcColMajorGen, kColMajor = kSrc == kSrcColMajor || kCmGen,
+                          kIndexed = kInPlace || kColMajor;
+    static constexpr int kCmBuf = kCmGen ? kColBuf : kPlainBuf; /* bytes of one band buffer */
+    static constexpr int kWaves = kStripThreads / 64;
+    static constexpr int kSlotBytes = kInPlace ? kInPlaceSlot : 8192;
+    static constexpr int kSeenB = kIndexed ? BEV_SEENB : kSeenBits; /* (the in-place source needs the LDS for its windows) */
+    /* the points of rows r, r+1, r+2.  Gather / identity: by thread, low halves in the first 4 KiB, high halves in the
+     * second.  In place: by window position, 32 B each, then the wrap-around positions, then the tail points */
+    /* column-major: two band buffers, then 8 KiB for the write-out's transposition */
+    alignas(16) char ring[kColMajor ? 2 * kCmBuf + 8192 : 3 * kSlotBytes];
+    alignas(16) u32x4 zero16[1];                              /* what an empty slot reads */
+    alignas(16) float4 edge[3][kWaves][4];                    /* rows r, r-1, (r-2): lanes 0, 1, 62, 63 of every wave */
+    /* per-wave candidate counts of the row being written, at [.][kWaves + wave] behind kWaves words that stay zero: the
+     * three words before a wave's own are the counts of the waves before it, whichever wave it is (no selects) */
+    alignas(16) uint32_t wave_cnt[2][2 * kWaves];
+    uint32_t wring[kSrc == kSrcGather ? 3 : 1][kSrc == kSrcGather ? kStripThreads : 1]; /* raw winner words of rows r+2, r+3, r+4 */
+    uint32_t idx[kIndexed ? 2 : 1][kIndexed ? kStripThreads + 1 : 1]; /* column offset -> position + 1 | tail key ([256]: nowhere) */
+    uint32_t tlist[kInPlace ? 3 : 1][kInPlace ? 64 : 1];      /* tail lists of rows r+2, r+3, r+4 */
+    int est_l[2][kInPlace ? kStreamMaxRows : 1];
+    uint32_t band_cursor[kMaxBands];                          /* entries already in this strip's code list of each band */
+    uint32_t seen[1 << kSeenB];                               /* direct-mapped memo of codes this strip has already listed */
+    int edge_x[kGridRows], edge_y[kGridCols];                 /* BEV bin of every ground-grid row's / column's lower edge */
+    /* column-major, general form: the frame's direction and row bases (k_probe), the window of this strip, who counts what */
+    uint32_t cm_nr_l[2];     /* no-return firings + 1 this strip owns, rows 2b, 2b + 1 of the band just arrived (LDS atomicMax) */
+    uint32_t cm_spec_l[2][2]; /* strip 0: [band & 1][row & 1]: the last no-return firing + 1 of the row that another strip owns (0: none) */
+    uint32_t cm_halo0_l[2];  /* [row & 1]: the index entry that the strip with the wrap-around halo found for virtual column H (= column 0) */
+    uint32_t cm_poll_l[2][kCmGen ? 32 : 1];
+    uint16_t cm_base_l[kCmGen ? kCmMaxRows : 2]; /* (LDS is what holds this source at three workgroups per CU: 42 allocation granules of 1,280 bytes and not one more) */
+    uint16_t cm_win0_l[kCmGen ? kCmMaxRows : 2]; /* strip 0: per row, the firing + 1 whose record it put into column 0 (written out at the end) */
+    uint8_t band_tab[512];                                    /* x bin -> raster band */
+    uint8_t tcnt_l[kInPlace ? kStreamMaxRows : 1];
+};
+static_assert(sizeof(WalkLds<kSrcInPlace>) <= 32 * 1280 && sizeof(WalkLds<kSrcGather>) <= 32 * 1280 && sizeof(WalkLds<kSrcStructured>) <= 32 * 1280,
+              "four column-walk workgroups per CU: 32 of the CU's 128 LDS granules (1,280 bytes) each");
+static_assert(sizeof(WalkLds<kSrcColMajorGen>) <= 42 * 1280 && sizeof(WalkLds<kSrcColMajor>) <= 42 * 1280, "three firing-order workgroups per CU");
+
+/* the walk of workgroup `bid` of a launch over nf frames (k_walk: a launch of its own; k_stage: beside the other stages) */
 template <int kSrc, bool kPow2, bool kGm>
-__global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSrcColMajorGen) ? 3 : 4) void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
+__device__ __forceinline__ void walk_body(char *arena, const BatchPtrs &b, const Geometry &g, const int f, int strip, uint32_t want_mode, int bid /* developer builds: which workgroup prints */)
 {
     TL_BEGIN;
     /* kStructured: the identity source over the caller's INPUT (record i = slot i's point or an all-zero record), every
@@ -138,13 +179,13 @@ __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSr
     constexpr bool kStructured = kSrc == kSrcStructured, kIdentity = kSrc == kSrcIdentity || kStructured, kInPlace = kSrc == kSrcInPlace;
     /* kIndexed: the sources whose points reach their columns through an index row (LDS atomicMax), after the step's barrier */
     constexpr bool kCmGen = kSrc == kSrcColMajorGen, kColMajor = kSrc == kSrcColMajor || kCmGen, kIndexed = kInPlace || kColMajor;
-    constexpr int kCmBuf = kCmGen ? kColBuf : kPlainBuf; /* bytes of one band buffer */
+    using Lds = WalkLds<kSrc>;
+    constexpr int kCmBuf = Lds::kCmBuf;
     static_assert(kWinPos == 256 && kStripVirt + 16 <= kWinPos && kTailCap == 64 && kWrapPos == 16, "DMA pieces of the in-place source");
-    int f, strip;
 #ifdef BEV_CS_CLOCK
     const long long tl_t0 = wall_clock64();
 #endif
-    if (!map_block_xcd(blockIdx.x, nf, g.strips, f, strip)) return;
+    (void)bid;
     /* firing order: strip 0 listens to the other strips of its frame (no-return records, see listen_band): it is dispatched
      * LAST of them, and finds them under way (dispatched first it waited a quarter of its life for them to start: the walk
      * 5 % slower) */
@@ -168,27 +209,28 @@ __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSr
     const bool outcol = tid >= 2 && tid < 2 + kStripCols && v < H;   /* owns column v's outputs */
     const int vcol = v >= H ? v - H : v;                             /* wrap; v < 0 keeps the flat rule */
 
-    constexpr int kWaves = kStripThreads / 64;
-    constexpr int kSlotBytes = kInPlace ? kInPlaceSlot : 8192;
-    constexpr int kSeenB = kIndexed ? BEV_SEENB : kSeenBits;       /* (the in-place source needs the LDS for its windows) */
-    /* the points of rows r, r+1, r+2.  Gather / identity: by thread, low halves in the first 4 KiB, high halves in the
-     * second.  In place: by window position, 32 B each, then the wrap-around positions, then the tail points */
-    /* column-major: two band buffers, then 8 KiB for the write-out's transposition */
-    __shared__ __attribute__((aligned(16))) char ring[kColMajor ? 2 * kCmBuf + 8192 : 3 * kSlotBytes];
-    __shared__ uint32_t wring[kSrc == kSrcGather ? 3 : 1][kStripThreads]; /* raw winner words of rows r+2, r+3, r+4 */
-    __shared__ uint32_t idx[kIndexed ? 2 : 1][kIndexed ? kStripThreads + 1 : 1]; /* column offset -> position + 1 | tail key ([256]: nowhere) */
-    __shared__ u32x4 zero16[kInPlace ? 1 : 1];                               /* what an empty slot reads */
-    __shared__ uint32_t tlist[kInPlace ? 3 : 1][kInPlace ? 64 : 1];       /* tail lists of rows r+2, r+3, r+4 */
-    __shared__ int est_l[2][kInPlace ? kStreamMaxRows : 1];
-    __shared__ uint8_t tcnt_l[kInPlace ? kStreamMaxRows : 1];
-    __shared__ float4 edge[3][kWaves][4];                  /* rows r, r-1, (r-2): lanes 0, 1, 62, 63 of every wave */
-    /* per-wave candidate counts of the row being written, at [.][kWaves + wave] behind kWaves words that stay zero: the
-     * three words before a wave's own are the counts of the waves before it, whichever wave it is (no selects) */
-    __shared__ __attribute__((aligned(16))) uint32_t wave_cnt[2][2 * kWaves];
-    __shared__ uint32_t band_cursor[kMaxBands];            /* entries already in this strip's code list of each band */
-    __shared__ uint8_t band_tab[512];                      /* x bin -> raster band */
-    __shared__ uint32_t seen[1 << kSeenB];                 /* direct-mapped memo of codes this strip has already listed */
-    __shared__ int edge_x[kGridRows], edge_y[kGridCols];   /* BEV bin of every ground-grid row's / column's lower edge */
+    constexpr int kWaves = Lds::kWaves, kSlotBytes = Lds::kSlotBytes, kSeenB = Lds::kSeenB;
+    Lds &lds_w = *reinterpret_cast<Lds *>(arena);
+    auto &ring = lds_w.ring;
+    auto &wring = lds_w.wring;
+    auto &idx = lds_w.idx;
+    auto &zero16 = lds_w.zero16;
+    auto &tlist = lds_w.tlist;
+    auto &est_l = lds_w.est_l;
+    auto &tcnt_l = lds_w.tcnt_l;
+    auto &edge = lds_w.edge;
+    auto &wave_cnt = lds_w.wave_cnt;
+    auto &band_cursor = lds_w.band_cursor;
+    auto &band_tab = lds_w.band_tab;
+    auto &seen = lds_w.seen;
+    auto &edge_x = lds_w.edge_x;
+    auto &edge_y = lds_w.edge_y;
+    auto &cm_base_l = lds_w.cm_base_l;
+    auto &cm_nr_l = lds_w.cm_nr_l;
+    auto &cm_spec_l = lds_w.cm_spec_l;
+    auto &cm_halo0_l = lds_w.cm_halo0_l;
+    auto &cm_win0_l = lds_w.cm_win0_l;
+    auto &cm_poll_l = lds_w.cm_poll_l;
     if (tid < kMaxBands) band_cursor[tid] = 0u;
     if (tid < 4 * kWaves) (&wave_cnt[0][0])[tid] = 0u;
     if (tid < 3 * kWaves * 4) (&edge[0][0][0])[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -363,11 +405,6 @@ __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSr
 
     /* ---- column-major ---- */
     /* the frame's direction and row bases (k_probe), the window of this strip, who counts what */
-    __shared__ uint16_t cm_base_l[kCmGen ? kCmMaxRows : 2]; /* (LDS is what holds this source at three workgroups per CU: 53,248 bytes and not one 512-byte granule more) */
-    __shared__ uint32_t cm_nr_l[2];     /* no-return firings + 1 this strip owns, rows 2b, 2b + 1 of the band just arrived (LDS atomicMax) */
-    __shared__ uint32_t cm_spec_l[2][2]; /* strip 0: [band & 1][row & 1]: the last no-return firing + 1 of the row that another strip owns (0: none) */
-    __shared__ uint32_t cm_halo0_l[2];  /* [row & 1]: the index entry that the strip with the wrap-around halo found for virtual column H (= column 0) */
-    __shared__ uint16_t cm_win0_l[kCmGen ? kCmMaxRows : 2]; /* strip 0: per row, the firing + 1 whose record it put into column 0 (written out at the end) */
     const bool cm_fwd = kCmGen ? b.cm_par[(size_t)f * kCmParWords] > 0 : true;
     const int cm_bmax = kCmGen ? b.cm_par[(size_t)f * kCmParWords + 1] : 0;
     if constexpr (kCmGen) {
@@ -493,7 +530,6 @@ __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSr
      * their LDS; strip 0 asks three steps before it uses the band, without waiting (the words come by LDS-DMA and are
      * looked at after the next step's memory wait): once it trails the others by that much it never stalls.  Only when
      * a report is still missing then does it wait for it (bounded), a step before the band is used. */
-    __shared__ uint32_t cm_poll_l[2][kCmGen ? 32 : 1];
     auto ask_band = [&](int band) { /* (wave 3) */
         if (band * kBandRows >= N) return; /* (uniform) */
         const int words = __builtin_amdgcn_readfirstlane(cm_words_v);
@@ -706,7 +742,7 @@ __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSr
     WalkRow pr[3] = {};
     PHA_DECL;
 #ifdef BEV_CS_CLOCK
-    if (lane == 0 && blockIdx.x == 100) printf("walk_prologue %lld (x10 ns)\n", pha_t - tl_t0);
+    if (lane == 0 && bid == 100) printf("walk_prologue %lld (x10 ns)\n", pha_t - tl_t0);
 #endif
     float zref = __uint_as_float(0x7fc00000u); /* height of the column's last candidate taken for ground (NaN: none yet) */
 
@@ -1081,15 +1117,15 @@ __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSr
     }
     wait_vm<0>(); /* no LDS-DMA may outlive the workgroup's LDS */
     PHA_PRINT(kInPlace ? "walk_inplace vmwait index barrier acquire writeout issue status rest" : "walk_gather vmwait - barrier acquire writeout issue status rest",
-              lane == 0 && blockIdx.x == 100);
+              lane == 0 && bid == 100);
     PHA_PRINT("walk_cm_strip0 vmwait index barrier acquire writeout issue status rest", kColMajor && lane == 0 && strip == 0 && f == 12);
 #ifdef BEV_CS_CLOCK
     if (kColMajor && lane == 0 && wv == 3 && strip == 0 && f == 12) printf("walk_cm_listen try_t %lld block_t %lld fails %d (x10 ns)\n", dbg_try_t, dbg_block_t, dbg_fail_n);
 #endif
     PHA_PRINT("walk_cm_strip2 vmwait index barrier acquire writeout issue status rest", kColMajor && lane == 0 && strip == 2 && f == 12);
 #ifdef BEV_CS_CLOCK /* where and when the workgroup ran: HW_ID (wave, SIMD, CU, SH, SE), XCC_ID; start and end on the 100 MHz clock */
-    if (tid == 0 && (kInPlace || kColMajor) && blockIdx.x < kWalkTlCap) {
-        long long *rec = g_walk_tl[blockIdx.x];
+    if (tid == 0 && (kInPlace || kColMajor) && bid < kWalkTlCap) {
+        long long *rec = g_walk_tl[bid];
         rec[0] = tl_t0;
         rec[1] = wall_clock64();
         rec[2] = (long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -1114,6 +1150,15 @@ __global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSr
         }
     }
     TL_END(K_GATHER_GROUND);
+}
+
+template <int kSrc, bool kPow2, bool kGm>
+__global__ __launch_bounds__(kStripThreads, (kSrc == kSrcColMajor || kSrc == kSrcColMajorGen) ? 3 : 4) void k_walk(BatchPtrs b, Geometry g, int nf, uint32_t want_mode)
+{
+    __shared__ __attribute__((aligned(16))) char arena[sizeof(WalkLds<kSrc>)];
+    int f, strip;
+    if (!map_block_xcd((int)blockIdx.x, nf, g.strips, f, strip)) return;
+    walk_body<kSrc, kPow2, kGm>(arena, b, g, f, strip, want_mode, (int)blockIdx.x);
 }
 
 } /* namespace bevk */

@@ -48,7 +48,11 @@ def test_json_line_has_roofline_and_cpu_baseline():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["pipeline"]["frac"] < 1
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["gpu_output_matches_oracle_on_sampled_frame"] is True
     assert cb["timed_region"]["value"] > 0 and cb["timed_region"]["value"] <= cb["value"] * 1.05
-    assert {k["name"] for k in d["kernels_pipelined"]} == {k["name"] for k in d["kernels"]}
+    # the timed region runs fused launches (k_stage: a sub-batch's walk beside the later stages of its neighbours); the
+    # one-lane pass behind it runs the same device code as one launch per kernel, which is what the roofline is read from
+    assert "k_stage" in {k["name"] for k in d["kernels_pipelined"]}
+    assert {"k_walk", "k_cell_sums", "k_ground_resolve", "k_bev_raster", "k_probe"} <= {k["name"] for k in d["kernels"]}
+    assert rf["kernel"] == "k_walk"
 
 
 @pytest.mark.gpu
