@@ -26,7 +26,7 @@ using namespace bevk;
 
 namespace {
 
-constexpr int kDescRing = 4;
+constexpr int kDescRing = 16;
 constexpr int kEventPairs = 2048;
 
 struct ProfSlot {
@@ -35,10 +35,11 @@ struct ProfSlot {
     int frames;
 };
 
-/* A sub-batch's workspace lives from its column walk to its rasters: four launches (k_stage, see run_pipeline), so
- * four workspace sets ("lanes", the name rounds 2-5 gave them when each also had a stream) go round.  Lane 0 doubles as
+/* A sub-batch's workspace lives from its column walk to its rasters: four launches of its stream, and two streams take
+ * sub-batches in turn (k_stage, see run_pipeline), so eight workspace sets ("lanes", the name rounds 2-5 gave them when
+ * each also had a stream) go round.  Lane 0 doubles as
  * the workspace of the single-cloud entry points. */
-constexpr int kMaxLanes = 4;
+constexpr int kMaxLanes = 8;
 struct Lane {
     FrameInfo *info = nullptr;  /* per frame: how its points reach their slots (k_probe / k_verdict) */
     uint32_t *est = nullptr;    /* stream frames: estimated input position of every (row, strip)'s first slot */
@@ -131,11 +132,18 @@ struct bev_ctx {
     /* sub-batch workspace sets; the aliases below are lane 0's */
     Lane lanes[kMaxLanes];
     int n_lanes = kMaxLanes;
-    int next_lane = 0;
+    /* fused launches alternate between two streams: sub-batch s on stage_st[s % 2], its workspace set s % 8 (always the
+     * same stream's), its later stages in that stream's next three launches — a launch's tail is filled by the other
+     * stream's launch, and nothing but the order of launches on ONE stream ever orders two stages of one sub-batch */
+    hipStream_t stage_st[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr;
+    int n_stage_streams = 2;   /* BEV_STAGE_STREAMS=1: everything on one stream (a launch's tail stands empty) */
+    unsigned sub_seq = 0;      /* sub-batches so far */
     /* fused: a sub-batch's stages ride in consecutive k_stage launches beside the stages of its neighbours (run_pipeline);
      * serial (BEV_LANES=1, bev_set_lanes(ctx, 1)): every kernel a launch of its own, back to back — per-kernel durations */
     bool fused = true;
-    int stage_lead = 12;       /* BEV_STAGE_LEAD: group slots by which a launch's walk workgroups precede its other stages' */
+    int stage_lead = 0;        /* BEV_STAGE_LEAD: group slots by which a launch's walk workgroups precede its other stages' */
     uint32_t *hint = nullptr;  /* mapped host words (k_verdict): [0] frames of the last verdict's sub-batch that were NOT read in place, [1] the modes k_probe gave its frames (bit = mode) */
     int mode_absent[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* looks at hint[1] since it last showed the mode (see run_pipeline) */
     int mode_ttl = 8;          /* a mode's in-place walk stays launched for this many sub-batches after a verdict last showed the mode (BEV_MODE_TTL) */
@@ -147,6 +155,7 @@ struct bev_ctx {
         bool want_multi, want_single;
         int8_t *gm_out; /* final ground_mat wanted (device), or nullptr */
         int next;       /* 1 phase B, 2 phase C, 3 rasters */
+        int q;          /* which of the two streams its stages ride on */
     };
     std::deque<Pending> pending;
     uint32_t *winner = nullptr;
@@ -159,12 +168,13 @@ struct bev_ctx {
 
     /* frame descriptors: ring of pinned host + device arrays */
     FrameDesc *h_desc[kDescRing] = {nullptr, nullptr, nullptr, nullptr};
-    FrameDesc *d_desc[kDescRing] = {nullptr, nullptr, nullptr, nullptr};
+    FrameDesc *d_desc[kDescRing] = {nullptr, nullptr, nullptr, nullptr}; /* the device's address of h_desc (mapped host memory) */
     size_t desc_cap[kDescRing] = {0, 0, 0, 0};
     hipEvent_t desc_copied[kDescRing]{};
     hipEvent_t desc_done[kDescRing]{};
     bool desc_used[kDescRing] = {false, false, false, false};
     int desc_next = 0;
+    int desc_ring = 4; /* calls the host may run ahead of the device */
 
     /* staging for the host-buffer entry points (lazily allocated) */
     bev_point_t *st_in = nullptr;
@@ -368,16 +378,17 @@ struct ProfScope {
 int acquire_desc(bev_ctx *c, size_t n, int *slot_out)
 {
     const int k = c->desc_next;
-    c->desc_next = (k + 1) % kDescRing;
+    c->desc_next = (k + 1) % c->desc_ring;
     if (c->desc_used[k]) HIPCK(c, hipEventSynchronize(c->desc_done[k]));
     if (c->desc_cap[k] < n) {
         if (c->h_desc[k]) HIPCK(c, hipHostFree(c->h_desc[k]));
-        if (c->d_desc[k]) HIPCK(c, hipFree(c->d_desc[k]));
         c->h_desc[k] = nullptr;
         c->d_desc[k] = nullptr;
         const size_t cap = std::max<size_t>(n, 64);
-        HIPCK(c, hipHostMalloc((void **)&c->h_desc[k], cap * sizeof(FrameDesc), hipHostMallocDefault));
-        HIPCK(c, hipMalloc((void **)&c->d_desc[k], cap * sizeof(FrameDesc)));
+        /* mapped: the kernels read a frame's 16 bytes over the link, once per workgroup — no copy command between the
+         * launches of a stream (the copies of two streams share a copy queue, where one waits behind the other) */
+        HIPCK(c, hipHostMalloc((void **)&c->h_desc[k], cap * sizeof(FrameDesc), hipHostMallocMapped));
+        HIPCK(c, hipHostGetDevicePointer((void **)&c->d_desc[k], c->h_desc[k], 0));
         c->desc_cap[k] = cap;
     }
     *slot_out = k;
@@ -394,13 +405,14 @@ int ensure_gm(bev_ctx *c)
 /* ---- the stages of earlier sub-batches that have not been launched yet ------------------------------------------- */
 /* Fills the later-stage parts of a fused launch from the pending sub-batches: each is advanced by ONE stage.  With every
  * launch advancing every pending sub-batch there is at most one per stage. */
-void take_pending(bev_ctx *c, StageArgs *a)
+void take_pending(bev_ctx *c, StageArgs *a, int q)
 {
     a->sums = StagePart{};
     a->resolve = StagePart{};
     a->raster = StagePart{};
     a->want_multi = a->want_single = 0;
     for (const bev_ctx::Pending &p : c->pending) {
+        if (p.q != q) continue;
         StagePart &part = p.next == 1 ? a->sums : (p.next == 2 ? a->resolve : a->raster);
         part.b = p.b;
         part.nf = p.nf;
@@ -413,38 +425,53 @@ void take_pending(bev_ctx *c, StageArgs *a)
 }
 /* ... after that launch: the optional final ground_mat of the sub-batch whose averages are now final (a plain launch:
  * rarely asked for), sub-batches through their rasters leave the queue */
-int advance_pending(bev_ctx *c)
+int advance_pending(bev_ctx *c, int q)
 {
     for (bev_ctx::Pending &p : c->pending) {
+        if (p.q != q) continue;
         if (p.next == 1 && p.gm_out) {
-            ProfScope ps(c, K_GROUND_MAT, p.nf);
-            launch_ground_mat(c->geo, p.b, p.gm_out, p.nf, c->stream);
+            ProfScope ps(c, K_GROUND_MAT, p.nf, c->stage_st[q]);
+            launch_ground_mat(c->geo, p.b, p.gm_out, p.nf, c->stage_st[q]);
         }
         ++p.next;
     }
-    while (!c->pending.empty() && c->pending.front().next > 3) c->pending.pop_front();
+    for (auto it = c->pending.begin(); it != c->pending.end();) it = it->next > 3 ? c->pending.erase(it) : it + 1;
     HIPCK(c, hipGetLastError());
     return BEV_OK;
 }
-/* launches what is left of every pending sub-batch: up to three launches without a walk */
-int flush_pending(bev_ctx *c)
+/* the context's stream continues behind everything the stage streams hold */
+int join_stage_streams(bev_ctx *c)
 {
-    while (!c->pending.empty()) {
-        StageArgs a{};
-        a.g = c->geo;
-        a.lead = 0;
-        take_pending(c, &a);
-        {
-            ProfScope ps(c, K_STAGE, 0);
-            launch_stage(a, -1, c->stream);
-        }
-        int rc = advance_pending(c);
-        if (rc != BEV_OK) return rc;
+    for (int q = 0; q < 2; ++q) {
+        HIPCK(c, hipEventRecord(c->stage_ev[q], c->stage_st[q]));
+        HIPCK(c, hipStreamWaitEvent(c->stream, c->stage_ev[q], 0));
     }
     return BEV_OK;
 }
+/* launches what is left of every pending sub-batch: up to three launches without a walk per stream; then joins */
+int flush_pending(bev_ctx *c)
+{
+    while (!c->pending.empty()) {
+        for (int q = 0; q < 2; ++q) {
+            bool any = false;
+            for (const bev_ctx::Pending &p : c->pending) any = any || p.q == q;
+            if (!any) continue;
+            StageArgs a{};
+            a.g = c->geo;
+            a.lead = 0;
+            take_pending(c, &a, q);
+            {
+                ProfScope ps(c, K_STAGE, 0, c->stage_st[q]);
+                launch_stage(a, -1, c->stage_st[q]);
+            }
+            int rc = advance_pending(c, q);
+            if (rc != BEV_OK) return rc;
+        }
+    }
+    return join_stage_streams(c);
+}
 
-/* The whole pipeline on device pointers, everything on the context's stream.  `identity`: d_pts already holds ordered
+/* The whole pipeline on device pointers.  `identity`: d_pts already holds ordered
  * clouds (n_frames * S points) and the order stage is skipped.
  *
  * Fused (the default): per sub-batch t ONE launch of k_stage holds its column walk and, as further workgroups of the
@@ -455,21 +482,24 @@ int flush_pending(bev_ctx *c)
  * Serial (bev_set_lanes(ctx, 1)): every kernel a launch of its own, back to back. */
 int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint64_t *h_offsets, bool identity,
                  bev_point_t *d_ordered, uint8_t *d_multi, uint8_t *d_single, int8_t *d_gm, bool flush = true,
-                 int sub_frames = 0 /* frames per sub-batch; 0: max_batch */)
+                 int sub_frames = 0 /* frames per sub-batch; 0: max_batch */,
+                 bool fork = true /* the stage streams start behind what the caller queued on the context's stream (its uploads) */)
 {
     if (n_frames == 0) return BEV_OK;
     const Geometry &g = c->geo;
     const size_t S = (size_t)g.S;
-    hipStream_t st = c->stream;
     HIPCK(c, hipSetDevice(c->device));
     if (d_gm) {
         int rc = ensure_gm(c);
         if (rc != BEV_OK) return rc;
     }
     const bool fused = c->fused && !identity;
-    if (!fused) { /* (the serial launches use the same workspace sets) */
+    if (!fused) { /* (the serial launches, on the context's stream, use the same workspace sets) */
         int rc = flush_pending(c);
         if (rc != BEV_OK) return rc;
+    } else if (fork) {
+        HIPCK(c, hipEventRecord(c->fork_ev, c->stream));
+        for (int q = 0; q < 2; ++q) HIPCK(c, hipStreamWaitEvent(c->stage_st[q], c->fork_ev, 0));
     }
 
     int ds = 0;
@@ -486,15 +516,16 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             c->h_desc[ds][f].n_pts = (uint32_t)(b - a);
             c->h_desc[ds][f]._pad = 0;
         }
-        HIPCK(c, hipMemcpyAsync(c->d_desc[ds], c->h_desc[ds], (size_t)n_frames * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
     }
 
     const int sub_size = sub_frames > 0 ? std::min(sub_frames, c->max_batch) : c->max_batch;
     for (int f0 = 0; f0 < n_frames; f0 += sub_size) {
         const int nb = std::min(sub_size, n_frames - f0);
-        /* the set's previous tenant is through its rasters: they rode in a launch three before this one at the latest */
-        Lane &ln = c->lanes[c->next_lane];
-        c->next_lane = (c->next_lane + 1) % c->n_lanes;
+        /* the set's previous tenant is through its rasters: they rode in this stream's launch before this one at the latest */
+        const int q = fused ? (int)(c->sub_seq % (unsigned)c->n_stage_streams) : 0;
+        hipStream_t st = fused ? c->stage_st[q] : c->stream;
+        Lane &ln = c->lanes[c->sub_seq % (unsigned)c->n_lanes];
+        ++c->sub_seq;
         BatchPtrs b{};
         b.pts = identity ? d_pts + (size_t)f0 * S : d_pts;
         b.frames = identity ? nullptr : c->d_desc[ds] + f0;
@@ -529,12 +560,12 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                 a.walk.nf = nb;
                 a.want_mode = mode;
                 a.lead = c->stage_lead;
-                take_pending(c, &a);
+                take_pending(c, &a, q);
                 {
                     ProfScope ps(c, K_STAGE, nb, st);
                     launch_stage(a, source, st);
                 }
-                return advance_pending(c);
+                return advance_pending(c, q);
             }
             ProfScope ps(c, kid, nb, st);
             launch_gather_ground(g, b, nb, source, mode, st);
@@ -606,7 +637,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             if (rc != BEV_OK) return rc;
         }
         if (fused) {
-            c->pending.push_back(bev_ctx::Pending{b, nb, d_multi != nullptr, d_single != nullptr, d_gm ? d_gm + (size_t)f0 * S : nullptr, 1});
+            c->pending.push_back(bev_ctx::Pending{b, nb, d_multi != nullptr, d_single != nullptr, d_gm ? d_gm + (size_t)f0 * S : nullptr, 1, q});
         } else {
             RoctxRange rb("bev:back (cell sums, resolve, rasters)");
             {
@@ -632,11 +663,15 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         c->last_info = identity ? nullptr : ln.info;
         HIPCK(c, hipGetLastError());
     }
+    if (fused) { /* (flush_pending joins as well) */
+        int rc = flush ? flush_pending(c) : join_stage_streams(c);
+        if (rc != BEV_OK) return rc;
+    }
     if (!identity) {
-        HIPCK(c, hipEventRecord(c->desc_done[ds], st));
+        HIPCK(c, hipEventRecord(c->desc_done[ds], c->stream));
         c->desc_used[ds] = true;
     }
-    return flush ? flush_pending(c) : BEV_OK;
+    return BEV_OK;
 }
 
 int ensure_staging(bev_ctx *c)
@@ -766,6 +801,8 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         const char *e = getenv("BEV_LANES");
         c->fused = !(e && atoi(e) == 1);
         if (const char *ld = getenv("BEV_STAGE_LEAD")) c->stage_lead = std::max(0, atoi(ld));
+        if (const char *ss = getenv("BEV_STAGE_STREAMS")) c->n_stage_streams = atoi(ss) == 1 ? 1 : 2;
+        if (const char *dr = getenv("BEV_DESC_RING")) c->desc_ring = std::max(1, std::min(kDescRing, atoi(dr)));
         /* Frames whose points are in slot order up to a tail (a sweep written row by row with dropped returns ABSENT — none
          * of the reference's three selectors writes exactly that: KITTI's structured clouds and MulRan's firing order have
          * routes of their own, kFrameStructured / kFrameColMajor, Oxford's file order goes the general way) are read in place: no order
@@ -775,6 +812,19 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         const char *sm = getenv("BEV_STREAM");
         c->allow_stream = !(sm && atoi(sm) == 0);
         if (const char *mt = getenv("BEV_MODE_TTL")) c->mode_ttl = std::max(1, atoi(mt));
+    }
+    {   /* streams of equal priority may be multiplexed onto ONE hardware queue (observed in round 2: two such streams never
+         * overlapped); streams of different priority get different queues */
+        int prio_least = 0, prio_greatest = 0;
+        CK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        for (int q = 0; q < 2; ++q) {
+            const char *pe = getenv("BEV_STAGE_PRIO"); /* experiment: 0 equal priorities, 2 the other stream first */
+            const int pm = pe ? atoi(pe) : 0;
+            const int pr = pm == 0 ? prio_greatest : (pm == 2 ? prio_greatest + (1 - q) : prio_greatest + q);
+            CK(hipStreamCreateWithPriority(&c->stage_st[q], hipStreamNonBlocking, std::min(prio_least, pr)));
+            CK(hipEventCreateWithFlags(&c->stage_ev[q], hipEventDisableTiming));
+        }
+        CK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
     }
     CK(hipHostMalloc((void **)&c->hint, 2 * sizeof(uint32_t), hipHostMallocMapped));
     c->hint[0] = 0xffffffffu; /* nothing known yet: the first order scan is launched wide, */
@@ -830,6 +880,12 @@ void bev_destroy(bev_ctx_t *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     c->pending.clear(); /* (stages never launched: their outputs were never waited for) */
+    for (int q = 0; q < 2; ++q) {
+        if (c->stage_st[q]) (void)hipStreamSynchronize(c->stage_st[q]);
+        if (c->stage_ev[q]) (void)hipEventDestroy(c->stage_ev[q]);
+        if (c->stage_st[q]) (void)hipStreamDestroy(c->stage_st[q]);
+    }
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (int l = 0; l < kMaxLanes; ++l) {
@@ -852,7 +908,6 @@ void bev_destroy(bev_ctx_t *c)
         if (p) (void)hipFree(p);
     for (int k = 0; k < kDescRing; ++k) {
         if (c->h_desc[k]) (void)hipHostFree(c->h_desc[k]);
-        if (c->d_desc[k]) (void)hipFree(c->d_desc[k]);
         if (c->desc_copied[k]) (void)hipEventDestroy(c->desc_copied[k]);
         if (c->desc_done[k]) (void)hipEventDestroy(c->desc_done[k]);
     }
@@ -880,8 +935,10 @@ int bev_process_device_resident(bev_ctx_t *c, int n_frames, const bev_point_t *d
 {
     if (!c || n_frames < 0 || !h_offsets || !d_ordered) return BEV_ERR_INVALID_ARG;
     if (n_frames > 0 && !d_pts && h_offsets[n_frames] != h_offsets[0]) return BEV_ERR_INVALID_ARG;
+    /* (no fork: nothing of this call is on the context's stream, and waiting for it would be waiting for BOTH stage
+     * streams' launches of the call before: the overlap across calls) */
     return run_pipeline(c, n_frames, d_pts, h_offsets, false, d_ordered, d_multi, d_single, d_ground_mat,
-                        /*flush=*/false);
+                        /*flush=*/false, 0, /*fork=*/false);
 }
 
 int bev_process_batch(bev_ctx_t *c, int n_frames, const bev_point_t *const *pts, const uint32_t *n_pts,
@@ -990,7 +1047,6 @@ int bev_order_cloud(bev_ctx_t *c, const bev_point_t *pts, uint32_t n_pts, bev_po
     rc = acquire_desc(c, 1, &ds);
     if (rc != BEV_OK) return rc;
     c->h_desc[ds][0] = FrameDesc{0, n_pts, 0};
-    HIPCK(c, hipMemcpyAsync(c->d_desc[ds], c->h_desc[ds], sizeof(FrameDesc), hipMemcpyHostToDevice, c->stream));
     if (n_pts)
         HIPCK(c, hipMemcpyAsync(c->st_in, pts, (size_t)n_pts * sizeof(bev_point_t), hipMemcpyHostToDevice, c->stream));
     BatchPtrs b{};

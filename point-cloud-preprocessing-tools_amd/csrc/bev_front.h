@@ -22,13 +22,29 @@ using namespace bevx;
 #define BEV_PROBE_THREADS 256
 #endif
 constexpr int kProbeThreads = BEV_PROBE_THREADS; /* one workgroup per frame */
-__global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g, int allow_stream)
+/* The probe's LDS — since round 6 a quarter of a CU's, like every kernel of the path (bev_internal.h: kSlotLdsBytes): its
+ * workgroups start wherever another one has retired (75 KB: only where two column-walk workgroups of a CU had retired
+ * together).  The firing-order analysis and the tail lists never run at the same time: one piece of LDS for both. */
+struct ProbeLds {
+    uint32_t samp[kMaxSamples]; /* slot of sample k (position k * kProbeStride) */
+    union {
+        struct {
+            uint16_t col[kCmMaxSamples], col1[kCmMaxSamples]; /* column of every sample and of its successor (their rows are position mod N: checked first) */
+            uint32_t ref[kCmMaxRows], lo[kCmMaxRows], hi[kCmMaxRows], base[kCmMaxRows], misc[4];
+        } cm;
+        uint32_t tcnt[kTailBuckets]; /* tail points listed per (row, strip) */
+    } u;
+    uint32_t first_bad, overflow, struct_bad, struct_zero, cm_bad, cm_not_plain;
+};
+static_assert(sizeof(ProbeLds) <= kSlotLdsBytes, "a quarter of a CU's LDS");
+__device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, const Geometry &g, int allow_stream, const int f)
 {
     TL_BEGIN;
-    __shared__ uint32_t samp[kMaxSamples]; /* slot of sample k (position k * kProbeStride) */
-    __shared__ uint32_t first_bad, overflow;
-    __shared__ uint32_t tcnt[kTailBuckets]; /* tail points listed per (row, strip) */
-    const int f = blockIdx.x, tid = threadIdx.x;
+    ProbeLds &lds_p = *reinterpret_cast<ProbeLds *>(arena);
+    auto &samp = lds_p.samp;
+    uint32_t &first_bad = lds_p.first_bad, &overflow = lds_p.overflow;
+    auto &tcnt = lds_p.u.tcnt;
+    const int tid = threadIdx.x;
     const FrameDesc fd = b.frames[f];
     const uint32_t n = fd.n_pts;
     const bev_point_t *fp = b.pts + fd.in_offset;
@@ -42,11 +58,16 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
     /* ... or S returns in firing order (kFrameColMajor): every sampled record is beam (position mod N) of firing
      * (position / N); its column follows the firing — in either direction, from any start azimuth, with a base of its own
      * per row (staggered beams) — or is out of range, or is column 0 (a no-return record): see below */
-    __shared__ uint32_t struct_bad, struct_zero, cm_bad, cm_not_plain;
+    uint32_t &struct_bad = lds_p.struct_bad, &struct_zero = lds_p.struct_zero, &cm_bad = lds_p.cm_bad, &cm_not_plain = lds_p.cm_not_plain;
     const bool can_cm = can_struct && g.N >= 2; /* (the plain sweep) */
     const bool can_cm_gen = can_cm && g.N <= kCmMaxRows && g.strips <= kCmMaxStrips && ns <= (uint32_t)kCmMaxSamples && b.cm_par != nullptr;
-    __shared__ uint32_t cmrc[kCmMaxSamples], cmrc1[kCmMaxSamples]; /* row | col << 16 of every sample and of its successor */
-    __shared__ uint32_t cm_ref[kCmMaxRows], cm_lo[kCmMaxRows], cm_hi[kCmMaxRows], cm_base[kCmMaxRows], cm_misc[4];
+    auto &cmcol = lds_p.u.cm.col;
+    auto &cmcol1 = lds_p.u.cm.col1;
+    auto &cm_ref = lds_p.u.cm.ref;
+    auto &cm_lo = lds_p.u.cm.lo;
+    auto &cm_hi = lds_p.u.cm.hi;
+    auto &cm_base = lds_p.u.cm.base;
+    auto &cm_misc = lds_p.u.cm.misc;
     if (tid == 0) {
         first_bad = can ? ns : 0u;
         struct_bad = 0u;
@@ -94,8 +115,8 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
                     if (col < (uint32_t)g.H && col - (uint32_t)i / (uint32_t)g.N > 8u) cm_not_plain = 1u;
                 }
                 if (can_cm_gen) {
-                    cmrc[k] = rc[u];
-                    cmrc1[k] = i + 1 < n ? rc1[u] : 0xffffffffu; /* (col 0xffff: out of range, not looked at) */
+                    cmcol[k] = (uint16_t)(rc[u] >> 16);
+                    cmcol1[k] = i + 1 < n ? (uint16_t)(rc1[u] >> 16) : (uint16_t)0xffffu; /* (col 0xffff: out of range, not looked at) */
                 }
                 if (can) samp[k] = sl;
             }
@@ -133,8 +154,7 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
                 }
                 if (tid < 4) cm_misc[tid] = tid == 1 ? 0xffffffffu : 0u; /* [0] failed, [1] smallest / [2] largest base offset (biased), [3] a row that has samples + 1 */
                 __syncthreads();
-                auto disp = [&](uint32_t pos, uint32_t rcw, uint32_t *row, uint32_t *d) -> bool { /* a sample that says something about its row's base */
-                    const uint32_t col = rcw >> 16;
+                auto disp = [&](uint32_t pos, uint32_t col, uint32_t *row, uint32_t *d) -> bool { /* a sample that says something about its row's base */
                     if (col == 0u || col >= H) return false;
                     const uint32_t fire = div_n(pos); /* (< H: the frame has S = N * H records) */
                     *row = pos - fire * N;
@@ -144,8 +164,8 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
                 };
                 for (uint32_t k = tid; k < ns; k += kProbeThreads) {
                     uint32_t row, d;
-                    if (disp(k * kProbeStride, cmrc[k], &row, &d)) cm_ref[row] = d; /* (any sample of the row will do as its reference) */
-                    if (disp(k * kProbeStride + 1u, cmrc1[k], &row, &d)) cm_ref[row] = d;
+                    if (disp(k * kProbeStride, cmcol[k], &row, &d)) cm_ref[row] = d; /* (any sample of the row will do as its reference) */
+                    if (disp(k * kProbeStride + 1u, cmcol1[k], &row, &d)) cm_ref[row] = d;
                 }
                 __syncthreads();
                 auto rel = [&](uint32_t d, uint32_t ref) -> uint32_t { /* d - ref as a signed offset around the circle, biased */
@@ -154,11 +174,11 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
                 };
                 for (uint32_t k = tid; k < ns; k += kProbeThreads) {
                     uint32_t row, d;
-                    if (disp(k * kProbeStride, cmrc[k], &row, &d)) {
+                    if (disp(k * kProbeStride, cmcol[k], &row, &d)) {
                         atomicMin(&cm_lo[row], rel(d, cm_ref[row]));
                         atomicMax(&cm_hi[row], rel(d, cm_ref[row]));
                     }
-                    if (disp(k * kProbeStride + 1u, cmrc1[k], &row, &d)) {
+                    if (disp(k * kProbeStride + 1u, cmcol1[k], &row, &d)) {
                         atomicMin(&cm_lo[row], rel(d, cm_ref[row]));
                         atomicMax(&cm_hi[row], rel(d, cm_ref[row]));
                     }
@@ -193,12 +213,12 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
                         for (uint32_t k = tid; k < ns; k += kProbeThreads) {
 #pragma unroll
                             for (int w = 0; w < 2; ++w) {
-                                const uint32_t rcw = w ? cmrc1[k] : cmrc[k], pos = k * kProbeStride + (uint32_t)w;
-                                if ((rcw >> 16) != 0u) continue;
+                                const uint32_t col = w ? cmcol1[k] : cmcol[k], pos = k * kProbeStride + (uint32_t)w;
+                                if (col != 0u) continue; /* (its row is position mod N: cm_bad == 0) */
                                 const uint32_t fire = div_n(pos), row = pos - fire * N;
                                 const uint32_t u = fwd ? fire : (fire ? H - fire : 0u);
                                 const uint32_t d = (2u * H - u - cm_base[row]) % H; /* (0 - u - base) mod H */
-                                if ((rcw & 0xffffu) == row && d > (uint32_t)kColMaxDisp) cm_misc[0] = 1u;
+                                if (d > (uint32_t)kColMaxDisp) cm_misc[0] = 1u;
                             }
                         }
                         __syncthreads();
@@ -340,6 +360,12 @@ __global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g
     TL_END(K_PROBE);
     PH_PRINT("probe samples prefix-end estimates tail-lists counts", tid == 0 && f == 100);
 }
+__global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g, int allow_stream)
+{
+    __shared__ __attribute__((aligned(16))) char arena[sizeof(ProbeLds)];
+    probe_body(arena, b, g, allow_stream, (int)blockIdx.x);
+}
+
 
 /* after the stream walk: a frame whose consumed points do not add up to its prefix, or with a failed check, is redone */
 /* ... and the host is told, without being waited for, how many frames of the sub-batch are NOT read in place (a word in

@@ -33,7 +33,7 @@ namespace bevk {
 /* developer aid (make tl): start, end and place of EVERY workgroup of the pipeline's kernels since the last reset — what
  * shares the chip with what, and when (scripts/pipeline_timeline.py) */
 #ifdef BEV_TL_ALL
-constexpr unsigned kTlAllCap = 1u << 17;
+constexpr unsigned kTlAllCap = 1u << 19;
 __device__ long long g_tl_all[kTlAllCap][4];
 __device__ unsigned g_tl_all_n;
 #define TL_BEGIN const long long tl_all_t0 = wall_clock64()

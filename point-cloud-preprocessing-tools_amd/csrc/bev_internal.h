@@ -101,7 +101,7 @@ constexpr uint32_t kInfoCmUsed = 2u; /* firing-order frames: a wrap-around halo 
 #endif
 constexpr int kProbeStride = BEV_PROBE_STRIDE;    /* k_probe looks at every 63rd point (odd: no resonance with firing orders of 2^k beams); the position of a
                                      * slot between two samples is interpolated: its error grows with the root of the stride */
-constexpr int kMaxSamples = 8192;   /* => stream mode for frames of up to 2^20 points; longer ones go the general way */
+constexpr int kMaxSamples = 4096;   /* => sorted frames of up to 258 k points are read in place (k_probe keeps their samples in LDS, a quarter of a CU's); longer ones go the general way */
 constexpr int kStreamMinPrefix = 2048;
 constexpr int kTailCap = 64;         /* tail points (those after the sorted prefix) a (row, strip) can list; more: general way */
 constexpr int kTailMax = 16384;     /* ... a frame can have */
