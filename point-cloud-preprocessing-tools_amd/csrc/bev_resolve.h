@@ -29,6 +29,10 @@ struct ResolveLds {
     float avg[kGridCells];                               /* the frame's 75 x 50 averages */
     int edge_x[kGridRows], edge_y[kGridCols];            /* BEV bin of every ground-grid row's / column's lower edge */
     uint32_t band_cursor[kMaxBands];
+    /* per wave: the un-grounded candidates waiting for their BEV codes (key, height, slot): an eighth of a frame's candidates
+     * is un-grounded, five to ten lanes of a slice — coded slice by slice, the code path (sixty-odd instructions) ran for
+     * every slice with those few lanes alive; parked here and coded 64 at a time it runs an eighth as often */
+    uint32_t ring[kResolveThreads / 64][3][128];
     uint16_t cnt[kMaxSegs / kResolveParts + 8];
     uint8_t band_tab[512];                               /* x bin -> raster band */
 };
@@ -51,6 +55,7 @@ __device__ __forceinline__ void resolve_body(char *arena, const BatchPtrs &b, co
     auto &band_cursor = lds_r.band_cursor;
     auto &band_tab = lds_r.band_tab;
     auto &cnt = lds_r.cnt;
+    auto &ring = lds_r.ring;
     constexpr int kPartsPerWg = kResolveParts / kResolveWgs;
     const int part0 = wg * kPartsPerWg;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,9 +108,36 @@ __device__ __forceinline__ void resolve_body(char *arena, const BatchPtrs &b, co
     }
     if (tid < kMaxBands) band_cursor[tid] = 0u;
     lds_barrier();
-    for (int s0 = t0 + wv; s0 < t1; s0 += kWaves * kResolveBatch) {
-        uint32_t key[kResolveBatch][kSl];
-        float z[kResolveBatch][kSl];
+    uint32_t rhead = 0u, rtail = 0u; /* (wave-uniform) entries ever parked in / taken from this wave's ring */
+    /* the codes of up to 64 parked candidates (lane l: entry tail + l), appended to this part's lists */
+    auto emit = [&](uint32_t n_valid) {
+        __builtin_amdgcn_wave_barrier(); /* (the entries were written by other lanes of this wave: LDS keeps a wave's order) */
+        const uint32_t at = (rtail + (uint32_t)lane) & 127u;
+        const uint32_t kk = ring[wv][0][at], idx = ring[wv][2][at];
+        const float zz = __uint_as_float(ring[wv][1][at]);
+        if ((uint32_t)lane < n_valid) {
+            const int cell = (int)(kk & kKeyCellMask);
+            uint32_t code;
+            if (!candidate_key_escapes(kk)) {
+                code = code_from_bins_t<kPow2>(edge_x[cell / kGridCols] + (int)((kk >> kKeyDxShift) & 3u),
+                                               edge_y[cell % kGridCols] + (int)((kk >> kKeyDyShift) & 3u), zz, rp);
+            } else { /* cell clamped or bins not next to the cell's edge: x, y from the point itself */
+                const float4 a = *reinterpret_cast<const float4 *>(fordered + idx);
+                code = code_t<kPow2>(a.x, a.y, a.z, 1 /* not 0: no kKeyNoCodeBit */, rp);
+            }
+            if (code != kSkip) {
+                const int band = band_tab[code_x(code)];
+                const uint32_t pos = atomicAdd(&band_cursor[band], 1u);
+                flist[(uint32_t)band * g.code_stride + (pos < code_cap ? pos : code_cap - 1u)] = code;
+            }
+        }
+        rtail += n_valid;
+        __builtin_amdgcn_wave_barrier();
+    };
+    /* a wave's segments of the part, kResolveBatch at a time; the next batch's loads are in flight while this one is tested */
+    uint32_t key_n[kResolveBatch][kSl];
+    float z_n[kResolveBatch][kSl];
+    auto request = [&](int s0) {
 #pragma unroll
         for (int j = 0; j < kResolveBatch; ++j) {
             const int sg = s0 + j * kWaves;
@@ -113,15 +145,28 @@ __device__ __forceinline__ void resolve_body(char *arena, const BatchPtrs &b, co
 #pragma unroll
             for (int k = 0; k < kSl; ++k) { /* whole slices, nothing but the loads inside the uniform test (see k_cell_sums) */
                 const size_t at = (size_t)(sg < t1 ? sg : t0) * kSeg + lane + 64 * k;
-                key[j][k] = 0u;
-                z[j][k] = 0.f;
+                key_n[j][k] = 0u;
+                z_n[j][k] = 0.f;
                 if (64 * k < __builtin_amdgcn_readfirstlane(n)) {
                     const uint2 kz = fcand[at];
-                    key[j][k] = kz.x;
-                    z[j][k] = __uint_as_float(kz.y);
+                    key_n[j][k] = kz.x;
+                    z_n[j][k] = __uint_as_float(kz.y);
                 }
             }
         }
+    };
+    request(t0 + wv);
+    for (int s0 = t0 + wv; s0 < t1; s0 += kWaves * kResolveBatch) {
+        uint32_t key[kResolveBatch][kSl];
+        float z[kResolveBatch][kSl];
+#pragma unroll
+        for (int j = 0; j < kResolveBatch; ++j)
+#pragma unroll
+            for (int k = 0; k < kSl; ++k) {
+                key[j][k] = key_n[j][k];
+                z[j][k] = z_n[j][k];
+            }
+        if (s0 + kWaves * kResolveBatch < t1) request(s0 + kWaves * kResolveBatch); /* (wave-uniform) */
 #pragma unroll
         for (int j = 0; j < kResolveBatch; ++j) {
             const int sg = s0 + j * kWaves;
@@ -137,22 +182,19 @@ __device__ __forceinline__ void resolve_body(char *arena, const BatchPtrs &b, co
                 const bool hit = have && (z[j][k] - minavg[cell]) >= 0.3f;
                 const bool pred = (kk & kKeyPredBit) != 0u;
                 const bool wrong = have && hit != pred;
-                if (!__ballot(hit || wrong)) continue; /* wave-uniform */
                 const uint32_t idx = slot0 + ((kk >> kKeyColShift) & 0xffu);
-                if (hit && !(kk & kKeyNoCodeBit)) {
-                    uint32_t code;
-                    if (!candidate_key_escapes(kk)) {
-                        code = code_from_bins_t<kPow2>(edge_x[cell / kGridCols] + (int)((kk >> kKeyDxShift) & 3u),
-                                                       edge_y[cell % kGridCols] + (int)((kk >> kKeyDyShift) & 3u), z[j][k], rp);
-                    } else { /* cell clamped or bins not next to the cell's edge: x, y from the point itself */
-                        const float4 a = *reinterpret_cast<const float4 *>(fordered + idx);
-                        code = code_t<kPow2>(a.x, a.y, a.z, 1 /* not 0: no kKeyNoCodeBit */, rp);
+                const bool coded = hit && !(kk & kKeyNoCodeBit);
+                const unsigned long long cm = __ballot(coded);
+                if (cm != 0ull) { /* (wave-uniform) park them behind the ring's head */
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                    if (coded) {
+                        const uint32_t at = (rhead + rank) & 127u;
+                        ring[wv][0][at] = kk;
+                        ring[wv][1][at] = __float_as_uint(z[j][k]);
+                        ring[wv][2][at] = idx;
                     }
-                    if (code != kSkip) {
-                        const int band = band_tab[code_x(code)];
-                        const uint32_t pos = atomicAdd(&band_cursor[band], 1u);
-                        flist[(uint32_t)band * g.code_stride + (pos < code_cap ? pos : code_cap - 1u)] = code;
-                    }
+                    rhead += (uint32_t)__popcll(cm);
+                    if (rhead - rtail >= 64u) emit(64u);
                 }
                 if (wrong) { /* the walk's provisional label differs */
                     /* not un-grounded: label = 0, BatchMultiBevGen.cpp:245; un-grounded: the point's own label back —
@@ -162,6 +204,7 @@ __device__ __forceinline__ void resolve_body(char *arena, const BatchPtrs &b, co
             }
         }
     }
+    if (rhead != rtail) emit(rhead - rtail); /* (wave-uniform) what is left of the part's */
     lds_barrier();
     if (tid < bands) b.ncode[((size_t)f * g.emitters + g.strips + part) * bands + tid] = band_cursor[tid];
   }

@@ -5,7 +5,8 @@ REV=$1; NAME=$2
 R=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
 mkdir -p $T/pkg/csrc $T/include
-for f in bev_kernels.hip bev_capi.hip bev_internal.h bev_exact.h bev_libm.h; do git -C $R show $REV:point-cloud-preprocessing-tools_amd/csrc/$f > $T/pkg/csrc/$f; done
+# (every tracked source of that revision's csrc/: one translation unit over per-kernel headers since round 6)
+for f in $(git -C $R ls-tree --name-only $REV point-cloud-preprocessing-tools_amd/csrc/ | grep -E '\.(hip|h)$'); do git -C $R show $REV:$f > $T/pkg/csrc/$(basename $f); done
 git -C $R show $REV:include/bev_mi355x.h > $T/include/bev_mi355x.h
 FLAGS="$EXTRA -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function"
 (cd $T/pkg && /opt/rocm/bin/hipcc $FLAGS -c csrc/bev_kernels.hip -o k.o && /opt/rocm/bin/hipcc $FLAGS -c csrc/bev_capi.hip -o c.o &&
