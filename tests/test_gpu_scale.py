@@ -1,5 +1,6 @@
-"""GPU: the batch machinery at BASELINE scale — many frames, device-resident, through the sub-batch
-lanes.  Size-independent properties: results do not depend on how frames are cut into sub-batches or
+"""GPU: the batch machinery at BASELINE scale — many frames, device-resident, through the fused launches
+(k_stage: a sub-batch's walk beside the later stages of its neighbours, two streams, eight workspace sets; BEV_LANES=1 /
+lanes=1 below: every kernel a launch of its own).  Size-independent properties: results do not depend on how frames are cut into sub-batches or
 dealt to lanes; a checksum over all frames is stable across repeated asynchronous calls; sampled frames
 equal the oracle."""
 import hashlib
@@ -16,7 +17,7 @@ pytestmark = pytest.mark.gpu
 N_FRAMES = 300
 
 
-def _run(p, frames, sub_batch, lanes, repeats=1):
+def _run(p, frames, sub_batch, lanes, repeats=1, want_info=False):
     import torch
 
     old = os.environ.get("BEV_LANES")
@@ -41,6 +42,9 @@ def _run(p, frames, sub_batch, lanes, repeats=1):
         ctx.process_device(len(frames), d_in.data_ptr(), offs, d_ord.data_ptr(), d_multi.data_ptr(), d_single.data_ptr())
     ctx.synchronize()
     out = (d_ord.cpu().numpy(), d_multi.cpu().numpy(), d_single.cpu().numpy())
+    if want_info:  # how the frames of the LAST sub-batch reached their slots (bev_debug_get_frame_info)
+        n_last = len(frames) - ((len(frames) - 1) // sub_batch) * sub_batch
+        out = out + (ctx.frame_info(0, n_last),)
     ctx.close()
     return out
 
@@ -190,3 +194,109 @@ def test_os1_firing_order_config_every_frame_matches_oracle():
     with ThreadPoolExecutor(16) as ex:
         bad = [i for i, ok in enumerate(ex.map(check, range(n))) if not ok]
     assert not bad, f"{len(bad)} of {n} frames differ from the oracle, first: {bad[:8]}"
+
+
+def _every_frame(p, frames, outs):
+    from concurrent.futures import ThreadPoolExecutor
+
+    ords, multis, singles = outs[:3]
+    S, M, L = p.slots, p.mat_size, p.n_layers
+    sp = orc.sensor_from_params(p)
+
+    def check(i):  # the oracle is plain C behind ctypes: the threads run it in parallel
+        o_ord, _, o_multi, o_single = orc.process_frame(sp, frames[i], want_gm=False)
+        return (ords[i * S * 32:(i + 1) * S * 32].tobytes() == o_ord.tobytes()
+                and multis[i * L * M * M:(i + 1) * L * M * M].tobytes() == o_multi.tobytes()
+                and singles[i * M * M:(i + 1) * M * M].tobytes() == o_single.tobytes())
+
+    with ThreadPoolExecutor(16) as ex:
+        bad = [i for i, ok in enumerate(ex.map(check, range(len(frames)))) if not ok]
+    assert not bad, f"{len(bad)} of {len(frames)} frames differ from the oracle, first: {bad[:8]}"
+
+
+def test_real_mulran_sweeps_at_launch_size_every_frame_matches_oracle():
+    """What mulran_point_cloud_select writes for REAL Ouster sweeps (MulranPointCloudSelect.cpp:112-130: any start azimuth,
+    either direction, staggered laser columns, 3 % no-return records in column 0) at bench.py's launch size — 1000 OS1_64
+    frames, sub-batches of 500, two asynchronous steps: EVERY frame against the oracle, and the frames of the last
+    sub-batch on route 5 (`bench.py --workload os1_firing_real`; round 5 tested the route on a dozen small batches)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    p = bev_amd.params_for_sensor("OS1_64")
+    n = 1000
+    with ThreadPoolExecutor(16) as ex:
+        frames = list(ex.map(lambda f: synth.firing_real(p, f, noret=0.03), range(n)))
+    outs = _run(p, frames, sub_batch=500, lanes=2, repeats=2, want_info=True)
+    modes = outs[3][:, 1]
+    assert (modes == 5).sum() >= 0.99 * len(modes), np.unique(modes, return_counts=True)
+    _every_frame(p, frames, outs)
+
+
+def test_mixed_layouts_at_launch_size_every_frame_matches_oracle():
+    """The layouts of the reference's producers alternating in groups of 32 HDL_64E frames (`bench.py --workload mixed`:
+    sorted sweeps with appended duplicates, structured clouds, real firing order), 1000 frames, sub-batches of 500: EVERY
+    frame against the oracle; no frame of the last sub-batch — frames 500 ... 999, far behind the first three groups —
+    is redone (the mode hint is sticky, BEV_MODE_TTL)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    p = bev_amd.params_for_sensor("HDL_64E")
+    n = 1000
+
+    def make(f):
+        kind = (f // 32) % 3
+        if kind == 0:
+            return synth.sweep(p, f, keep=0.98, n_dup=5000)
+        return synth.structured(p, f, keep=0.98) if kind == 1 else synth.firing_real(p, f, noret=0.03)
+
+    with ThreadPoolExecutor(16) as ex:
+        frames = list(ex.map(make, range(n)))
+    outs = _run(p, frames, sub_batch=500, lanes=2, repeats=2, want_info=True)
+    modes = outs[3][:, 1]
+    assert not (modes == 2).any() and set(np.unique(modes)) == {1, 3, 5}, np.unique(modes, return_counts=True)
+    _every_frame(p, frames, outs)
+
+
+def test_many_small_calls_without_a_synchronisation():
+    """The later stages of a call's last sub-batches ride in the NEXT call's launches (or bev_synchronize launches them):
+    thirty calls of one to three small sub-batches each, never synchronised in between, go three times round the eight
+    workspace sets and alternate between the two streams; every call has its own buffers; one bev_synchronize at the end;
+    every frame of every call against the oracle.  (A bare device synchronisation is NOT enough — include/bev_mi355x.h.)"""
+    import torch
+
+    p = bev_amd.params_for_sensor("HDL_32E")
+    sb = 5
+    sp = orc.sensor_from_params(p)
+    dev = torch.device("cuda:0")
+    S, M, L = p.slots, p.mat_size, p.n_layers
+    sizes = [1 + (7 * i) % (3 * sb) for i in range(30)]
+    calls = []
+    seed = 12000
+    for n in sizes:
+        frames = []
+        for _ in range(n):
+            k = seed % 4
+            frames.append(synth.sweep(p, seed, keep=0.9, n_dup=200) if k == 0 else synth.structured(p, seed, 0.9) if k == 1
+                          else synth.firing_order(p, seed) if k == 2 else synth.adversarial(p, 20000, 3, False))
+            seed += 1
+        calls.append(frames)
+    ctx = bev_amd.BevContext(p, device=0, max_batch=sb, max_points=max(len(f) for c in calls for f in c))
+    staged = []
+    for frames in calls:
+        offs = np.zeros(len(frames) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(f) for f in frames])
+        d_in = torch.from_numpy(np.concatenate(frames).view(np.uint8).reshape(-1)).to(dev)
+        outs = [torch.zeros(len(frames) * k, dtype=torch.uint8, device=dev) for k in (S * 32, L * M * M, M * M)]
+        staged.append((offs, d_in, outs))
+    torch.cuda.synchronize()
+    try:
+        for offs, d_in, outs in staged:
+            ctx.process_device(len(offs) - 1, d_in.data_ptr(), offs, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr())
+        ctx.synchronize()
+        for c, (frames, (_, _, outs)) in enumerate(zip(calls, staged)):
+            got = [o.cpu().numpy() for o in outs]
+            for i, pts in enumerate(frames):
+                o_ord, _, o_multi, o_single = orc.process_frame(sp, pts, want_gm=False)
+                assert got[0][i * S * 32:(i + 1) * S * 32].tobytes() == o_ord.tobytes(), (c, i)
+                assert got[1][i * L * M * M:(i + 1) * L * M * M].tobytes() == o_multi.tobytes(), (c, i)
+                assert got[2][i * M * M:(i + 1) * M * M].tobytes() == o_single.tobytes(), (c, i)
+    finally:
+        ctx.close()
