@@ -106,14 +106,14 @@ __device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, cons
                         if (sl1 != (uint32_t)(i + 1) && rc1[u] != 0u) struct_bad = 1u;
                         if (rc1[u] == 0u) struct_zero = 1u;
                         if (row1 != (uint32_t)(i + 1) % (uint32_t)g.N) cm_bad = 1u;
-                        if (col1 < (uint32_t)g.H && col1 - (uint32_t)(i + 1) / (uint32_t)g.N > 8u) cm_not_plain = 1u; /* (the plain sweep: column = firing + 0 .. 8) */
+                        if (col1 < (uint32_t)g.H && col1 - (uint32_t)(i + 1) / (uint32_t)g.N > (uint32_t)kPlainDisp) cm_not_plain = 1u; /* (the plain sweep: column = firing + 0 .. kPlainDisp) */
                     }
                 }
                 if (can_struct) {
                     if (sl0 != (uint32_t)i && rc[u] != 0u) struct_bad = 1u;
                     if (rc[u] == 0u && i >= 1) struct_zero = 1u;
                     if (row != (uint32_t)i % (uint32_t)g.N) cm_bad = 1u;
-                    if (col < (uint32_t)g.H && col - (uint32_t)i / (uint32_t)g.N > 8u) cm_not_plain = 1u;
+                    if (col < (uint32_t)g.H && col - (uint32_t)i / (uint32_t)g.N > (uint32_t)kPlainDisp) cm_not_plain = 1u;
                 }
                 if (can_cm_gen) {
                     cmcol[k] = (uint16_t)(rc[u] >> 16);
@@ -384,7 +384,10 @@ __global__ __launch_bounds__(1024) void k_verdict(FrameInfo *info, int nf, uint3
     for (int f = threadIdx.x; f < nf; f += 1024) {
         FrameInfo fi = info[f];
         mask |= 1u << (fi.mode & 31u);
-        bool bad_stream = (fi.mode == kFrameStream || fi.mode == kFrameColMajor || fi.mode == kFrameColMajorGen) && ((fi.failed & kInfoFailed) != 0u || fi.consumed != fi.T);
+        /* (sorted prefixes and the plain sweep only ever raise kInfoFailed: any bit fails them; the general firing order also
+         * raises kInfoCmUsed / kInfoCmStray, looked at below) */
+        bool bad_stream = ((fi.mode == kFrameStream || fi.mode == kFrameColMajor) && (fi.failed != 0u || fi.consumed != fi.T)) ||
+                          (fi.mode == kFrameColMajorGen && ((fi.failed & kInfoFailed) != 0u || fi.consumed != fi.T));
         /* firing order: where a strip's wrap-around halo fell back on column 0 (BatchMultiBevGen.cpp:146-149; rare: the upper
          * point's intensity is -1) it must have taken the record that strip 0 — which hears of every no-return record of the
          * row — put there */

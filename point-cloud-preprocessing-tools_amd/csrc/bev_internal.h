@@ -78,11 +78,13 @@ struct FrameDesc {
  *                  walk reads the records in place, once, coalesced, checks every one of them, and learns on the way
  *                  whether an all-zero record exists — which k_probe had to guess from its samples (the guess decides
  *                  slot 0 before the walk has seen the frame; a wrong guess is a failed frame);
- *   kFrameColMajor the input is S returns in firing order, what the MulRan selector writes
- *                  (MulranPointCloudSelect.cpp:112-130): position k holds beam k % N of firing k / N, its column is the
- *                  firing's number plus 0 .. 8 (or out of range: dropped).  The walk fetches a strip's firings band by
- *                  band (two rows of a firing are one 64-byte sector), settles the last writer of every slot in an LDS
- *                  index row and checks every record it fetches. */
+ *   kFrameColMajor the input is S returns in firing order, the PLAIN sweep (BASELINE config 3): position k holds beam
+ *                  k % N of firing k / N, its column is the firing's number plus 0 .. kPlainDisp (or out of range:
+ *                  dropped).  The walk fetches a strip's firings band by band (two rows of a firing are one 64-byte
+ *                  sector), settles the last writer of every slot in an LDS index row and checks every record it fetches;
+ *   kFrameColMajorGen  ... what the MulRan selector writes for real sweeps (MulranPointCloudSelect.cpp:112-130): any start
+ *                  azimuth, either direction, a base column per row (staggered beams) + 0 .. kColMaxDisp, no-return
+ *                  records in column 0 (see the constants below; BatchPtrs::cm_par / cm_sync are this mode's alone). */
 enum : uint32_t { kFrameGeneral = 0, kFrameStream = 1, kFrameRedo = 2, kFrameStructured = 3, kFrameColMajor = 4, kFrameColMajorGen = 5 };
 __host__ __device__ inline bool frame_read_in_place(uint32_t mode) { return mode == kFrameStream || mode == kFrameStructured || mode == kFrameColMajor || mode == kFrameColMajorGen; }
 struct FrameInfo {
@@ -95,7 +97,7 @@ struct FrameInfo {
 };
 constexpr uint32_t kInfoFailed = 1u, kInfoZeroSeen = 2u, kInfoZeroGuess = 4u;
 constexpr uint32_t kInfoCmStray = 8u; /* firing-order frames whose strips do not talk: a strip other than 0 owns a no-return record: k_verdict checks that it would not have won column 0 */
-constexpr uint32_t kInfoCmUsed = 2u; /* firing-order frames: a wrap-around halo fell back on column 0 somewhere: k_verdict compares what it took with what strip 0 put there */
+constexpr uint32_t kInfoCmUsed = 16u; /* (a bit of its own: round 5 shared kInfoZeroSeen's, told apart by the frame's mode) firing-order frames: a wrap-around halo fell back on column 0 somewhere: k_verdict compares what it took with what strip 0 put there */
 /* k_probe looks at every 63rd point of a frame (odd: no resonance with firing orders of 2^k beams) — at every 127th of a DENSE
  * sweep (at least nine tenths as many points as slots, and not exactly S records: those may be structured clouds or firing
  * orders, whose analysis wants its samples): the position of a slot between two samples is interpolated, its error grows with
@@ -112,6 +114,7 @@ constexpr int kTailBuckets = 2048;  /* (row, strip) pairs of a frame that k_prob
  * u = +-firing mod H (the sweep's direction) a return of row r has column (u + B[r] + 0 .. kColMaxDisp) mod H, B[r] the
  * row's base (start azimuth + the beam's azimuth offset), or is out of range (>= H: dropped), or sits in column 0 whatever
  * its firing (a no-return record: x = y = 0 -> atan2(0, 0) = 0, MulranPointCloudSelect.cpp:123-125). */
+constexpr int kPlainDisp = 8;        /* the PLAIN sweep (kFrameColMajor): column = firing + 0 .. kPlainDisp, or >= H (k_probe's test and k_walk<4>'s check) */
 constexpr int kColMaxDisp = 12;      /* (a row's displacements may spread over 8 columns and still leave k_probe, which sees every 63rd record, two columns of slack on either side) */
 constexpr int kCmSpread = 18;        /* the rows' bases lie within this many columns of each other (an OS1-64's four laser columns: +-9) */
 constexpr int kCmProbeDisp = kColMaxDisp; /* spread of a row's SAMPLED displacements that k_probe accepts; what is left of kColMaxDisp is put half below, half above them, for the records it did not see */
@@ -161,8 +164,8 @@ struct BatchPtrs {
     uint32_t *est;               /* [nf][strips][N]: stream frames: estimated input position of slot (r, first column of strip - 2) */
     uint32_t *tail_list;         /* [nf][N][strips][kTailCap]: stream frames: column offset | input index << 8 of the tail points (nullptr: no stream mode) */
     uint32_t *tail_cnt;          /* [nf][strips][N] */
-    int32_t *cm_par;             /* [nf][kCmParWords]: kFrameColMajor: the frame's direction and row bases (k_probe) */
-    uint32_t *cm_sync;           /* [nf][kCmSyncWords]: kFrameColMajor, zeroed by k_probe: per band of two rows and strip: kCmUsedBit | the last no-return firing + 1 of either row
+    int32_t *cm_par;             /* [nf][kCmParWords]: kFrameColMajorGen: the frame's direction and row bases (k_probe) */
+    uint32_t *cm_sync;           /* [nf][kCmSyncWords]: kFrameColMajorGen, zeroed by k_probe: per band of two rows and strip: kCmUsedBit | the last no-return firing + 1 of either row
                                   * that the strip owns; per row: the firing + 1 whose record strip 0 put into column 0; per row: kCmUsedBit | the firing + 1 that the
                                   * strip with the wrap-around halo took for column 0 when column H - 2 fell back on it */
     uint32_t *winner;            /* [nf][S]  (win_tag << win_shift) | index+1 of the last input point per slot */
@@ -228,10 +231,10 @@ size_t stage_lds_bytes(const Geometry &g, int source);
 /* launchers (bev_kernels.hip) — all asynchronous on `st` */
 /* the frames that are not read in place: general ones and (after k_verdict) those whose verification failed */
 void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t max_pts, bool thin, hipStream_t st);
-/* the column walk.  source 0: through the winner table (frames of every mode but kFrameStream / kFrameStructured);
+/* the column walk.  source 0: through the winner table (the frames that are not read in place: pass kFrameGeneral);
  * 1: identity, b.pts already is the ordered cloud (bev_mark_ground); 2: in place (frames of mode kFrameStream: pass
- * mode = kFrameStream); 3: structured clouds (frames of mode kFrameStructured: pass that mode); 4: clouds in firing
- * order (kFrameColMajor) */
+ * mode = kFrameStream); 3: structured clouds (kFrameStructured); 4: the plain sweep in firing order (kFrameColMajor);
+ * 5: firing order in its general form (kFrameColMajorGen) — sources 2 .. 5 take the frames of the mode passed */
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int source, uint32_t mode, hipStream_t st);
 void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st);
 void launch_verdict(const Geometry &g, const BatchPtrs &b, int nf, uint32_t *host_hint, hipStream_t st);

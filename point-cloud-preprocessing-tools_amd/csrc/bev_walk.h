@@ -83,7 +83,7 @@ constexpr int kBandRows = 2;
 /* the PLAIN sweep (kFrameColMajor: starts at azimuth 0, turns forward, column = firing + 0 .. 8, no no-return records; BASELINE
  * config 3) keeps round 4's walk: a thread per firing from kColLead firings before the strip's first own column, side windows of
  * the first / last kPlainSide firings, 50 KB of LDS.  Everything else in firing order takes the general form below (kFrameColMajorGen). */
-constexpr int kPlainDisp = 8, kColLead = 2 + kPlainDisp, kPlainSide = 16;
+constexpr int kColLead = 2 + kPlainDisp, kPlainSide = 16;
 constexpr int kPlainBuf = kStripThreads * 32 * kBandRows + 2 * kPlainSide * 32 * kBandRows; /* one band buffer: the band, the flat-rule window, the wrap-around window */
 static_assert(kPlainSide * 2 * kBandRows == 64 && kStripVirt + kPlainDisp <= kStripThreads && kPlainDisp + 2 <= kPlainSide, "the plain sweep's windows");
 constexpr int kSideFirings = 32; /* firings of the side area: the wrap-around halo's window or strip 0's flat-index halo's */
@@ -98,7 +98,7 @@ constexpr uint32_t kLocExt = kStripThreads, kLocSide = kLocExt + kCmExt, kLocSpe
 static_assert(kLocSpecial < (1u << kLocBits) && kCmExt * 2 * kBandRows == 64, "location bits; the extra firings of a band are one LDS-DMA instruction");
 static_assert(kStripVirt + kColMaxDisp + kCmSpread <= kStripThreads + kCmExt && 2 + kColMaxDisp + kCmSpread <= kSideFirings,
               "firings a strip's columns can come from");
-constexpr uint32_t kCmSpins = 1u << 20;
+constexpr uint32_t kCmSpins = 1u << 12; /* polls (a sleep and an agent-scope load each, a microsecond or two) before strip 0 gives up on the others' reports: milliseconds, where a walk workgroup lives a fifth of one */
 constexpr int kWinPos = kStripThreads; /* in-place source: window positions of a (row, strip), one per thread: est - kWinLead ... */
 constexpr int kWinLead = 12;
 constexpr int kWrapPos = 16;       /* ... the last strip's wrap-around halo: positions around the row's start */
@@ -575,8 +575,10 @@ __device__ __forceinline__ void walk_body(char *arena, const BatchPtrs &b, const
             w = (l < words && (lane < 32 || more)) ? __hip_atomic_load(cm_pub() + ((size_t)(band + 2 * (lane >> 5)) * kCmMaxStrips + 1) * 2 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                                       : kCmUsedBit;
             if (__ballot((w & kCmUsedBit) == 0u) == 0ull) break;
-            if (++spins > kCmSpins) { /* (never seen; the frame is redone the general way) */
+            if (++spins > kCmSpins) { /* (never seen; the frame is redone the general way) and strip 0 stops listening: one
+                                       * bounded wait per frame, not one per band (advisor, round 5) */
                 failed |= 1u;
+                cm_f &= ~(uint32_t)kCfListens;
                 w = 0u;
                 break;
             }
@@ -884,7 +886,10 @@ __device__ __forceinline__ void walk_body(char *arena, const BatchPtrs &b, const
             if (kCmGen && (cm_f & kCfReports) && (r % kBandRows) == 0 && r < N && tid < kBandRows) {
                 const uint32_t nr = cm_nr_l[tid];
                 cm_nr_l[tid] = 0u;
+                (void)nr;
+#ifndef BEV_EXP_NO_REPORTS /* (developer build, scripts/cm_timeout_check.py: the reports never arrive — strip 0 must give up, once, and the frame be redone) */
                 __hip_atomic_store(cm_pub() + ((size_t)(r / kBandRows) * kCmMaxStrips + strip) * 2 + tid, kCmUsedBit | nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             }
             if (kCmGen && (cm_f & kCfListens)) { /* (uniform) */
                 if ((r % kBandRows) == 0) { /* after this step's memory wait: the reports asked for two steps ago, for the band two steps on;

@@ -138,3 +138,65 @@ def test_real_sweep_defects_are_caught():
     b2["row"][64 * 500 + 9] = 10
     modes, info = _run(p, [a, b2, good])
     assert modes[2] == COLMAJOR_GEN and modes[0] in (REDO, GENERAL) and modes[1] in (REDO, GENERAL), info
+
+
+# ---- round 6 (advisor, round 5): deterministic cases for the branches the soaks reached only by chance
+def _unsampled(k):
+    """a position k_probe does not look at (frames of exactly S records: every 63rd and its successor)"""
+    while k % 63 in (0, 1):
+        k += 1
+    return k
+
+
+def test_a_plain_sweep_with_one_return_nine_columns_off_is_redone():
+    """the plain sweep's walk (mode 4) takes column = firing + 0 .. 8 (kPlainDisp); a single return at + 9 hidden from the
+    probe's samples: the probe says mode 4, the walk's check fails, the frame is redone — same outputs"""
+    p = bev_amd.params_for_sensor("OS1_64")
+    f = _displaced(p, 40, 8, 40)
+    k = _unsampled(64 * 300 + 11)
+    f["col"][k] = k // 64 + 9
+    modes, info = _run(p, [f, _displaced(p, 41, 8, 41)])
+    assert modes == [REDO, COLMAJOR], info
+
+
+def test_a_stray_no_return_record_that_would_win_column_zero_is_caught():
+    """A real sweep WITHOUT no-return records among the probe's samples is walked without the strips' talk (kCfQuiet).  One
+    no-return record (x = y = z = 0 -> column 0 of its row, MulranPointCloudSelect.cpp:123-125) at a position the probe does
+    not sample, in a firing the LAST strip owns, later in the input than the return strip 0 put into column 0 of that row:
+    the last writer wins (BatchMultiBevGen.cpp:112-115), so it must end up in column 0 — the strip that owns it leaves it in
+    cm_sync (kInfoCmStray), k_verdict sees that it beats strip 0's, the frame is redone.  The same record EARLIER than strip
+    0's winner changes nothing: the frame stays on route 5."""
+    p = bev_amd.params_for_sensor("OS1_64")
+    base = synth.firing_real(p, 51, noret=0.0, phase=0, direction=1, stagger=1.0)
+
+    def with_noret(firing, beam):
+        f = base.copy()
+        k = _unsampled(64 * firing + beam)
+        assert k // 64 == firing
+        for name in ("x", "y", "z"):
+            f[name][k] = 0.0
+        f["col"][k] = 0
+        return f
+
+    # beam 23 sits 9 columns BEHIND its firing's azimuth (beam mod 4 == 3): row 23's column 0 holds the return of firing 9, and a
+    # no-return record of firing 1000 — the last strip's: columns 944 ... — is later in the input; firing 0 is strip 0's own
+    late, early = with_noret(1000, 23), with_noret(0, 21)
+    modes, info = _run(p, [late, early, base])
+    assert modes[0] == REDO and modes[2] == COLMAJOR_GEN and modes[1] in (COLMAJOR_GEN, REDO), info
+
+
+@pytest.mark.parametrize("n,h,g", [(31, 300, 20), (16, 245, 8), (5, 473, 2), (33, 300, 20)])
+def test_real_sweeps_on_small_and_odd_sensors(n, h, g):
+    """two strips and an odd number of rows (a last band of one row; backward rotation puts its second row's pieces past the
+    frame's end), 237 < H < 252 (own_at != 16: the strips' counted ranges tile a short circle), a last strip of one column.
+    (33 rows: k_probe looks at every 63rd record and its successor — beams 0 and 1 mod 3 of a 33-beam sensor, never beam 2 mod 3:
+    rows it has no sample of take another row's base, staggered beams then fail the walk's checks and the frame is redone.
+    The stride is odd for the sake of 2^k beams; sensors whose beam count shares a factor with 63 go the general way.)"""
+    p = bev_amd.params_for_sensor("HDL_32E")
+    p.n_scan, p.horizon_scan, p.ground_upper_scan = n, h, g
+    frames = [synth.firing_real(p, 60, noret=0.05, direction=-1), synth.firing_real(p, 61, noret=0.0, direction=1),
+              _with_invalid(synth.firing_real(p, 62, noret=0.2, direction=-1, stagger=0.5), 62, 0.3),
+              synth.firing_real(p, 63, noret=0.01, phase=h - 1, direction=1)]
+    modes, info = _run(p, frames)
+    assert set(modes) <= {COLMAJOR_GEN, REDO}, (n, h, g, info)
+    assert COLMAJOR_GEN in modes or n == 33, (n, h, g, info)
