@@ -52,6 +52,9 @@ def main() -> int:
     ap.add_argument("--n-dup", type=int, default=int(os.environ.get("BEV_BENCH_NDUP", "5000")),
                     help="duplicates appended to every hdl64_sweep frame (BASELINE config 2: 5000; anything else is a "
                          "developer experiment and is named in config.workload)")
+    ap.add_argument("--layout-hint", default="none", choices=["none", "structured", "firing"],
+                    help="bev_set_layout_hint: the caller says how its clouds are laid out and k_probe does not look (verified by the "
+                         "walk like any guess); named in config.workload")
     ap.add_argument("--cpu-sample", type=int, default=400, help="frames timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
@@ -190,6 +193,9 @@ def main() -> int:
     d_single = torch.empty(count * M * M, dtype=torch.uint8, device=dev)
 
     ctx = bev_amd.BevContext(p, device=local_rank, max_batch=args.sub_batch, max_points=int(counts.max()))
+
+    if args.layout_hint != "none":
+        ctx.set_layout_hint(bev_amd.LAYOUT_STRUCTURED if args.layout_hint == "structured" else bev_amd.LAYOUT_FIRING_ORDER)
 
     def step():
         ctx.process_device(count, d_in.data_ptr(), offsets, d_ordered.data_ptr(), d_multi.data_ptr(),
@@ -421,7 +427,8 @@ def main() -> int:
             "data": "synthetic",
             "config": {"workload": f"{F} synthetic {args.workload} {args.sensor} clouds per GPU (mean {mean_pts:.0f} input pts, "
                                    f"{S} slots), single+multi BEV, device-resident" +
-                                   (f" [developer run: {n_dup} appended duplicates instead of 5000]" if args.workload == "hdl64_sweep" and n_dup != 5000 else ""),
+                                   (f" [developer run: {n_dup} appended duplicates instead of 5000]" if args.workload == "hdl64_sweep" and n_dup != 5000 else "") +
+                                   (f" [bev_set_layout_hint: {args.layout_hint}]" if args.layout_hint != "none" else ""),
                        "frames_per_gpu": F, "frames_per_step": F * world, "sub_batch": args.sub_batch, "sensor": args.sensor,
                        "algorithmic_bytes_per_frame": b_frame, "parallelism": f"frames x{world}"},
             "roofline": roofline,

@@ -215,6 +215,26 @@ void bev_yaw_translate_matrix(float tx, float ty, float tz, float yaw_deg, float
 int bev_project_xyzi(bev_ctx_t *ctx, int kind, const float *xyzi, uint32_t n, bev_point_t *out);
 size_t bev_project_out_points(int kind, uint32_t n); /* 0 for an unknown kind */
 
+/* ---- layout hint -------------------------------------------------------
+ * What the caller knows about how its clouds are laid out, so that the library need not look (k_probe reads every 63rd
+ * record of a frame to find out: 0.36 MB and 0.07 us of an HDL_64E frame).  Sticky per context; applies to frames of
+ * exactly S = n_scan * horizon_scan records, every other frame is probed as ever:
+ *   BEV_LAYOUT_STRUCTURED    what kitti_point_cloud_select writes (KittiPointCloudSelect.cpp:206-207,240) and what
+ *                            bev_project_xyzi(BEV_PROJECT_KITTI_HDL_64E) returns (that call sets this hint by itself):
+ *                            record i is the point of slot i, or all-zero;
+ *   BEV_LAYOUT_FIRING_ORDER  the plain sweep in firing order (BASELINE config 3): record k is beam k % n_scan of firing
+ *                            k / n_scan, its column the firing's number + 0 .. 8 or >= horizon_scan.  (What
+ *                            mulran_point_cloud_select writes for REAL sweeps — MulranPointCloudSelect.cpp:112-130: any
+ *                            start azimuth, either direction, staggered beams, no-return records — needs the sweep's
+ *                            direction and a base column per row, which k_probe measures: no hint for it.)
+ *   BEV_LAYOUT_UNKNOWN       (default) the library looks.
+ * The hint is a guess like the library's own: the walk checks every record it reads, a frame that is not what the hint
+ * said is done again the general way — a wrong hint costs time, never results (tests/test_gpu_structured.py). */
+#define BEV_LAYOUT_UNKNOWN 0
+#define BEV_LAYOUT_STRUCTURED 3
+#define BEV_LAYOUT_FIRING_ORDER 4
+int bev_set_layout_hint(bev_ctx_t *ctx, int layout);
+
 /* ---- measurement ------------------------------------------------------- */
 /* Sub-batches (max_batch frames) run as FUSED launches: one launch holds the column walk of sub-batch t and, as further
  * workgroups of the same grid, phase B of sub-batch t - 1, phase C of t - 2 and the rasters of t - 3, over four

@@ -66,6 +66,7 @@ class BevError(RuntimeError):
 
 
 _lib = None
+LAYOUT_UNKNOWN, LAYOUT_STRUCTURED, LAYOUT_FIRING_ORDER = 0, 3, 4  # bev_set_layout_hint
 
 # every symbol include/bev_mi355x.h declares
 ABI_SYMBOLS = [
@@ -74,7 +75,7 @@ ABI_SYMBOLS = [
     "bev_process_batch", "bev_process_device_resident", "bev_synchronize",
     "bev_order_cloud", "bev_mark_ground", "bev_multi_bev", "bev_single_bev",
     "bev_float_bev", "bev_float_bev_size", "bev_transform_cloud", "bev_yaw_translate_matrix", "bev_project_xyzi", "bev_project_out_points", "bev_host_alloc", "bev_host_free",
-    "bev_set_lanes", "bev_profile_enable", "bev_profile_reset", "bev_profile_get",
+    "bev_set_lanes", "bev_set_layout_hint", "bev_profile_enable", "bev_profile_reset", "bev_profile_get",
     "bev_debug_get_cell_avg", "bev_debug_get_frame_info", "bev_debug_get_code_overflow", "bev_debug_angle_predicate", "bev_abi_version",
 ]
 
@@ -135,6 +136,7 @@ def load_lib() -> C.CDLL:
     lib.bev_project_out_points.argtypes = [i32, u32]
     lib.bev_project_out_points.restype = C.c_size_t
     lib.bev_set_lanes.argtypes = [vp, i32]
+    lib.bev_set_layout_hint.argtypes = [vp, i32]
     lib.bev_profile_enable.argtypes = [vp, i32]
     lib.bev_profile_reset.argtypes = [vp]
     lib.bev_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32]
@@ -279,6 +281,10 @@ class BevContext:
         self._check(self.lib.bev_project_xyzi(self._h, kind, _ptr(xyzi) if n else None, n, _ptr(out) if n_out else None),
                     "bev_project_xyzi")
         return out
+
+    def set_layout_hint(self, layout: int):
+        """LAYOUT_UNKNOWN (the library looks), LAYOUT_STRUCTURED, LAYOUT_FIRING_ORDER: include/bev_mi355x.h"""
+        self._check(self.lib.bev_set_layout_hint(self._h, layout), "bev_set_layout_hint")
 
     # ---- measurement / test hooks ------------------------------------------
     def set_lanes(self, n: int) -> int:

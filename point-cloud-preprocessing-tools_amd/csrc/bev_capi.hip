@@ -147,6 +147,7 @@ struct bev_ctx {
     uint32_t *hint = nullptr;  /* mapped host words (k_verdict): [0] frames of the last verdict's sub-batch that were NOT read in place, [1] the modes k_probe gave its frames (bit = mode) */
     int mode_absent[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* looks at hint[1] since it last showed the mode (see run_pipeline) */
     int mode_ttl = 8;          /* a mode's in-place walk stays launched for this many sub-batches after a verdict last showed the mode (BEV_MODE_TTL) */
+    int layout_hint = 0;       /* bev_set_layout_hint: 0, kFrameStructured or kFrameColMajor */
     bool allow_stream = true;  /* sorted-prefix frames are read in place (k_probe); BEV_STREAM=0 turns it off, see bev_create */
     /* sub-batches whose later stages have not been launched yet, oldest first (see run_pipeline / flush_pending) */
     struct Pending {
@@ -594,7 +595,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
             b.win_tag = ln.win_gen;
             {   /* which frames are sorted up to a tail and can be read in place */
                 ProfScope ps(c, K_PROBE, nb, st);
-                launch_probe(g, b, nb, c->allow_stream, st);
+                launch_probe(g, b, nb, c->allow_stream, c->layout_hint, st);
             }
             /* The walks of the modes that read in place.  A mode's walk is launched unless the last mode_ttl looks at the
              * word k_verdict leaves in mapped host memory (the modes k_probe gave the frames of the last sub-batch whose
@@ -611,6 +612,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                     if (c->mode_absent[m] < c->mode_ttl) seen |= 1u << m;
                 }
             }
+            if (c->layout_hint) seen |= 1u << c->layout_hint; /* (the probe hands the hinted mode out whatever the last verdicts saw) */
             int rc = BEV_OK;
             if (c->allow_stream && ln.tail_list && (seen & (1u << kFrameStream))) /* frames k_probe found sorted up to a tail: read in place, verified */
                 rc = walk(K_GATHER_GROUND, 2, kFrameStream);
@@ -1195,6 +1197,7 @@ int bev_project_xyzi(bev_ctx_t *c, int kind, const float *xyzi, uint32_t n, bev_
     if ((size_t)n * 16 > (size_t)c->max_batch * c->geo.S * sizeof(bev_point_t)) return BEV_ERR_TOO_LARGE;
     if (n_out > c->st_in_elems) return BEV_ERR_TOO_LARGE;
     if (n) HIPCK(c, hipMemcpyAsync(d_raw, xyzi, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    if (kind == BEV_PROJECT_KITTI_HDL_64E) c->layout_hint = BEV_LAYOUT_STRUCTURED; /* what this call writes is a structured cloud (bev_set_layout_hint) */
     if (kind == BEV_PROJECT_KITTI_HDL_64E) {
         if (n == 0) { /* defined here, undefined in the reference: an empty file gives the all-zero structured cloud */
             HIPCK(c, hipMemsetAsync(c->st_in, 0, n_out * sizeof(bev_point_t), c->stream));
@@ -1287,6 +1290,14 @@ void bev_yaw_translate_matrix(float tx, float ty, float tz, float yaw_deg, float
     m[0] = c;    m[1] = 0.0f - s; m[2] = 0.0f;  m[3] = tx;
     m[4] = s;    m[5] = c;        m[6] = 0.0f;  m[7] = ty;
     m[8] = 0.0f; m[9] = 0.0f;     m[10] = one_minus_c + c; m[11] = tz;
+}
+
+int bev_set_layout_hint(bev_ctx_t *c, int layout)
+{
+    if (!c || (layout != BEV_LAYOUT_UNKNOWN && layout != BEV_LAYOUT_STRUCTURED && layout != BEV_LAYOUT_FIRING_ORDER)) return BEV_ERR_INVALID_ARG;
+    static_assert(BEV_LAYOUT_STRUCTURED == (int)kFrameStructured && BEV_LAYOUT_FIRING_ORDER == (int)kFrameColMajor, "the hint is the mode k_probe hands out");
+    c->layout_hint = layout;
+    return BEV_OK;
 }
 
 int bev_set_lanes(bev_ctx_t *c, int n)

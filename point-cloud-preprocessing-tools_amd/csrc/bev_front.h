@@ -37,7 +37,7 @@ struct ProbeLds {
     uint32_t first_bad, overflow, struct_bad, struct_zero, cm_bad, cm_not_plain;
 };
 static_assert(sizeof(ProbeLds) <= kSlotLdsBytes, "a quarter of a CU's LDS");
-__device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, const Geometry &g, int allow_stream, const int f)
+__device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, const Geometry &g, int allow_stream, int layout_hint, const int f)
 {
     TL_BEGIN;
     ProbeLds &lds_p = *reinterpret_cast<ProbeLds *>(arena);
@@ -52,6 +52,14 @@ __device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, cons
     const uint32_t ns = n ? (n - 1u) / stride + 1u : 0u;
     PH_DECL;
     PH();
+    /* The caller's layout hint (bev_set_layout_hint): a frame of exactly S records is TAKEN for a structured cloud / a plain
+     * sweep in firing order without a look at it — a guess like the samples', verified by the walk record by record and
+     * redone when wrong; a frame of another size is probed as ever.  (Structured: the guess that decides slot 0 is "some
+     * record after the first is all-zero" — what every KITTI sweep with a dropped return has, KittiPointCloudSelect.cpp:207.) */
+    if (allow_stream && n == (uint32_t)g.S && (layout_hint == (int)kFrameStructured || (layout_hint == (int)kFrameColMajor && g.N >= 2))) {
+        if (threadIdx.x == 0) b.info[f] = FrameInfo{n, (uint32_t)layout_hint, 0u, layout_hint == (int)kFrameStructured ? kInfoZeroGuess : 0u};
+        return;
+    }
     const bool can = allow_stream && n >= (uint32_t)kStreamMinPrefix && ns <= (uint32_t)kMaxSamples && g.N <= kStreamMaxRows &&
                      g.N * g.strips <= kTailBuckets && n < (1u << 24) && b.tail_list != nullptr;
     /* a structured cloud (kFrameStructured): exactly S records, every sampled one its own slot's point or empty */
@@ -361,10 +369,10 @@ __device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, cons
     TL_END(K_PROBE);
     PH_PRINT("probe samples prefix-end estimates tail-lists counts", tid == 0 && f == 100);
 }
-__global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g, int allow_stream)
+__global__ __launch_bounds__(kProbeThreads) void k_probe(BatchPtrs b, Geometry g, int allow_stream, int layout_hint)
 {
     __shared__ __attribute__((aligned(16))) char arena[sizeof(ProbeLds)];
-    probe_body(arena, b, g, allow_stream, (int)blockIdx.x);
+    probe_body(arena, b, g, allow_stream, layout_hint, (int)blockIdx.x);
 }
 
 

@@ -236,7 +236,7 @@ void launch_order_scan(const Geometry &g, const BatchPtrs &b, int nf, uint32_t m
  * mode = kFrameStream); 3: structured clouds (kFrameStructured); 4: the plain sweep in firing order (kFrameColMajor);
  * 5: firing order in its general form (kFrameColMajorGen) — sources 2 .. 5 take the frames of the mode passed */
 void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int source, uint32_t mode, hipStream_t st);
-void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st);
+void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, int layout_hint /* 0, kFrameStructured or kFrameColMajor */, hipStream_t st);
 void launch_verdict(const Geometry &g, const BatchPtrs &b, int nf, uint32_t *host_hint, hipStream_t st);
 void launch_gather_only(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);
 void launch_cell_sums(const Geometry &g, const BatchPtrs &b, int nf, hipStream_t st);

@@ -186,10 +186,10 @@ void launch_gather_ground(const Geometry &g, const BatchPtrs &b, int nf, int sou
     else if (source == kSrcColMajorGen) launch_walk<kSrcColMajorGen>(g, b, nf, mode, grid, st);
     else launch_walk<kSrcGather>(g, b, nf, mode, grid, st);
 }
-void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, hipStream_t st)
+void launch_probe(const Geometry &g, const BatchPtrs &b, int nf, bool allow_stream, int layout_hint, hipStream_t st)
 {
     if (nf == 0) return;
-    hipLaunchKernelGGL(k_probe, dim3(nf), dim3(kProbeThreads), 0, st, b, g, allow_stream ? 1 : 0);
+    hipLaunchKernelGGL(k_probe, dim3(nf), dim3(kProbeThreads), 0, st, b, g, allow_stream ? 1 : 0, layout_hint);
 }
 void launch_verdict(const Geometry &g, const BatchPtrs &b, int nf, uint32_t *host_hint, hipStream_t st)
 {

@@ -348,6 +348,22 @@ double BatchMultiBevGen::processFiles(const std::vector<std::string> &files, std
                 continue;
             }
         }
+        {   /* What the PCD parser can tell the library about the layout (bev_set_layout_hint): when every cloud of the batch
+             * has exactly S records and a few of them, spread over the first cloud, are each their slot's point or all-zero
+             * — what kitti_point_cloud_select writes, KittiPointCloudSelect.cpp:206-207,240 — the clouds are announced as
+             * structured and the library does not sample them; anything else: it looks by itself.  A wrong guess here costs
+             * time only: the walk checks every record. */
+            bool structured = nb > 0;
+            for (int i = 0; i < nb; ++i) structured = structured && (std::size_t)npts[i] == S;
+            for (std::size_t k = 0; structured && k < 64; ++k) {
+                const std::size_t at = k * (S / 64) + k; /* (an odd walk over rows and columns) */
+                if (at >= S) break;
+                const bev_point_t &q = pts[0][at];
+                const bool zero = q.x == 0.f && q.y == 0.f && q.z == 0.f && q.intensity == 0.f && q.row == 0 && q.col == 0;
+                structured = zero || (std::size_t)q.row * (std::size_t)params_.Horizon_SCAN + q.col == at;
+            }
+            (void)bev_set_layout_hint(ctx_, structured ? BEV_LAYOUT_STRUCTURED : BEV_LAYOUT_UNKNOWN);
+        }
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<char> done(nb, 1);
         int rc = bev_process_batch(ctx_, nb, pts.data(), npts.data(), ord.data(), mo.data(), so.data(), nullptr);

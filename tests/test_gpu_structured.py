@@ -188,3 +188,39 @@ def test_alternating_layouts_are_read_in_place_after_warm_up():
                 assert np.array_equal(multi[i], o_multi) and np.array_equal(single[i], o_single), (rnd, i)
     finally:
         ctx.close()
+
+
+def test_layout_hint_right_and_wrong():
+    """bev_set_layout_hint (round 6): frames of exactly S records are TAKEN for what the caller says they are — k_probe does
+    not look — and verified by the walk like any guess.  Right hint: read in place (mode 3 / 4).  Wrong hint (structured
+    clouds announced as firing order, firing order announced as structured, a complete structured cloud whose slot 0 the
+    hint's guess gets wrong): every frame is redone the general way (mode 2) — the same bytes as the oracle's.  Frames of
+    another size are probed as ever.  bev_project_xyzi(KITTI) sets the hint by itself."""
+    p = bev_amd.params_for_sensor("HDL_32E")
+    structured = [synth.structured(p, 300 + i, 0.9) for i in range(3)]
+    firing = [synth.firing_order(p, 310 + i) for i in range(3)]
+    sweeps = [synth.sweep(p, 320 + i, n_dup=200) for i in range(2)]
+    sp = orc.sensor_from_params(p)
+    ctx = bev_amd.BevContext(p, device=0, max_batch=16, max_points=max(len(f) for f in structured + firing + sweeps))
+
+    def run(frames, want):
+        ordered, multi, single, gm = ctx.process_batch(frames, want_ground_mat=True)
+        modes = [int(m) for m in ctx.frame_info(0, len(frames))[:, 1]]
+        for i, pts in enumerate(frames):
+            o_ord, o_gm, o_multi, o_single = orc.process_frame(sp, pts)
+            assert ordered[i].tobytes() == o_ord.tobytes() and np.array_equal(gm[i], o_gm), (want, i)
+            assert np.array_equal(multi[i], o_multi) and np.array_equal(single[i], o_single), (want, i)
+        assert modes == want, (modes, want)
+
+    try:
+        ctx.set_layout_hint(bev_amd.LAYOUT_STRUCTURED)
+        run(structured + sweeps, [STRUCTURED] * 3 + [STREAM] * 2)      # right; the sweeps (another size) are probed
+        run(firing, [REDO] * 3)                                          # wrong: redone
+        run([synth.structured(p, 330, 1.0)], [REDO])                    # a cloud without a single dropped return: slot 0 guessed wrong
+        ctx.set_layout_hint(bev_amd.LAYOUT_FIRING_ORDER)
+        run(firing, [COLMAJOR] * 3)
+        run(structured, [REDO] * 3)
+        ctx.set_layout_hint(bev_amd.LAYOUT_UNKNOWN)
+        run(structured + firing, [STRUCTURED] * 3 + [COLMAJOR] * 3)
+    finally:
+        ctx.close()
