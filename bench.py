@@ -40,12 +40,15 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU (BASELINE config: 1000)")
     ap.add_argument("--sensor", default=None)
-    ap.add_argument("--workload", default="hdl64_sweep", choices=["hdl64_sweep", "os1_firing", "oxford_concat", "hdl64_structured", "os1_firing_real", "mixed"],
+    ap.add_argument("--workload", default="hdl64_sweep", choices=["hdl64_sweep", "os1_firing", "oxford_concat", "hdl64_structured", "os1_firing_real", "mixed", "hdl64_shuffled"],
                     help="hdl64_sweep = BASELINE configs[1]/[3] (default, the graded metric); os1_firing = configs[2] "
                          "(MulRan-style unordered OS1_64); oxford_concat = configs[4] (HDL_32E, ~2M points per frame); "
                          "hdl64_structured = the same sweeps in the layout the reference's KITTI selector writes "
                          "(KittiPointCloudSelect.cpp:206-207,240: S records, dropped returns as all-zero records; not a "
-                         "BASELINE config, named in config.workload)")
+                         "BASELINE config, named in config.workload); hdl64_shuffled = configs[1]'s frames with their points in a "
+                         "random order (what getOrderedCloud's contract allows, BatchMultiBevGen.cpp:102-116: the general path — "
+                         "order scan + gather walk —, the route of any layout the probe does not recognise and of every frame that "
+                         "fails its checks; not the graded metric)")
     ap.add_argument("--sub-batch", type=int, default=int(os.environ.get("BEV_SUB_BATCH", "500")),
                     help="frames per sub-batch of the two-stage pipeline (500: two sub-batches per 1000-frame step; measured "
                          "300-309 k frames/s against 288-297 k at 256 on the same box)")
@@ -121,7 +124,7 @@ def main() -> int:
         raise SystemExit(f"{bev_amd.LIB_PATH} missing")
 
     default_sensor = {"hdl64_sweep": "HDL_64E", "os1_firing": "OS1_64", "oxford_concat": "HDL_32E",
-                      "hdl64_structured": "HDL_64E", "os1_firing_real": "OS1_64", "mixed": "HDL_64E"}[args.workload]
+                      "hdl64_structured": "HDL_64E", "os1_firing_real": "OS1_64", "mixed": "HDL_64E", "hdl64_shuffled": "HDL_64E"}[args.workload]
     args.sensor = args.sensor or default_sensor
     p = bev_amd.params_for_sensor(args.sensor)
     S, M, L = p.slots, p.mat_size, p.n_layers
@@ -136,7 +139,7 @@ def main() -> int:
     n_dup = args.n_dup
     n_sweeps = 60
     cap = {"hdl64_sweep": S + n_dup, "os1_firing": S, "oxford_concat": S * n_sweeps, "hdl64_structured": S,
-           "os1_firing_real": S, "mixed": S + n_dup}[args.workload]
+           "os1_firing_real": S, "mixed": S + n_dup, "hdl64_shuffled": S + n_dup}[args.workload]
     t_gen = time.time()
     host = np.empty((count, cap), dtype=bev_amd.POINT_DTYPE)
     counts = np.zeros(count, dtype=np.int64)
@@ -144,6 +147,10 @@ def main() -> int:
     def gen(i):
         if args.workload == "hdl64_sweep":
             counts[i] = len(synth.sweep(p, first + i, keep=0.98, n_dup=n_dup, out=host[i]))
+        elif args.workload == "hdl64_shuffled":
+            n_i = len(synth.sweep(p, first + i, keep=0.98, n_dup=n_dup, out=host[i]))
+            host[i, :n_i] = host[i, :n_i][np.random.default_rng(0x5EED0000 + first + i).permutation(n_i)]
+            counts[i] = n_i
         elif args.workload == "os1_firing":
             pts = synth.firing_order(p, first + i)
             host[i, :len(pts)] = pts
@@ -306,7 +313,7 @@ def main() -> int:
         pmc_prefix = {"k_walk": "k_walk<2,", "k_walk_general": "k_walk<0,", "k_walk_structured": "k_walk<3,",
                       "k_walk_colmajor": "k_walk<4,", "k_walk_colmajor_gen": "k_walk<5,"}.get(dom["name"], dom["name"])
         tag = "" if args.workload == "hdl64_sweep" else args.workload + "_"
-        rounds = ("r05", "r04") if args.workload != "hdl64_sweep" else ("r05", "r04", "r03", "r02")
+        rounds = ("r06", "r05", "r04") if args.workload != "hdl64_sweep" else ("r06", "r05", "r04", "r03", "r02")
         for name in (f"{r}_{tag}pmc_traffic.json" for r in rounds):
             pmc_file = REPO / "profiles" / name
             if not pmc_file.exists():

@@ -27,7 +27,7 @@ for name, out in (("bench_under_rocprof.log", "_bench_under_rocprof.json"), ("be
     if os.path.exists(p):
         json.dump(last_json_line(p), open(prefix + out, "w"), indent=1)
 
-for wl in ("os1_firing", "oxford_concat", "hdl64_structured", "os1_firing_real", "mixed"):
+for wl in ("os1_firing", "oxford_concat", "hdl64_structured", "os1_firing_real", "mixed", "hdl64_shuffled"):
     st = glob.glob(os.path.join(src, "trace_" + wl, "**", "*kernel_stats.csv"), recursive=True)
     if st:
         shutil.copy(st[0], f"{prefix}_{wl}_kernel_stats.csv")
@@ -91,14 +91,16 @@ def pmc_summary(dir_glob, out_path, frames, what):
 pmc_summary("pmc[0-9]*", prefix + "_pmc_traffic.json", pmc_frames, "bench.py --steps 1 --warmup 1 (the 1000-frame workload, sub-batch 500)")
 pmc_summary("pmcgen[0-9]*", prefix + "_pmc_traffic_general.json", pmc_frames,
             "BEV_STREAM=0 bench.py --steps 1 --warmup 1 (the 1000-frame workload through the GENERAL path: order scan + gather walk)")
-for wl in ("os1_firing", "hdl64_structured", "os1_firing_real"):
+pmc_summary("pmcf[0-9]*", prefix + "_pmc_traffic_fused.json", pmc_frames,
+            "bench.py --steps 1 --warmup 1 with FUSED launches (k_stage: the configuration of the timed region; no BEV_LANES=1)")
+for wl in ("os1_firing", "hdl64_structured", "os1_firing_real", "hdl64_shuffled"):
     pmc_summary(f"pmc_{wl}[0-9]*", f"{prefix}_{wl}_pmc_traffic.json", pmc_frames, f"bench.py --steps 1 --warmup 1 --workload {wl}")
 pmc_summary("pmc_oxford_concat[0-9]*", prefix + "_oxford_concat_pmc_traffic.json", pmc_frames // 10, "bench.py --steps 1 --warmup 1 --workload oxford_concat --frames 100")
 # the bench lines of THIS run carry the traffic of THIS run's PMC passes (bench.py itself can only look at what was committed
 # before it ran: the counters are collected after the bench line is printed)
 PREFIX = {"k_walk": "k_walk<2,", "k_walk_general": "k_walk<0,", "k_walk_structured": "k_walk<3,", "k_walk_colmajor": "k_walk<4,",
           "k_walk_colmajor_gen": "k_walk<5,"}
-for tag in ("", "os1_firing_", "hdl64_structured_", "os1_firing_real_", "oxford_concat_"):
+for tag in ("", "os1_firing_", "hdl64_structured_", "os1_firing_real_", "oxford_concat_", "hdl64_shuffled_"):
     pmc_path = f"{prefix}_{tag}pmc_traffic.json"
     if not os.path.exists(pmc_path):
         continue

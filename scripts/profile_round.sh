@@ -2,7 +2,7 @@
 #   default : plain bench line (with CPU baseline) + rocprofv3 kernel trace/stats of the same command with one lane
 #   pmc     : + the PMC passes (one counter group per run) on the SAME 1000-frame workload
 #   pmcothers: + FETCH_SIZE / WRITE_SIZE passes of the general path (BEV_STREAM=0) and of os1_firing / hdl64_structured
-#   others  : + bench line and kernel stats of BASELINE configs 3 (os1_firing) and 5 (oxford_concat), of hdl64_structured, os1_firing_real and mixed
+#   others  : + bench line and kernel stats of BASELINE configs 3 (os1_firing) and 5 (oxford_concat), of hdl64_structured, os1_firing_real, mixed and hdl64_shuffled (the general path)
 #   repeat  : + the graded workload and hdl64_structured five times each, unprofiled, on the same box -> repeat.txt
 # The libraries are built ONCE up front; every profiled command is `rocprofv3 ... -- python3 bench.py --no-build`, so
 # nothing is spawned from a process the profiler has already attached to the GPU.
@@ -14,7 +14,7 @@ python3 -c "import __graft_entry__ as g; g.build()" || exit 1
 # 1. plain bench first (with the CPU baseline): the GPU slows down by 5-10 % once the profiled runs have warmed it up
 timeout 900 python3 bench.py --no-build --steps 20 --warmup 5 > $OUT/bench.log 2>$OUT/bench.err || exit 1
 tail -c 600 $OUT/bench.log
-# 2. kernel trace + stats of the bench command line with ONE lane (BEV_LANES=1): every launch runs back to back, like in
+# 2. kernel trace + stats of the bench command line with serial launches (BEV_LANES=1): every kernel a launch of its own, back to back, like in
 #    bench.py's roofline pass, so AverageNs is comparable with roofline.avg_launch_ms
 BEV_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-build --steps 5 --warmup 2 --no-cpu > $OUT/bench_under_rocprof.log 2>$OUT/bench_under_rocprof.err || exit 1
 for w in "$@"; do
@@ -26,6 +26,13 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
   i=$((i+1))
   BEV_LANES=1 timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -- python3 $ARGS > $OUT/pmc$i.log 2>&1 || exit 1
 done
+# 3a. the same workload as the timed region runs it — fused launches (k_stage), no BEV_LANES=1: the bytes of the WHOLE path in
+#     the configuration the headline comes from (one kernel name: the per-stage split is the serial passes' above)
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcf$i -- python3 $ARGS > $OUT/pmcf$i.log 2>&1 || exit 1
+done
 fi
 if [ "$w" = pmcothers ]; then
 # 3b. HBM traffic (FETCH_SIZE, WRITE_SIZE: two passes each) of the general path on the headline workload and of the other layouts
@@ -33,7 +40,7 @@ i=0
 for set in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   BEV_STREAM=0 BEV_LANES=1 timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmcgen$i -- python3 bench.py --no-build --steps 1 --warmup 1 --no-cpu --no-profile > $OUT/pmcgen$i.log 2>&1 || exit 1
-  for wl in os1_firing hdl64_structured os1_firing_real oxford_concat; do
+  for wl in os1_firing hdl64_structured os1_firing_real oxford_concat hdl64_shuffled; do
     F=1000; if [ $wl = oxford_concat ]; then F=100; fi
     BEV_LANES=1 timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/pmc_${wl}$i -- python3 bench.py --no-build --steps 1 --warmup 1 --no-cpu --no-profile --workload $wl --frames $F > $OUT/pmc_${wl}$i.log 2>&1 || exit 1
   done
@@ -46,7 +53,7 @@ for rep in 1 2 3 4 5; do for wl in hdl64_sweep hdl64_structured; do
 done; done
 fi
 if [ "$w" = others ]; then
-for wl in os1_firing oxford_concat hdl64_structured os1_firing_real mixed; do
+for wl in os1_firing oxford_concat hdl64_structured os1_firing_real mixed hdl64_shuffled; do
   F=1000; if [ $wl = oxford_concat ]; then F=100; fi
   timeout 900 python3 bench.py --no-build --steps 20 --warmup 5 --workload $wl --frames $F --cpu-sample 50 > $OUT/bench_$wl.log 2>$OUT/bench_$wl.err || exit 1
   BEV_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -- python3 bench.py --no-build --steps 3 --warmup 1 --no-cpu --workload $wl --frames $F > $OUT/bench_under_rocprof_$wl.log 2>&1 || exit 1

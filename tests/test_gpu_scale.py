@@ -300,3 +300,24 @@ def test_many_small_calls_without_a_synchronisation():
                 assert got[2][i * M * M:(i + 1) * M * M].tobytes() == o_single.tobytes(), (c, i)
     finally:
         ctx.close()
+
+
+def test_shuffled_sweeps_at_launch_size_every_frame_matches_oracle():
+    """getOrderedCloud's actual contract is ANY input order (BatchMultiBevGen.cpp:102-116, last writer wins): BASELINE
+    configs[1]'s 1000 HDL_64E frames with their points in a random order (`bench.py --workload hdl64_shuffled`) go the
+    general way — order scan + gather walk, the route of every layout the probe does not recognise and of every frame that
+    fails its checks — at sub-batch 500: EVERY frame against the oracle, every frame of the last sub-batch on route 0."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    p = bev_amd.params_for_sensor("HDL_64E")
+    n = 1000
+
+    def make(f):
+        pts = synth.sweep(p, f, keep=0.98, n_dup=5000)
+        return pts[np.random.default_rng(0x5EED0000 + f).permutation(len(pts))]
+
+    with ThreadPoolExecutor(16) as ex:
+        frames = list(ex.map(make, range(n)))
+    outs = _run(p, frames, sub_batch=500, lanes=2, repeats=2, want_info=True)
+    assert (outs[3][:, 1] == 0).all(), np.unique(outs[3][:, 1], return_counts=True)
+    _every_frame(p, frames, outs)
