@@ -237,15 +237,16 @@ int bev_set_layout_hint(bev_ctx_t *ctx, int layout);
 
 /* ---- measurement ------------------------------------------------------- */
 /* Sub-batches (max_batch frames) run as FUSED launches: one launch holds the column walk of sub-batch t and, as further
- * workgroups of the same grid, phase B of sub-batch t - 1, phase C of t - 2 and the rasters of t - 3, over four
- * workspace sets; every kernel has one workgroup shape (256 threads, a quarter of a CU's LDS and registers).
+ * workgroups of the same grid, phase B of an earlier sub-batch, phase C of the one before that and the rasters of the one
+ * before that; the launches alternate between two streams of equal priority (a sub-batch's stages stay on its stream),
+ * over eight workspace sets; every kernel has one workgroup shape (256 threads, a quarter of a CU's LDS and registers).
  * bev_set_lanes(ctx, 1) makes every kernel a launch of its own, back to back (clean per-kernel durations for
  * profiling; the same device code); bev_set_lanes(ctx, n > 1) switches back.  Returns the number of workspace sets now
- * in rotation (1 or 4), or a negative status.  Environment of bev_create: BEV_LANES=1 starts serial; BEV_STREAM=0
+ * in rotation (1 or 8), or a negative status.  Environment of bev_create: BEV_LANES=1 starts serial; BEV_STREAM=0
  * sends every frame through the general path (order scan + gather walk); BEV_MODE_TTL=n: sub-batches for which a
  * layout's walk stays launched after the workspace set last saw the layout (default 8); BEV_CODE_CAP=n: entries of a
- * raster-band code list (tests); BEV_STAGE_LEAD=n: group slots by which a fused launch's walk workgroups precede its
- * other stages' (default 12; placement only).  These are all the knobs the library reads. */
+ * raster-band code list (tests); BEV_STAGE_STREAMS=n (1 .. 4, default 2): streams the fused launches take turns on, with
+ * 4 n workspace sets.  These are all the knobs the library reads. */
 int bev_set_lanes(bev_ctx_t *ctx, int n);
 
 #define BEV_MAX_KERNELS 16

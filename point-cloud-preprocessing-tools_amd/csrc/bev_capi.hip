@@ -39,7 +39,8 @@ struct ProfSlot {
  * sub-batches in turn (k_stage, see run_pipeline), so eight workspace sets ("lanes", the name rounds 2-5 gave them when
  * each also had a stream) go round.  Lane 0 doubles as
  * the workspace of the single-cloud entry points. */
-constexpr int kMaxLanes = 8;
+constexpr int kMaxStageStreams = 4;
+constexpr int kMaxLanes = 4 * kMaxStageStreams;
 struct Lane {
     FrameInfo *info = nullptr;  /* per frame: how its points reach their slots (k_probe / k_verdict) */
     uint32_t *est = nullptr;    /* stream frames: estimated input position of every (row, strip)'s first slot */
@@ -131,19 +132,19 @@ struct bev_ctx {
 
     /* sub-batch workspace sets; the aliases below are lane 0's */
     Lane lanes[kMaxLanes];
-    int n_lanes = kMaxLanes;
+    int n_lanes = 8; /* 4 * n_stage_streams */
     /* fused launches alternate between two streams: sub-batch s on stage_st[s % 2], its workspace set s % 8 (always the
      * same stream's), its later stages in that stream's next three launches — a launch's tail is filled by the other
      * stream's launch, and nothing but the order of launches on ONE stream ever orders two stages of one sub-batch */
-    hipStream_t stage_st[2] = {nullptr, nullptr};
-    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    hipStream_t stage_st[kMaxStageStreams] = {};
+    hipEvent_t stage_ev[kMaxStageStreams] = {};
     hipEvent_t fork_ev = nullptr;
-    int n_stage_streams = 2;   /* BEV_STAGE_STREAMS=1: everything on one stream (a launch's tail stands empty) */
+    int n_stage_streams = 2;   /* BEV_STAGE_STREAMS=1 .. 4 (1: a launch's tail stands empty; 3, 4: measured like 2, with 12 / 16 workspace sets) */
     unsigned sub_seq = 0;      /* sub-batches so far */
     /* fused: a sub-batch's stages ride in consecutive k_stage launches beside the stages of its neighbours (run_pipeline);
      * serial (BEV_LANES=1, bev_set_lanes(ctx, 1)): every kernel a launch of its own, back to back — per-kernel durations */
     bool fused = true;
-    int stage_lead = 0;        /* BEV_STAGE_LEAD: group slots by which a launch's walk workgroups precede its other stages' */
+    int stage_lead = 0;        /* group slots by which a launch's walk workgroups precede its other stages' (0, 4, 12, 24, 32 measured the same) */
     uint32_t *hint = nullptr;  /* mapped host words (k_verdict): [0] frames of the last verdict's sub-batch that were NOT read in place, [1] the modes k_probe gave its frames (bit = mode) */
     int mode_absent[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* looks at hint[1] since it last showed the mode (see run_pipeline) */
     int mode_ttl = 8;          /* a mode's in-place walk stays launched for this many sub-batches after a verdict last showed the mode (BEV_MODE_TTL) */
@@ -443,7 +444,7 @@ int advance_pending(bev_ctx *c, int q)
 /* the context's stream continues behind everything the stage streams hold */
 int join_stage_streams(bev_ctx *c)
 {
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < kMaxStageStreams; ++q) {
         HIPCK(c, hipEventRecord(c->stage_ev[q], c->stage_st[q]));
         HIPCK(c, hipStreamWaitEvent(c->stream, c->stage_ev[q], 0));
     }
@@ -453,7 +454,7 @@ int join_stage_streams(bev_ctx *c)
 int flush_pending(bev_ctx *c)
 {
     while (!c->pending.empty()) {
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < kMaxStageStreams; ++q) {
             bool any = false;
             for (const bev_ctx::Pending &p : c->pending) any = any || p.q == q;
             if (!any) continue;
@@ -500,7 +501,7 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         if (rc != BEV_OK) return rc;
     } else if (fork) {
         HIPCK(c, hipEventRecord(c->fork_ev, c->stream));
-        for (int q = 0; q < 2; ++q) HIPCK(c, hipStreamWaitEvent(c->stage_st[q], c->fork_ev, 0));
+        for (int q = 0; q < kMaxStageStreams; ++q) HIPCK(c, hipStreamWaitEvent(c->stage_st[q], c->fork_ev, 0));
     }
 
     int ds = 0;
@@ -802,9 +803,8 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         /* BEV_LANES=1: serial launches from the start (what bev_set_lanes(ctx, 1) switches to) */
         const char *e = getenv("BEV_LANES");
         c->fused = !(e && atoi(e) == 1);
-        if (const char *ld = getenv("BEV_STAGE_LEAD")) c->stage_lead = std::max(0, atoi(ld));
-        if (const char *ss = getenv("BEV_STAGE_STREAMS")) c->n_stage_streams = atoi(ss) == 1 ? 1 : 2;
-        if (const char *dr = getenv("BEV_DESC_RING")) c->desc_ring = std::max(1, std::min(kDescRing, atoi(dr)));
+        if (const char *ss = getenv("BEV_STAGE_STREAMS")) c->n_stage_streams = std::max(1, std::min(kMaxStageStreams, atoi(ss)));
+        c->n_lanes = 4 * c->n_stage_streams;
         /* Frames whose points are in slot order up to a tail (a sweep written row by row with dropped returns ABSENT — none
          * of the reference's three selectors writes exactly that: KITTI's structured clouds and MulRan's firing order have
          * routes of their own, kFrameStructured / kFrameColMajor, Oxford's file order goes the general way) are read in place: no order
@@ -815,15 +815,13 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
         c->allow_stream = !(sm && atoi(sm) == 0);
         if (const char *mt = getenv("BEV_MODE_TTL")) c->mode_ttl = std::max(1, atoi(mt));
     }
-    {   /* streams of equal priority may be multiplexed onto ONE hardware queue (observed in round 2: two such streams never
-         * overlapped); streams of different priority get different queues */
+    {   /* EQUAL priorities (profiles/r06_experiments.txt): the launches of two such streams share the chip workgroup by workgroup,
+         * 396-400 k frames/s where different priorities (the higher stream's launch dispatched first, whole) gave 384-386 k
+         * and one stream 368-370 k on the same box */
         int prio_least = 0, prio_greatest = 0;
         CK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        for (int q = 0; q < 2; ++q) {
-            const char *pe = getenv("BEV_STAGE_PRIO"); /* experiment: 0 equal priorities, 2 the other stream first */
-            const int pm = pe ? atoi(pe) : 0;
-            const int pr = pm == 0 ? prio_greatest : (pm == 2 ? prio_greatest + (1 - q) : prio_greatest + q);
-            CK(hipStreamCreateWithPriority(&c->stage_st[q], hipStreamNonBlocking, std::min(prio_least, pr)));
+        for (int q = 0; q < kMaxStageStreams; ++q) {
+            CK(hipStreamCreateWithPriority(&c->stage_st[q], hipStreamNonBlocking, prio_greatest));
             CK(hipEventCreateWithFlags(&c->stage_ev[q], hipEventDisableTiming));
         }
         CK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
@@ -882,7 +880,7 @@ void bev_destroy(bev_ctx_t *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     c->pending.clear(); /* (stages never launched: their outputs were never waited for) */
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < kMaxStageStreams; ++q) {
         if (c->stage_st[q]) (void)hipStreamSynchronize(c->stage_st[q]);
         if (c->stage_ev[q]) (void)hipEventDestroy(c->stage_ev[q]);
         if (c->stage_st[q]) (void)hipStreamDestroy(c->stage_st[q]);
