@@ -272,7 +272,7 @@ def main() -> int:
     # which part of B_frame each kernel is the one to move (DESIGN.md "Kernels"): the input is counted ONCE, for the kernel
     # whose read of it cannot be avoided — the column walk when P ~ S (it gathers every point it writes), the order scan
     # when P >> S (oxford_concat: 2 M points into 33,792 slots; the walk then only gathers the S winners)
-    if args.workload == "oxford_concat":
+    if args.workload in ("oxford_concat", "hdl64_shuffled"):  # (shuffled: scattered atomics make the scan the longest kernel; it is the one that streams the input)
         own_bytes = {"k_order_scan": 32.0 * mean_pts, "k_walk": 32.0 * S, "k_walk_general": 32.0 * S,
                      "k_bev_raster": float(L * M * M + M * M)}
     else:  # k_walk: frames read in place; k_walk_general: frames that go through the winner table (only one of the two moves a frame)
