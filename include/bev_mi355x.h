@@ -138,7 +138,10 @@ int bev_process_batch(bev_ctx_t *ctx, int n_frames,
  * or by bev_synchronize() (and by every other entry point of the context).
  * A bare hipDeviceSynchronize() is therefore NOT enough: bev_synchronize()
  * launches what is pending, then waits.  The buffers of a call must stay
- * valid until then. */
+ * valid until then.  Work the caller has queued on the DEFAULT stream before
+ * the call (an upload or a fill of these buffers) is waited for on the device;
+ * work on other streams of the caller's is the caller's to synchronise with:
+ * the library's streams are non-blocking. */
 int bev_process_device_resident(bev_ctx_t *ctx, int n_frames,
                                 const bev_point_t *d_pts,
                                 const uint64_t *h_offsets,

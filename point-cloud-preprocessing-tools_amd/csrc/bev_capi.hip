@@ -138,7 +138,7 @@ struct bev_ctx {
      * stream's launch, and nothing but the order of launches on ONE stream ever orders two stages of one sub-batch */
     hipStream_t stage_st[kMaxStageStreams] = {};
     hipEvent_t stage_ev[kMaxStageStreams] = {};
-    hipEvent_t fork_ev = nullptr;
+    hipEvent_t fork_ev = nullptr, null_ev = nullptr;
     int n_stage_streams = 2;   /* BEV_STAGE_STREAMS=1 .. 4 (1: a launch's tail stands empty; 3, 4: measured like 2, with 12 / 16 workspace sets) */
     unsigned sub_seq = 0;      /* sub-batches so far */
     /* fused: a sub-batch's stages ride in consecutive k_stage launches beside the stages of its neighbours (run_pipeline);
@@ -503,6 +503,14 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         HIPCK(c, hipEventRecord(c->fork_ev, c->stream));
         for (int q = 0; q < kMaxStageStreams; ++q) HIPCK(c, hipStreamWaitEvent(c->stage_st[q], c->fork_ev, 0));
     }
+    if (!fork && !identity) {
+        /* device pointers from the caller: whatever it has queued on the default stream up to now — the upload or the fill of
+         * these very buffers, typically — comes first (the library's streams are non-blocking: nothing else orders them behind
+         * it; work on OTHER streams of the caller's is the caller's to wait for) */
+        HIPCK(c, hipEventRecord(c->null_ev, nullptr));
+        if (!fused) HIPCK(c, hipStreamWaitEvent(c->stream, c->null_ev, 0));
+        for (int q = 0; fused && q < c->n_stage_streams; ++q) HIPCK(c, hipStreamWaitEvent(c->stage_st[q], c->null_ev, 0));
+    }
 
     int ds = 0;
     if (!identity) {
@@ -825,6 +833,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
             CK(hipEventCreateWithFlags(&c->stage_ev[q], hipEventDisableTiming));
         }
         CK(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&c->null_ev, hipEventDisableTiming));
     }
     CK(hipHostMalloc((void **)&c->hint, 2 * sizeof(uint32_t), hipHostMallocMapped));
     c->hint[0] = 0xffffffffu; /* nothing known yet: the first order scan is launched wide, */
@@ -886,6 +895,7 @@ void bev_destroy(bev_ctx_t *c)
         if (c->stage_st[q]) (void)hipStreamDestroy(c->stage_st[q]);
     }
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->null_ev) (void)hipEventDestroy(c->null_ev);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (int l = 0; l < kMaxLanes; ++l) {

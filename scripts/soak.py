@@ -73,6 +73,7 @@ for rnd in range(rounds):
     d_in = torch.from_numpy(np.concatenate(frames).view(np.uint8).reshape(-1)).to(dev)
     d_ord = torch.zeros(n * S * 32, dtype=torch.uint8, device=dev)
     d_multi = torch.zeros(n * L * M * M, dtype=torch.uint8, device=dev); d_single = torch.zeros(n * M * M, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()  # torch's fills and copies run on ITS stream; the library's streams do not wait for it
     for _ in range(2):
         ctx.process_device(n, d_in.data_ptr(), offs, d_ord.data_ptr(), d_multi.data_ptr(), d_single.data_ptr())
     ctx.synchronize()
