@@ -325,32 +325,34 @@ def test_shuffled_sweeps_at_launch_size_every_frame_matches_oracle():
 
 def test_buffers_filled_on_the_default_stream_right_before_the_call():
     """The library's streams are non-blocking; what the caller has queued on the DEFAULT stream before a device-resident call
-    — here torch's zero-fill of the very output buffers, 1.4 GB of it, and the upload's tail — is waited for on the device
-    (an event on the default stream at the head of every call).  Without that the fills land on top of the first outputs
-    (round 6's soak found it: the fused launches start writing sooner than round 5's pipeline did)."""
+    — here torch's fill of the very output buffers, 5.6 GB of it — is waited for on the device (an event on the default stream
+    at the head of every call).  Without that the fill's tail lands on top of the second sub-batch's outputs (round 6's soak
+    found it: the fused launches of BOTH streams start writing at once)."""
     import torch
 
     p = bev_amd.params_for_sensor("HDL_64E")
-    frames = [synth.sweep(p, 7000 + f, keep=0.97, n_dup=1000) for f in range(N_FRAMES)]
+    n = 1000
+    base = [synth.sweep(p, 7000 + f, keep=0.97, n_dup=1000) for f in range(40)]
+    frames = [base[f % len(base)] for f in range(n)]
     sp = orc.sensor_from_params(p)
+    want = [orc.process_frame(sp, f, want_gm=False) for f in base]
     dev = torch.device("cuda:0")
     S, M, L = p.slots, p.mat_size, p.n_layers
-    offs = np.zeros(len(frames) + 1, np.uint64)
+    offs = np.zeros(n + 1, np.uint64)
     offs[1:] = np.cumsum([len(f) for f in frames])
-    ctx = bev_amd.BevContext(p, device=0, max_batch=100, max_points=max(len(f) for f in frames))
+    ctx = bev_amd.BevContext(p, device=0, max_batch=500, max_points=max(len(f) for f in frames))
     try:
-        for rep in range(3):
+        d_in = torch.from_numpy(np.concatenate(frames).view(np.uint8).reshape(-1)).to(dev)
+        for rep in range(2):
             torch.cuda.synchronize()
-            d_in = torch.from_numpy(np.concatenate(frames).view(np.uint8).reshape(-1)).to(dev)
-            outs = [torch.full((len(frames) * k,), 0x5A, dtype=torch.uint8, device=dev) for k in (S * 32, L * M * M, M * M)]
-            ctx.process_device(len(frames), d_in.data_ptr(), offs, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr())   # no synchronisation in between
+            outs = [torch.full((n * k,), 0x5A, dtype=torch.uint8, device=dev) for k in (S * 32, L * M * M, M * M)]
+            ctx.process_device(n, d_in.data_ptr(), offs, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr())   # no synchronisation in between
             ctx.synchronize()
-            got = [o.cpu().numpy() for o in outs]
-            for i in (0, 1, 50, 99, 100, 199, N_FRAMES - 1):
-                o_ord, _, o_multi, o_single = orc.process_frame(sp, frames[i], want_gm=False)
-                assert got[0][i * S * 32:(i + 1) * S * 32].tobytes() == o_ord.tobytes(), (rep, i)
-                assert got[1][i * L * M * M:(i + 1) * L * M * M].tobytes() == o_multi.tobytes(), (rep, i)
-                assert got[2][i * M * M:(i + 1) * M * M].tobytes() == o_single.tobytes(), (rep, i)
-            del d_in, outs
+            for i in (0, 1, 250, 499, 500, 501, 640, 777, 900, 998, 999):
+                o_ord, _, o_multi, o_single = want[i % len(base)]
+                assert outs[0][i * S * 32:(i + 1) * S * 32].cpu().numpy().tobytes() == o_ord.tobytes(), (rep, i)
+                assert outs[1][i * L * M * M:(i + 1) * L * M * M].cpu().numpy().tobytes() == o_multi.tobytes(), (rep, i)
+                assert outs[2][i * M * M:(i + 1) * M * M].cpu().numpy().tobytes() == o_single.tobytes(), (rep, i)
+            del outs
     finally:
         ctx.close()
