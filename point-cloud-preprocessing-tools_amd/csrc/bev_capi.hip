@@ -26,7 +26,7 @@ using namespace bevk;
 
 namespace {
 
-constexpr int kDescRing = 16;
+constexpr int kDescRing = 4; /* calls the host may run ahead of the device (2 and 12 measured the same) */
 constexpr int kEventPairs = 2048;
 
 struct ProfSlot {
@@ -128,7 +128,6 @@ struct bev_ctx {
     int win_shift = 32;  /* bits an input index + 1 needs; the rest of a winner entry is the generation tag */
     size_t multi_bytes = 0, single_bytes = 0;
     hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;
 
     /* sub-batch workspace sets; the aliases below are lane 0's */
     Lane lanes[kMaxLanes];
@@ -172,11 +171,9 @@ struct bev_ctx {
     FrameDesc *h_desc[kDescRing] = {nullptr, nullptr, nullptr, nullptr};
     FrameDesc *d_desc[kDescRing] = {nullptr, nullptr, nullptr, nullptr}; /* the device's address of h_desc (mapped host memory) */
     size_t desc_cap[kDescRing] = {0, 0, 0, 0};
-    hipEvent_t desc_copied[kDescRing]{};
     hipEvent_t desc_done[kDescRing]{};
     bool desc_used[kDescRing] = {false, false, false, false};
     int desc_next = 0;
-    int desc_ring = 4; /* calls the host may run ahead of the device */
 
     /* staging for the host-buffer entry points (lazily allocated) */
     bev_point_t *st_in = nullptr;
@@ -380,7 +377,7 @@ struct ProfScope {
 int acquire_desc(bev_ctx *c, size_t n, int *slot_out)
 {
     const int k = c->desc_next;
-    c->desc_next = (k + 1) % c->desc_ring;
+    c->desc_next = (k + 1) % kDescRing;
     if (c->desc_used[k]) HIPCK(c, hipEventSynchronize(c->desc_done[k]));
     if (c->desc_cap[k] < n) {
         if (c->h_desc[k]) HIPCK(c, hipHostFree(c->h_desc[k]));
@@ -800,9 +797,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
 
     CK(hipSetDevice(device));
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (int k = 0; k < kDescRing; ++k) {
-        CK(hipEventCreateWithFlags(&c->desc_copied[k], hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&c->desc_done[k], hipEventDisableTiming));
     }
     const size_t S = (size_t)c->geo.S, nb = (size_t)max_batch;
@@ -897,7 +892,6 @@ void bev_destroy(bev_ctx_t *c)
     if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
     if (c->null_ev) (void)hipEventDestroy(c->null_ev);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (int l = 0; l < kMaxLanes; ++l) {
         Lane &ln = c->lanes[l];
         void *ws[] = {ln.info, ln.est, ln.tail_list, ln.tail_cnt, ln.cm_par, ln.cm_sync, ln.winner, ln.cand, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
@@ -918,7 +912,6 @@ void bev_destroy(bev_ctx_t *c)
         if (p) (void)hipFree(p);
     for (int k = 0; k < kDescRing; ++k) {
         if (c->h_desc[k]) (void)hipHostFree(c->h_desc[k]);
-        if (c->desc_copied[k]) (void)hipEventDestroy(c->desc_copied[k]);
         if (c->desc_done[k]) (void)hipEventDestroy(c->desc_done[k]);
     }
     for (auto &s : c->prof_pool) {
@@ -926,7 +919,6 @@ void bev_destroy(bev_ctx_t *c)
         if (s.b) (void)hipEventDestroy(s.b);
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
 }
 
