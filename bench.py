@@ -36,8 +36,8 @@ WALK_SHAPE_CEILING_GBPS = 5010.0
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps (a step = the whole path over the frames; 20 x 2.5 ms: the bench is mostly set-up and the CPU baseline)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU (BASELINE config: 1000)")
     ap.add_argument("--sensor", default=None)
     ap.add_argument("--workload", default="hdl64_sweep", choices=["hdl64_sweep", "os1_firing", "oxford_concat", "hdl64_structured", "os1_firing_real", "mixed", "hdl64_shuffled"],
