@@ -404,6 +404,18 @@ int ensure_gm(bev_ctx *c)
 /* ---- the stages of earlier sub-batches that have not been launched yet ------------------------------------------- */
 /* Fills the later-stage parts of a fused launch from the pending sub-batches: each is advanced by ONE stage.  With every
  * launch advancing every pending sub-batch there is at most one per stage. */
+/* (the invariant: every launch of a stream advances every pending sub-batch of that stream by one stage and adds at most one
+ * new one, so no two of them wait for the same stage; should it ever not hold, the caller launches what is pending first) */
+bool pending_is_consistent(const bev_ctx *c, int q)
+{
+    unsigned seen = 0u;
+    for (const bev_ctx::Pending &p : c->pending) {
+        if (p.q != q) continue;
+        if (p.next < 1 || p.next > 3 || (seen & (1u << p.next))) return false;
+        seen |= 1u << p.next;
+    }
+    return true;
+}
 void take_pending(bev_ctx *c, StageArgs *a, int q)
 {
     a->sums = StagePart{};
@@ -567,6 +579,10 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                 a.walk.nf = nb;
                 a.want_mode = mode;
                 a.lead = c->stage_lead;
+                if (!pending_is_consistent(c, q)) {
+                    const int rc_ = flush_pending(c);
+                    if (rc_ != BEV_OK) return rc_;
+                }
                 take_pending(c, &a, q);
                 {
                     ProfScope ps(c, K_STAGE, nb, st);
