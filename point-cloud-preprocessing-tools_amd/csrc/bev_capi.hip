@@ -43,6 +43,7 @@ constexpr int kMaxStageStreams = 4;
 constexpr int kMaxLanes = 4 * kMaxStageStreams;
 struct Lane {
     FrameInfo *info = nullptr;  /* per frame: how its points reach their slots (k_probe / k_verdict) */
+    FrameDesc *desc = nullptr;  /* per frame: k_probe's device copy of the caller's descriptor */
     uint32_t *est = nullptr;    /* stream frames: estimated input position of every (row, strip)'s first slot */
     uint32_t *tail_list = nullptr, *tail_cnt = nullptr; /* ... and their tail points per (row, strip) (stream mode only) */
     int32_t *cm_par = nullptr;   /* firing-order frames: direction and row bases (k_probe) */
@@ -547,7 +548,9 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
         ++c->sub_seq;
         BatchPtrs b{};
         b.pts = identity ? d_pts + (size_t)f0 * S : d_pts;
-        b.frames = identity ? nullptr : c->d_desc[ds] + f0;
+        b.frames = identity ? nullptr : ln.desc;
+        b.frames_src = identity ? nullptr : c->d_desc[ds] + f0;
+        b.frames_copy = identity ? nullptr : ln.desc;
         b.info = identity ? nullptr : ln.info;
         b.est = ln.est;
         b.tail_list = ln.tail_list;
@@ -851,6 +854,7 @@ int bev_create(bev_ctx_t **out, int device, const bev_params_t *p, int max_batch
     c->hint[1] = 0xffffffffu; /* ... every walk is launched */
     for (int l = 0; l < c->n_lanes; ++l) {
         Lane &ln = c->lanes[l];
+        CK(hipMalloc((void **)&ln.desc, nb * sizeof(FrameDesc)));
         CK(hipMalloc((void **)&ln.info, nb * sizeof(FrameInfo)));
         CK(hipMemset(ln.info, 0, nb * sizeof(FrameInfo)));
         CK(hipMalloc((void **)&ln.est, nb * (size_t)c->geo.N * c->geo.strips * sizeof(uint32_t)));
@@ -910,7 +914,7 @@ void bev_destroy(bev_ctx_t *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int l = 0; l < kMaxLanes; ++l) {
         Lane &ln = c->lanes[l];
-        void *ws[] = {ln.info, ln.est, ln.tail_list, ln.tail_cnt, ln.cm_par, ln.cm_sync, ln.winner, ln.cand, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
+        void *ws[] = {ln.desc, ln.info, ln.est, ln.tail_list, ln.tail_cnt, ln.cm_par, ln.cm_sync, ln.winner, ln.cand, ln.ncand, ln.code_main, ln.ncode, ln.avg, ln.gm};
         for (void *p : ws)
             if (p) (void)hipFree(p);
     }

@@ -45,7 +45,8 @@ __device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, cons
     uint32_t &first_bad = lds_p.first_bad, &overflow = lds_p.overflow;
     auto &tcnt = lds_p.u.tcnt;
     const int tid = threadIdx.x;
-    const FrameDesc fd = b.frames[f];
+    const FrameDesc fd = b.frames_src ? b.frames_src[f] : b.frames[f];
+    if (b.frames_copy && threadIdx.x == 0) b.frames_copy[f] = fd; /* (every later kernel of the sub-batch reads this copy: device memory) */
     const uint32_t n = fd.n_pts;
     const bev_point_t *fp = b.pts + fd.in_offset;
     const uint32_t stride = (n != (uint32_t)g.S && n >= (uint32_t)g.S - (uint32_t)g.S / 10u) ? (uint32_t)kProbeStrideDense : (uint32_t)kProbeStride;

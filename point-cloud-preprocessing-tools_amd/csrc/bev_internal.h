@@ -159,7 +159,9 @@ struct Geometry {
 /* device-side views of one sub-batch */
 struct BatchPtrs {
     const bev_point_t *pts;      /* packed input points (or ordered cloud in identity mode) */
-    const FrameDesc *frames;
+    const FrameDesc *frames;     /* [nf] where the walk and the scan read a frame's descriptor: device memory (k_probe's copy) or the host's mapped array */
+    const FrameDesc *frames_src; /* [nf] k_probe: the host's mapped array the caller's offsets were written to (16 bytes per frame over the link, once) */
+    FrameDesc *frames_copy;      /* [nf] k_probe writes its copy here (== frames), or nullptr */
     FrameInfo *info;             /* [nf] (nullptr: every frame general) */
     uint32_t *est;               /* [nf][strips][N]: stream frames: estimated input position of slot (r, first column of strip - 2) */
     uint32_t *tail_list;         /* [nf][N][strips][kTailCap]: stream frames: column offset | input index << 8 of the tail points (nullptr: no stream mode) */
