@@ -356,3 +356,60 @@ def test_buffers_filled_on_the_default_stream_right_before_the_call():
             del outs
     finally:
         ctx.close()
+
+
+def test_other_entry_points_and_mode_switches_between_asynchronous_calls():
+    """What a device-resident call leaves pending must survive whatever the caller does next with the context: a
+    single-cloud entry point (they use workspace set 0 and the context's own stream: they launch what is pending first), a
+    switch to serial launches and back (bev_set_lanes), a host-buffer call.  Every device-resident call has its own
+    buffers and is checked after ONE final bev_synchronize."""
+    import torch
+
+    p = bev_amd.params_for_sensor("HDL_32E")
+    sp = orc.sensor_from_params(p)
+    dev = torch.device("cuda:0")
+    S, M, L = p.slots, p.mat_size, p.n_layers
+    sb = 6
+    ctx = bev_amd.BevContext(p, device=0, max_batch=sb, max_points=40000)
+
+    def stage(frames):
+        offs = np.zeros(len(frames) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(f) for f in frames])
+        d_in = torch.from_numpy(np.concatenate(frames).view(np.uint8).reshape(-1)).to(dev)
+        outs = [torch.zeros(len(frames) * k, dtype=torch.uint8, device=dev) for k in (S * 32, L * M * M, M * M)]
+        return frames, offs, d_in, outs
+
+    calls = [stage([synth.sweep(p, 15000 + 20 * c + i, keep=0.9, n_dup=100 * c) for i in range(n)]) for c, n in enumerate((13, 5, 9, 17, 6, 11))]
+    single = synth.sweep(p, 15999, keep=0.8)
+    torch.cuda.synchronize()
+    try:
+        def go(k):
+            frames, offs, d_in, outs = calls[k]
+            ctx.process_device(len(frames), d_in.data_ptr(), offs, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr())
+
+        go(0)
+        o = ctx.order_cloud(single)                                  # a single-cloud entry point in between
+        assert o.tobytes() == orc.order_cloud(sp, single).tobytes()
+        go(1)
+        assert ctx.set_lanes(1) == 1                                 # serial launches ...
+        go(2)
+        assert ctx.set_lanes(2) > 1                                  # ... and fused again
+        go(3)
+        ordered, multi, single_bev, _ = ctx.process_batch([single, single[:1000]])   # a host-buffer call in between
+        for i, pts in enumerate([single, single[:1000]]):
+            o_ord, _, o_multi, o_single = orc.process_frame(sp, pts, want_gm=False)
+            assert ordered[i].tobytes() == o_ord.tobytes() and np.array_equal(multi[i], o_multi) and np.array_equal(single_bev[i], o_single)
+        go(4)
+        mb = ctx.multi_bev(single)                                   # (raster of an arbitrary cloud)
+        assert np.array_equal(mb.reshape(L, M, M), orc.multi_bev(sp, single))
+        go(5)
+        ctx.synchronize()
+        for c, (frames, _, _, outs) in enumerate(calls):
+            got = [t.cpu().numpy() for t in outs]
+            for i, pts in enumerate(frames):
+                o_ord, _, o_multi, o_single = orc.process_frame(sp, pts, want_gm=False)
+                assert got[0][i * S * 32:(i + 1) * S * 32].tobytes() == o_ord.tobytes(), (c, i)
+                assert got[1][i * L * M * M:(i + 1) * L * M * M].tobytes() == o_multi.tobytes(), (c, i)
+                assert got[2][i * M * M:(i + 1) * M * M].tobytes() == o_single.tobytes(), (c, i)
+    finally:
+        ctx.close()
