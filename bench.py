@@ -5,7 +5,9 @@ Workload (BASELINE.json configs[1]; configs[3] is the same per GPU): 1000
 synthetic KITTI-like HDL_64E clouds (~135.6k input points each into 133,312
 slots) per GPU, resident in HBM; one "step" = one pass of the whole hot path
 (order -> ground segmentation -> multi + single BEV) over those 1000 frames,
-outputs left in HBM.  N > 1: one process per GPU (torch.distributed, backend
+outputs left in HBM.  The timed region runs the library's default mode — fused launches
+(k_stage) over two streams —, the roofline of the dominant kernel comes from a pass of the
+same steps with one launch per kernel (bev_set_lanes(ctx, 1)).  N > 1: one process per GPU (torch.distributed, backend
 nccl = RCCL), frames sharded contiguously, the only collective on the path is
 the broadcast of the frame-range table; weak scaling (1000 frames per GPU).
 
@@ -50,8 +52,8 @@ def main() -> int:
                          "order scan + gather walk —, the route of any layout the probe does not recognise and of every frame that "
                          "fails its checks; not the graded metric)")
     ap.add_argument("--sub-batch", type=int, default=int(os.environ.get("BEV_SUB_BATCH", "500")),
-                    help="frames per sub-batch of the two-stage pipeline (500: two sub-batches per 1000-frame step; measured "
-                         "300-309 k frames/s against 288-297 k at 256 on the same box)")
+                    help="frames per sub-batch (= per fused launch: a sub-batch's walk beside the later stages of earlier ones; 500: two per "
+                         "1000-frame step; 125 / 250 / 334 / 1000 measured 2-3 % behind 500, profiles/r06_experiments.txt)")
     ap.add_argument("--n-dup", type=int, default=int(os.environ.get("BEV_BENCH_NDUP", "5000")),
                     help="duplicates appended to every hdl64_sweep frame (BASELINE config 2: 5000; anything else is a "
                          "developer experiment and is named in config.workload)")
@@ -336,7 +338,7 @@ def main() -> int:
             "kernel": dom["name"], "frames_per_launch": per_launch_frames,
             "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": avg_ms,
             "note": "kernel durations from a one-lane pass of the same steps right after the timed region (back-to-back launches); "
-                    "the timed region itself runs the two-stage pipeline (front of sub-batch k+1 beside the back of sub-batch k)",
+                    "the timed region itself runs FUSED launches (k_stage: a sub-batch's walk beside the later stages of earlier sub-batches, two streams)",
             "pipeline": {"bytes_per_frame": b_frame, "achieved": pipe_achieved, "frac": pipe_achieved / HBM_PEAK_GBPS,
                          "hbm_traffic_per_frame_all_kernels": traffic_total,
                          "real_traffic_gbps": (traffic_total * frames_per_s / 1e9) if traffic_total else None,

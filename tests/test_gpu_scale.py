@@ -105,7 +105,7 @@ def test_winner_generation_wraps():
 @pytest.mark.parametrize("layout,sub_batch", [("sweep", 500), ("sweep", 256), ("structured", 500)])
 def test_baseline_config_every_frame_matches_oracle(layout, sub_batch):
     """BASELINE configs[1] as bench.py runs it (1000 HDL_64E frames, sub-batches of 500 — bench.py's default launch
-    size — and of 256, the two-stage pipeline, three back-to-back asynchronous steps over the same buffers): EVERY frame
+    size — and of 256, fused launches over two streams, three back-to-back asynchronous steps over the same buffers): EVERY frame
     of the last step against the oracle.  "structured": the same sweeps in the layout the KITTI selector writes
     (bench.py --workload hdl64_structured)."""
     from concurrent.futures import ThreadPoolExecutor
