@@ -587,7 +587,20 @@ int run_pipeline(bev_ctx *c, int n_frames, const bev_point_t *d_pts, const uint6
                     if (rc_ != BEV_OK) return rc_;
                 }
                 take_pending(c, &a, q);
-                {
+                if (source == 4 || source == 5) {
+                    /* the firing-order walks need 50-53 KB of LDS, three workgroups per CU — fused, every stage of the launch
+                     * would run three per CU; so the walk is a launch of its own and the later stages a fused launch without a
+                     * walk behind it, four per CU (same box, three passes: config 3 + 0.3 ... 1.8 %, real MulRan sweeps + 2.1 ...
+                     * 3.3 %; profiles/r06_experiments.txt) */
+                    {
+                        ProfScope ps(c, kid, nb, st);
+                        launch_gather_ground(g, b, nb, source, mode, st);
+                    }
+                    a.walk.nf = 0;
+                    a.lead = 0;
+                    ProfScope ps(c, K_STAGE, 0, st);
+                    launch_stage(a, -1, st);
+                } else {
                     ProfScope ps(c, K_STAGE, nb, st);
                     launch_stage(a, source, st);
                 }

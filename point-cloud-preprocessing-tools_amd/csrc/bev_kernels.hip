@@ -64,9 +64,10 @@ const char *kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kNames[id] 
  * short workgroups of the later stages (a launch's tail is as long as its last workgroups live).  The stages of ONE
  * sub-batch meet only through the order of launches on the stream. */
 template <int kSrc, bool kPow2, bool kGm>
-__global__ __launch_bounds__(kStageThreads, (kSrc == kSrcColMajor || kSrc == kSrcColMajorGen) ? 3 : 4) void k_stage(StageArgs a)
+__global__ __launch_bounds__(kStageThreads, 4) void k_stage(StageArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char stage_arena[];
+    static_assert(kSrc != kSrcColMajor && kSrc != kSrcColMajorGen, "the firing-order walks are launched apart");
     static_assert(kStripThreads == kStageThreads && kSumThreads == kStageThreads && kResolveThreads == kStageThreads && kRasterThreads == kStageThreads, "one workgroup shape");
     const int bid = (int)blockIdx.x, x = bid & 7, j = bid >> 3;
     const int strips = a.g.strips;
@@ -103,8 +104,7 @@ size_t stage_lds_bytes(const Geometry &g, int source)
     case kSrcIdentity: w = walk_lds_bytes<kSrcIdentity>(); break;
     case kSrcInPlace: w = walk_lds_bytes<kSrcInPlace>(); break;
     case kSrcStructured: w = walk_lds_bytes<kSrcStructured>(); break;
-    case kSrcColMajor: w = walk_lds_bytes<kSrcColMajor>(); break;
-    case kSrcColMajorGen: w = walk_lds_bytes<kSrcColMajorGen>(); break;
+    /* (the firing-order walks are never fused: 50-53 KB of LDS would hold every stage of the launch to three per CU) */
     default: w = walk_lds_bytes<kSrcGather>(); break;
     }
     const size_t others = std::max(std::max(SumDims::lds_bytes(g.segs), sizeof(ResolveLds)), raster_lds_bytes(g));
@@ -136,9 +136,7 @@ void launch_stage(const StageArgs &a, int source, hipStream_t st)
     if (source == kSrcIdentity) launch_stage_src<kSrcIdentity>(a, st);
     else if (source == kSrcInPlace) launch_stage_src<kSrcInPlace>(a, st);
     else if (source == kSrcStructured) launch_stage_src<kSrcStructured>(a, st);
-    else if (source == kSrcColMajor) launch_stage_src<kSrcColMajor>(a, st);
-    else if (source == kSrcColMajorGen) launch_stage_src<kSrcColMajorGen>(a, st);
-    else launch_stage_src<kSrcGather>(a, st);
+    else launch_stage_src<kSrcGather>(a, st); /* (kSrcColMajor / kSrcColMajorGen: launched apart, see run_pipeline) */
 }
 
 /* ------------------------------------------------------------------------- */
