@@ -144,7 +144,11 @@ __device__ __forceinline__ void resolve_body(char *arena, const BatchPtrs &b, co
             const int n = sg < t1 ? (int)cnt[sg - t0] : 0; /* wave-uniform */
 #pragma unroll
             for (int k = 0; k < kSl; ++k) { /* whole slices, nothing but the loads inside the uniform test (see k_cell_sums) */
-                const size_t at = (size_t)(sg < t1 ? sg : t0) * kSeg + lane + 64 * k;
+                /* (lanes past the segment's count read its last candidate again — a sector that moves anyway — instead of the
+                 * stale entries behind it: a segment holds 140 candidates on average, three slices of 64 fetched 192: a quarter
+                 * of this kernel's read bytes) */
+                const int last = n > 0 ? n - 1 : 0, mine = lane + 64 * k;
+                const size_t at = (size_t)(sg < t1 ? sg : t0) * kSeg + (size_t)(mine < last ? mine : last);
                 key_n[j][k] = 0u;
                 z_n[j][k] = 0.f;
                 if (64 * k < __builtin_amdgcn_readfirstlane(n)) {
