@@ -49,7 +49,11 @@ __device__ __forceinline__ void probe_body(char *arena, const BatchPtrs &b, cons
     if (b.frames_copy && threadIdx.x == 0) b.frames_copy[f] = fd; /* (every later kernel of the sub-batch reads this copy: device memory) */
     const uint32_t n = fd.n_pts;
     const bev_point_t *fp = b.pts + fd.in_offset;
-    const uint32_t stride = (n != (uint32_t)g.S && n >= (uint32_t)g.S - (uint32_t)g.S / 10u) ? (uint32_t)kProbeStrideDense : (uint32_t)kProbeStride;
+    /* (frames of exactly S records may be in firing order: position k = beam k % N — a stride that shares a factor with N
+     * would never sample some beams (63 = 3 * 3 * 7 against a 33- or a 7-beam sensor: their rows took another row's base and
+     * failed the walk's checks); 61 is prime) */
+    const uint32_t stride = (n != (uint32_t)g.S && n >= (uint32_t)g.S - (uint32_t)g.S / 10u) ? (uint32_t)kProbeStrideDense
+                            : ((n == (uint32_t)g.S && (g.N % 3 == 0 || g.N % 7 == 0)) ? 61u : (uint32_t)kProbeStride);
     const uint32_t ns = n ? (n - 1u) / stride + 1u : 0u;
     PH_DECL;
     PH();
