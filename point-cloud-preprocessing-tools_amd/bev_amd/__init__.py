@@ -136,7 +136,10 @@ def load_lib() -> C.CDLL:
     lib.bev_project_out_points.argtypes = [i32, u32]
     lib.bev_project_out_points.restype = C.c_size_t
     lib.bev_set_lanes.argtypes = [vp, i32]
-    lib.bev_set_layout_hint.argtypes = [vp, i32]
+    try:  # (an older build of the library, selected with BEV_AMD_LIB for a same-box A/B: scripts/ab_libs.sh)
+        lib.bev_set_layout_hint.argtypes = [vp, i32]
+    except AttributeError:
+        pass
     lib.bev_profile_enable.argtypes = [vp, i32]
     lib.bev_profile_reset.argtypes = [vp]
     lib.bev_profile_get.argtypes = [vp, C.POINTER(KernelStat), i32]
