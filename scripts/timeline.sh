@@ -1,8 +1,7 @@
-# kernel timeline (start/end per dispatch) of the default multi-stream run, to see which kernels really overlap
+# kernel timeline (start/end per dispatch) of the default run (fused launches on two streams), to see which launches really overlap
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 OUT=$R/gpurun_out/timeline; rm -rf $OUT; mkdir -p $OUT
-export BEV_STAGED=${STAGED:-1}
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 bench.py --no-build --steps 3 --warmup 1 --no-cpu --no-profile > $OUT/bench.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
